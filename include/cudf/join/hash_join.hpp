@@ -1,0 +1,54 @@
+// SPDX-License-Identifier: Apache-2.0
+// cudf::hash_join — build once on `right`, probe many times. Signatures follow reference
+// cpp/include/cudf/join/hash_join.hpp:62 (nullable_join: YES == false!), :71 (class), ctor pair, inner_join,
+// left_join, full_join, *_join_size. Probes are const and may run concurrently on different streams.
+#pragma once
+#include <cudf/join/join.hpp>
+#include <memory>
+#include <optional>
+
+namespace cudf {
+namespace detail {
+class hash_join_impl;
+}
+
+// NOTE: YES has the value `false` (reference hash_join.hpp:62) — compare against the enumerator.
+enum class nullable_join : bool { YES, NO };
+
+class hash_join {
+ public:
+  hash_join() = delete;
+  ~hash_join();
+  hash_join(hash_join const&)            = delete;
+  hash_join(hash_join&&)                 = delete;
+  hash_join& operator=(hash_join const&) = delete;
+  hash_join& operator=(hash_join&&)      = delete;
+
+  hash_join(table_view const& right, null_equality compare_nulls,
+            stream_ref stream                 = get_default_stream(),
+            rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+  hash_join(table_view const& right, nullable_join has_nulls, null_equality compare_nulls, double load_factor,
+            stream_ref stream                 = get_default_stream(),
+            rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+
+  [[nodiscard]] join_index_pair inner_join(table_view const& left,
+                                           std::optional<std::size_t> output_size = {},
+                                           stream_ref stream                      = get_default_stream(),
+                                           rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] join_index_pair left_join(table_view const& left,
+                                          std::optional<std::size_t> output_size = {},
+                                          stream_ref stream                      = get_default_stream(),
+                                          rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] join_index_pair full_join(table_view const& left,
+                                          std::optional<std::size_t> output_size = {},
+                                          stream_ref stream                      = get_default_stream(),
+                                          rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] std::size_t inner_join_size(table_view const& left, stream_ref stream = get_default_stream()) const;
+  [[nodiscard]] std::size_t left_join_size(table_view const& left, stream_ref stream = get_default_stream()) const;
+  [[nodiscard]] std::size_t full_join_size(table_view const& left, stream_ref stream = get_default_stream(),
+                                           rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+
+ private:
+  std::unique_ptr<detail::hash_join_impl const> _impl;
+};
+}  // namespace cudf

@@ -1,0 +1,87 @@
+// SPDX-License-Identifier: Apache-2.0
+// Stream-ordered device memory resources for MI355X. The reference allocates every output through the
+// caller's `rmm::device_async_resource_ref` (e.g. cpp/include/cudf/groupby.hpp:181-184) and temporaries
+// through cudf::get_current_device_resource_ref(); this is the HIP-native equivalent with the same shape:
+// a non-owning ref onto a polymorphic resource with allocate/deallocate(bytes, stream).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+
+namespace rmm {
+namespace mr {
+
+class device_memory_resource {
+ public:
+  virtual ~device_memory_resource() = default;
+  void* allocate(std::size_t bytes, hipStream_t stream) { return bytes ? do_allocate(bytes, stream) : nullptr; }
+  void deallocate(void* p, std::size_t bytes, hipStream_t stream) noexcept
+  {
+    if (p) do_deallocate(p, bytes, stream);
+  }
+
+ private:
+  virtual void* do_allocate(std::size_t bytes, hipStream_t stream)                    = 0;
+  virtual void do_deallocate(void* p, std::size_t bytes, hipStream_t stream) noexcept = 0;
+};
+
+// hipMallocAsync / hipFreeAsync on the device's default pool (release threshold raised so that 288 GB of
+// HBM3E is recycled instead of trimmed between calls). Throws std::bad_alloc on OOM.
+class hip_async_memory_resource final : public device_memory_resource {
+ public:
+  hip_async_memory_resource();
+
+ private:
+  void* do_allocate(std::size_t bytes, hipStream_t stream) override;
+  void do_deallocate(void* p, std::size_t bytes, hipStream_t stream) noexcept override;
+};
+
+// Counts live/peak bytes on top of another resource (benchmarks and leak tests).
+class statistics_resource_adaptor final : public device_memory_resource {
+ public:
+  explicit statistics_resource_adaptor(device_memory_resource* upstream) : _up{upstream} {}
+  [[nodiscard]] std::size_t current_bytes() const { return _cur; }
+  [[nodiscard]] std::size_t peak_bytes() const { return _peak; }
+  [[nodiscard]] std::size_t allocation_count() const { return _count; }
+  void reset_peak() { _peak = _cur; }
+
+ private:
+  void* do_allocate(std::size_t bytes, hipStream_t stream) override
+  {
+    void* p = _up->allocate(bytes, stream);
+    _cur += bytes;
+    ++_count;
+    if (_cur > _peak) _peak = _cur;
+    return p;
+  }
+  void do_deallocate(void* p, std::size_t bytes, hipStream_t stream) noexcept override
+  {
+    _up->deallocate(p, bytes, stream);
+    _cur -= bytes;
+  }
+  device_memory_resource* _up;
+  std::size_t _cur{0}, _peak{0}, _count{0};
+};
+
+device_memory_resource* get_current_device_resource();
+device_memory_resource* set_current_device_resource(device_memory_resource* mr);
+}  // namespace mr
+
+class device_async_resource_ref {
+ public:
+  device_async_resource_ref(mr::device_memory_resource* r) : _r{r} {}
+  device_async_resource_ref(mr::device_memory_resource& r) : _r{&r} {}
+  void* allocate_async(std::size_t bytes, hipStream_t s) { return _r->allocate(bytes, s); }
+  void deallocate_async(void* p, std::size_t bytes, hipStream_t s) noexcept { _r->deallocate(p, bytes, s); }
+  [[nodiscard]] mr::device_memory_resource* resource() const { return _r; }
+
+ private:
+  mr::device_memory_resource* _r;
+};
+}  // namespace rmm
+
+namespace cudf {
+inline rmm::device_async_resource_ref get_current_device_resource_ref()
+{
+  return rmm::device_async_resource_ref{rmm::mr::get_current_device_resource()};
+}
+}  // namespace cudf
