@@ -1,0 +1,74 @@
+"""ctypes loader for libcudf_amd.so (the HIP/gfx950 library). There is NO CPU fallback: if the shared library
+is missing or fails to load, importing the product fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcudf_amd.so")
+
+
+class ColumnView(C.Structure):
+    _fields_ = [("type_id", C.c_int32), ("size", C.c_int32), ("data", C.c_void_p), ("null_mask", C.c_void_p),
+                ("null_count", C.c_int32), ("offset", C.c_int32), ("scale", C.c_int32)]
+
+
+class AggregationRequest(C.Structure):
+    _fields_ = [("values", ColumnView), ("kinds", C.POINTER(C.c_int32)), ("num_kinds", C.c_int32)]
+
+
+# Every symbol declared in include/cudf_amd_c.h: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "cudf_amd_last_error": (C.c_char_p, []),
+    "cudf_amd_version": (C.c_char_p, []),
+    "cudf_amd_malloc": (C.c_int, [C.POINTER(_P), C.c_size_t, _P]),
+    "cudf_amd_free": (C.c_int, [_P, _P]),
+    "cudf_amd_memcpy": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, _P]),
+    "cudf_amd_memset": (C.c_int, [_P, C.c_int32, C.c_size_t, _P]),
+    "cudf_amd_stream_synchronize": (C.c_int, [_P]),
+    "cudf_amd_memory_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cudf_amd_table_num_columns": (C.c_int32, [_P]),
+    "cudf_amd_table_num_rows": (C.c_int32, [_P]),
+    "cudf_amd_table_column": (C.c_int, [_P, C.c_int32, C.POINTER(ColumnView)]),
+    "cudf_amd_table_free": (None, [_P]),
+    "cudf_amd_groupby_aggregate": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.c_int32, C.c_int32,
+                                             C.POINTER(AggregationRequest), C.c_int32, _P, C.POINTER(_P),
+                                             C.POINTER(_P), C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc, gfx950). cudf_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class CudfAmdError(RuntimeError):
+    """cudf::logic_error / device errors (pylibcudf maps these to RuntimeError)."""
+
+
+# status -> Python exception, as pylibcudf's exception_handler maps the C++ types
+# (reference python/pylibcudf/pylibcudf/exception_handler.pxd:34-64)
+def check(status):
+    if status == 0:
+        return
+    msg = load().cudf_amd_last_error().decode(errors="replace")
+    if status == 2:
+        raise ValueError(msg)
+    if status == 3:
+        raise TypeError(msg)
+    if status == 5:
+        raise MemoryError(msg)
+    raise CudfAmdError(msg)

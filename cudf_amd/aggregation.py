@@ -1,0 +1,96 @@
+"""Aggregation factories mirroring pylibcudf.aggregation (reference python/pylibcudf/pylibcudf/aggregation.pyi:16-114);
+Kind values are those of cudf::aggregation::Kind (cpp/include/cudf/aggregation.hpp:78-121)."""
+from enum import IntEnum
+
+from .types import NullPolicy
+
+
+class Kind(IntEnum):
+    SUM = 0
+    SUM_OVERFLOW = 1
+    PRODUCT = 2
+    MIN = 3
+    MAX = 4
+    COUNT_VALID = 5
+    COUNT_ALL = 6
+    ANY = 7
+    ALL = 8
+    SUM_OF_SQUARES = 9
+    MEAN = 10
+    M2 = 11
+    VARIANCE = 12
+    STD = 13
+    MEDIAN = 14
+    QUANTILE = 15
+    ARGMAX = 16
+    ARGMIN = 17
+    NUNIQUE = 18
+    NTH_ELEMENT = 19
+
+
+class Aggregation:
+    def __init__(self, kind: Kind):
+        self._kind = Kind(kind)
+
+    def kind(self) -> Kind:
+        return self._kind
+
+    def __repr__(self):
+        return f"Aggregation({self._kind.name})"
+
+
+def sum():
+    return Aggregation(Kind.SUM)
+
+
+def product():
+    return Aggregation(Kind.PRODUCT)
+
+
+def min():
+    return Aggregation(Kind.MIN)
+
+
+def max():
+    return Aggregation(Kind.MAX)
+
+
+def count(null_handling: NullPolicy = NullPolicy.INCLUDE):
+    # pylibcudf's default is INCLUDE (aggregation.pyi:76); EXCLUDE -> COUNT_VALID, INCLUDE -> COUNT_ALL
+    return Aggregation(Kind.COUNT_ALL if null_handling == NullPolicy.INCLUDE else Kind.COUNT_VALID)
+
+
+def sum_of_squares():
+    return Aggregation(Kind.SUM_OF_SQUARES)
+
+
+def mean():
+    return Aggregation(Kind.MEAN)
+
+
+def variance(ddof: int = 1):
+    return Aggregation(Kind.VARIANCE)
+
+
+def std(ddof: int = 1):
+    return Aggregation(Kind.STD)
+
+
+def median():
+    return Aggregation(Kind.MEDIAN)
+
+
+def argmax():
+    return Aggregation(Kind.ARGMAX)
+
+
+def argmin():
+    return Aggregation(Kind.ARGMIN)
+
+
+def nth_element(n: int, null_handling: NullPolicy = NullPolicy.INCLUDE):
+    return Aggregation(Kind.NTH_ELEMENT)
+
+
+def m2():
+    return Aggregation(Kind.M2)

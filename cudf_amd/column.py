@@ -1,0 +1,189 @@
+"""Device columns and tables: host-side mirror of pylibcudf.Column / pylibcudf.Table
+(reference python/pylibcudf/pylibcudf/column.pyx, table.pyx) over the C ABI. A Column is either a
+non-owning view over caller memory (a torch tensor, a raw device pointer) or a view into an owning result
+table handle kept alive by reference."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .types import DataType, TypeId
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return None
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    if hasattr(stream, "cuda_stream"):  # torch.cuda.Stream
+        return C.c_void_p(stream.cuda_stream)
+    raise TypeError("stream must be None, an int hipStream_t, or a torch.cuda.Stream")
+
+
+class _DeviceAlloc:
+    """Owning device allocation from the library's device resource."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        self.nbytes = nbytes
+        _lib.check(_lib.load().cudf_amd_malloc(C.byref(self.ptr), max(nbytes, 1), None))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.load().cudf_amd_free(self.ptr, None)
+        except Exception:
+            pass
+
+
+class _TableHandle:
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().cudf_amd_table_free(self.handle)
+        except Exception:
+            pass
+
+
+class Column:
+    def __init__(self, dtype: DataType, size: int, data_ptr, mask_ptr=None, null_count: int = 0, offset: int = 0,
+                 owner=None):
+        self._dtype = dtype
+        self._size = int(size)
+        self._data = int(data_ptr or 0)
+        self._mask = int(mask_ptr or 0)
+        self._null_count = int(null_count)
+        self._offset = int(offset)
+        self._owner = owner  # keeps the underlying memory alive
+
+    # ---- pylibcudf.Column accessors
+    def type(self) -> DataType:
+        return self._dtype
+
+    def size(self) -> int:
+        return self._size
+
+    def null_count(self) -> int:
+        return self._null_count
+
+    def offset(self) -> int:
+        return self._offset
+
+    def data_ptr(self) -> int:
+        return self._data
+
+    def null_mask_ptr(self) -> int:
+        return self._mask
+
+    def nullable(self) -> bool:
+        return self._mask != 0
+
+    def _view(self) -> _lib.ColumnView:
+        return _lib.ColumnView(int(self._dtype.id()), self._size, self._data or None, self._mask or None,
+                               self._null_count, self._offset, self._dtype.scale())
+
+    # ---- constructors
+    @staticmethod
+    def from_numpy(data, valid=None, dtype: DataType = None, offset: int = 0) -> "Column":
+        """Copies a host array (and optional boolean validity array) to the device. With `offset`, the column
+        is a slice [offset:] of the uploaded buffers (Arrow offset semantics)."""
+        data = np.ascontiguousarray(data)
+        if dtype is None:
+            dtype = DataType.from_numpy(data.dtype)
+        raw = data.astype(np.uint8) if data.dtype == np.bool_ else data
+        lib = _lib.load()
+        dbuf = _DeviceAlloc(raw.nbytes)
+        _lib.check(lib.cudf_amd_memcpy(dbuf.ptr, raw.ctypes.data, raw.nbytes, 0, None))
+        owner = [dbuf]
+        mask_ptr, nulls = None, 0
+        if valid is not None:
+            valid = np.asarray(valid, dtype=bool)
+            assert len(valid) == len(data)
+            nbits = len(valid)
+            padded = np.zeros(((nbits + 511) // 512) * 512 + 512, dtype=np.uint8)
+            padded[:nbits] = valid
+            words = np.packbits(padded.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).copy()
+            mbuf = _DeviceAlloc(words.nbytes)
+            _lib.check(lib.cudf_amd_memcpy(mbuf.ptr, words.ctypes.data, words.nbytes, 0, None))
+            owner.append(mbuf)
+            mask_ptr = mbuf.ptr.value
+            nulls = int((~valid[offset:]).sum())
+        _lib.check(lib.cudf_amd_stream_synchronize(None))
+        return Column(dtype, len(data) - offset, dbuf.ptr.value, mask_ptr, nulls, offset, owner)
+
+    @staticmethod
+    def from_torch(tensor, mask_tensor=None, null_count: int = 0, dtype: DataType = None) -> "Column":
+        """Zero-copy view over a contiguous 1-D torch tensor on the GPU (and an optional int32 bitmask tensor)."""
+        import torch
+
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.dim() == 1
+        if dtype is None:
+            dtype = DataType.from_numpy(torch.empty(0, dtype=tensor.dtype).numpy().dtype)
+        mptr = None
+        if mask_tensor is not None:
+            assert mask_tensor.is_cuda and mask_tensor.is_contiguous()
+            mptr = mask_tensor.data_ptr()
+        return Column(dtype, tensor.numel(), tensor.data_ptr(), mptr, null_count, 0, (tensor, mask_tensor))
+
+    # ---- host transfer
+    def to_numpy(self):
+        """Returns (data, valid_or_None) on the host."""
+        lib = _lib.load()
+        npdt = self._dtype.numpy_dtype()
+        raw_dt = np.uint8 if npdt == np.bool_ else npdt
+        out = np.empty(self._size, dtype=raw_dt)
+        if self._size:
+            src = self._data + self._offset * out.itemsize
+            _lib.check(lib.cudf_amd_memcpy(out.ctypes.data, C.c_void_p(src), out.nbytes, 1, None))
+        valid = None
+        if self._mask:
+            nwords = (self._offset + self._size + 31) // 32
+            words = np.empty(max(nwords, 1), dtype=np.uint32)
+            if nwords:
+                _lib.check(lib.cudf_amd_memcpy(words.ctypes.data, C.c_void_p(self._mask), nwords * 4, 1, None))
+        _lib.check(lib.cudf_amd_stream_synchronize(None))
+        if self._mask:
+            bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+            valid = bits[self._offset:self._offset + self._size].astype(bool)
+        if npdt == np.bool_:
+            out = out != 0
+        return out, valid
+
+    def __repr__(self):
+        return f"Column({self._dtype}, size={self._size}, nulls={self._null_count})"
+
+
+class Table:
+    def __init__(self, columns):
+        self._columns = list(columns)
+        if self._columns:
+            n = self._columns[0].size()
+            assert all(c.size() == n for c in self._columns), "Column size mismatch."
+
+    def columns(self):
+        return list(self._columns)
+
+    def num_columns(self):
+        return len(self._columns)
+
+    def num_rows(self):
+        return self._columns[0].size() if self._columns else 0
+
+    def _views(self):
+        arr = (_lib.ColumnView * max(1, len(self._columns)))(*[c._view() for c in self._columns])
+        return arr
+
+    @staticmethod
+    def _from_handle(handle) -> "Table":
+        lib = _lib.load()
+        owner = _TableHandle(handle)
+        cols = []
+        for i in range(lib.cudf_amd_table_num_columns(handle)):
+            v = _lib.ColumnView()
+            _lib.check(lib.cudf_amd_table_column(handle, i, C.byref(v)))
+            cols.append(Column(DataType(TypeId(v.type_id), v.scale), v.size, v.data, v.null_mask, v.null_count,
+                               v.offset, owner))
+        return Table(cols)

@@ -1,0 +1,191 @@
+// SPDX-License-Identifier: Apache-2.0
+// extern "C" shim over the C++ boundary (include/cudf_amd_c.h). Translates views, maps exceptions to status
+// codes (pylibcudf does the same mapping in exception_handler.pxd:34-64).
+#include <cudf_amd_c.h>
+
+#include <cudf/groupby.hpp>
+#include <cudf/table/table.hpp>
+#include <cudf/utilities/error.hpp>
+
+#include <new>
+#include <string>
+#include <vector>
+
+struct cudf_amd_table_s {
+  std::vector<std::unique_ptr<cudf::column>> cols;
+};
+
+namespace {
+thread_local std::string g_last_error;
+
+rmm::mr::statistics_resource_adaptor& stats_mr()
+{
+  static rmm::mr::hip_async_memory_resource base{};
+  static rmm::mr::statistics_resource_adaptor stats{&base};
+  return stats;
+}
+void ensure_resource()
+{
+  static bool const once = [] {
+    rmm::mr::set_current_device_resource(&stats_mr());
+    return true;
+  }();
+  (void)once;
+}
+
+template <typename F>
+cudf_amd_status guarded(F&& f)
+{
+  try {
+    ensure_resource();
+    f();
+    return CUDF_AMD_OK;
+  } catch (cudf::data_type_error const& e) {
+    g_last_error = e.what();
+    return CUDF_AMD_DATA_TYPE_ERROR;
+  } catch (std::invalid_argument const& e) {
+    g_last_error = e.what();
+    return CUDF_AMD_INVALID_ARGUMENT;
+  } catch (cudf::logic_error const& e) {
+    g_last_error = e.what();
+    return CUDF_AMD_LOGIC_ERROR;
+  } catch (cudf::hip_error const& e) {
+    g_last_error = e.what();
+    return CUDF_AMD_DEVICE_ERROR;
+  } catch (std::bad_alloc const& e) {
+    g_last_error = "std::bad_alloc: out of device memory";
+    return CUDF_AMD_BAD_ALLOC;
+  } catch (std::exception const& e) {
+    g_last_error = e.what();
+    return CUDF_AMD_OTHER_ERROR;
+  }
+}
+
+cudf::column_view to_view(cudf_amd_column_view const& c)
+{
+  auto const id = static_cast<cudf::type_id>(c.type_id);
+  cudf::data_type const t =
+    (id == cudf::type_id::DECIMAL32 || id == cudf::type_id::DECIMAL64 || id == cudf::type_id::DECIMAL128)
+      ? cudf::data_type{id, c.scale}
+      : cudf::data_type{id};
+  return cudf::column_view{t, c.size, c.data, c.null_mask, c.null_count, c.offset};
+}
+cudf::table_view to_table(cudf_amd_column_view const* cols, int32_t n)
+{
+  std::vector<cudf::column_view> v;
+  v.reserve(n);
+  for (int32_t i = 0; i < n; ++i) v.push_back(to_view(cols[i]));
+  return cudf::table_view{v};
+}
+hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+std::unique_ptr<cudf::groupby_aggregation> make_agg(int32_t kind)
+{
+  using A = cudf::aggregation;
+  switch (kind) {
+    case A::SUM: return cudf::make_sum_aggregation<cudf::groupby_aggregation>();
+    case A::PRODUCT: return cudf::make_product_aggregation<cudf::groupby_aggregation>();
+    case A::MIN: return cudf::make_min_aggregation<cudf::groupby_aggregation>();
+    case A::MAX: return cudf::make_max_aggregation<cudf::groupby_aggregation>();
+    case A::COUNT_VALID: return cudf::make_count_aggregation<cudf::groupby_aggregation>(cudf::null_policy::EXCLUDE);
+    case A::COUNT_ALL: return cudf::make_count_aggregation<cudf::groupby_aggregation>(cudf::null_policy::INCLUDE);
+    case A::SUM_OF_SQUARES: return cudf::make_sum_of_squares_aggregation<cudf::groupby_aggregation>();
+    case A::MEAN: return cudf::make_mean_aggregation<cudf::groupby_aggregation>();
+    case A::M2: return cudf::make_m2_aggregation<cudf::groupby_aggregation>();
+    case A::VARIANCE: return cudf::make_variance_aggregation<cudf::groupby_aggregation>();
+    case A::STD: return cudf::make_std_aggregation<cudf::groupby_aggregation>();
+    case A::ARGMAX: return cudf::make_argmax_aggregation<cudf::groupby_aggregation>();
+    case A::ARGMIN: return cudf::make_argmin_aggregation<cudf::groupby_aggregation>();
+    case A::MEDIAN: return cudf::make_median_aggregation<cudf::groupby_aggregation>();
+    case A::NTH_ELEMENT: return cudf::make_nth_element_aggregation<cudf::groupby_aggregation>(0);
+    default: CUDF_FAIL("Unsupported aggregation kind in the C ABI.", std::invalid_argument);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* cudf_amd_last_error(void) { return g_last_error.c_str(); }
+const char* cudf_amd_version(void) { return "cudf_amd 0.1.0 (gfx950; libcudf 26.10 API subset)"; }
+
+cudf_amd_status cudf_amd_malloc(void** ptr, size_t bytes, void* stream)
+{
+  return guarded([&] { *ptr = cudf::get_current_device_resource_ref().allocate_async(bytes, as_stream(stream)); });
+}
+cudf_amd_status cudf_amd_free(void* ptr, void* stream)
+{
+  return guarded([&] { cudf::get_current_device_resource_ref().deallocate_async(ptr, 0, as_stream(stream)); });
+}
+cudf_amd_status cudf_amd_memcpy(void* dst, const void* src, size_t bytes, int32_t kind, void* stream)
+{
+  return guarded([&] {
+    auto const k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (bytes) CUDF_HIP_TRY(hipMemcpyAsync(dst, src, bytes, k, as_stream(stream)));
+  });
+}
+cudf_amd_status cudf_amd_memset(void* dst, int32_t value, size_t bytes, void* stream)
+{
+  return guarded([&] {
+    if (bytes) CUDF_HIP_TRY(hipMemsetAsync(dst, value, bytes, as_stream(stream)));
+  });
+}
+cudf_amd_status cudf_amd_stream_synchronize(void* stream)
+{
+  return guarded([&] { CUDF_HIP_TRY(hipStreamSynchronize(as_stream(stream))); });
+}
+cudf_amd_status cudf_amd_memory_stats(uint64_t* current_bytes, uint64_t* peak_bytes)
+{
+  return guarded([&] {
+    *current_bytes = stats_mr().current_bytes();
+    *peak_bytes    = stats_mr().peak_bytes();
+  });
+}
+
+int32_t cudf_amd_table_num_columns(cudf_amd_table_t t) { return t ? static_cast<int32_t>(t->cols.size()) : 0; }
+int32_t cudf_amd_table_num_rows(cudf_amd_table_t t) { return (t && !t->cols.empty()) ? t->cols.front()->size() : 0; }
+cudf_amd_status cudf_amd_table_column(cudf_amd_table_t t, int32_t i, cudf_amd_column_view* out)
+{
+  return guarded([&] {
+    CUDF_EXPECTS(t != nullptr && i >= 0 && i < static_cast<int32_t>(t->cols.size()), "column index out of range",
+                 std::invalid_argument);
+    auto const v    = t->cols[i]->view();
+    out->type_id    = static_cast<int32_t>(v.type().id());
+    out->size       = v.size();
+    out->data       = v.head();
+    out->null_mask  = v.null_mask();
+    out->null_count = v.null_count();
+    out->offset     = v.offset();
+    out->scale      = v.type().scale();
+  });
+}
+void cudf_amd_table_free(cudf_amd_table_t t) { delete t; }
+
+cudf_amd_status cudf_amd_groupby_aggregate(const cudf_amd_column_view* keys, int32_t num_keys,
+                                           int32_t include_null_keys, int32_t keys_are_sorted,
+                                           const cudf_amd_aggregation_request* requests, int32_t num_requests,
+                                           void* stream, cudf_amd_table_t* out_keys, cudf_amd_table_t* out_results,
+                                           int32_t* out_path)
+{
+  return guarded([&] {
+    *out_keys    = nullptr;
+    *out_results = nullptr;
+    auto const kt = to_table(keys, num_keys);
+    std::vector<cudf::groupby::aggregation_request> reqs(num_requests);
+    for (int32_t r = 0; r < num_requests; ++r) {
+      reqs[r].values = to_view(requests[r].values);
+      for (int32_t k = 0; k < requests[r].num_kinds; ++k) reqs[r].aggregations.push_back(make_agg(requests[r].kinds[k]));
+    }
+    cudf::groupby::groupby gb{kt, include_null_keys ? cudf::null_policy::INCLUDE : cudf::null_policy::EXCLUDE,
+                              keys_are_sorted ? cudf::sorted::YES : cudf::sorted::NO};
+    auto [ukeys, results] = gb.aggregate(reqs, cudf::stream_ref{as_stream(stream)});
+    auto kh               = std::make_unique<cudf_amd_table_s>();
+    kh->cols              = ukeys->release();
+    auto rh               = std::make_unique<cudf_amd_table_s>();
+    for (auto& r : results)
+      for (auto& c : r.results) rh->cols.push_back(std::move(c));
+    if (out_path) *out_path = static_cast<int32_t>(gb.last_path());
+    *out_keys    = kh.release();
+    *out_results = rh.release();
+  });
+}
+}  // extern "C"

@@ -1,0 +1,172 @@
+// SPDX-License-Identifier: Apache-2.0
+// Hash-groupby engine for MI355X: shared host/device plan structures and kernel launchers.
+//
+// Design: rows are packed into fixed-size RECORDS of 8-byte units
+//   raw record     = [KU key units | NPAY payload units]      (payload = values converted to their 8-byte
+//                                                               accumulator class, + a validity-flags half)
+//   partial record = [KU key units | NACC accumulator units]   (one per (group, work item))
+// and aggregated ONLY in LDS hash tables (ds_add_f64 / ds_add_u64 / ds_min/max) — scattered global atomics
+// run at ~24 G ops/s on gfx950 (profiles/microbench_r1.txt) and cannot carry 1B rows. When the groups do
+// not fit one LDS table the records are first radix-partitioned on the top bits of a 64-bit key hash
+// (LDS-staged multi-split with exact offsets), so each partition's groups fit one table.
+// Replaces the reference's cuco::static_set + global-atomic design
+// (cpp/src/groupby/hash/compute_groupby.cu:51-155, compute_global_memory_aggs.cuh:74-187,
+// single_pass_functors.cuh:86-157) and its LDS path (compute_mapping_indices.cuh:92-151,
+// compute_shared_memory_aggs.cu:260-353).
+#pragma once
+#include "../common/device_table.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace cudf::groupby::detail {
+
+using cudf::detail::device_column;
+using cudf::detail::MAX_COLS;
+
+constexpr int MAX_KU    = 4;   // key units (8 B each) per record
+constexpr int MAX_PAY   = 8;   // raw payload units
+constexpr int MAX_ACC   = 12;  // accumulators per group
+constexpr int MAX_UNITS = 16;  // units per record (raw or partial)
+
+// Source of one 32-bit half of a key/payload unit.
+constexpr int8_t H_NONE     = -1;
+constexpr int8_t H_KEYNULLS = -2;  // bit c set = key column c is NULL at this row (null_policy::INCLUDE)
+constexpr int8_t H_VALVALID = -3;  // bit v set = value column v is valid at this row
+
+struct unit_desc {
+  int8_t full;  // 1: the unit is the 8-byte column `lo`
+  int8_t lo;    // column index (>= 0) or H_*
+  int8_t hi;
+  int8_t is_key;
+};
+
+// Merge operator of an accumulator (identities: reference device_operators.cuh:60-76,132-139,190-197).
+enum acc_op : int8_t { ADD_I64 = 0, ADD_F64, MIN_I64, MIN_U64, MIN_F64, MAX_I64, MAX_U64, MAX_F64 };
+// How a RAW row contributes (reference device_aggregators.cuh:24-112,428-446: null source elements are
+// skipped for everything except COUNT_ALL).
+enum acc_src : int8_t { SRC_VALUE = 0, SRC_ONE_IF_VALID, SRC_ONE, SRC_SQUARE };
+
+struct acc_desc {
+  int8_t op;
+  int8_t src;
+  int8_t pay;        // raw payload unit holding the value (or -1)
+  int8_t valid_bit;  // bit in VALVALID, or -1 if the value column has no nulls
+};
+
+struct plan_dev {
+  device_column cols[MAX_COLS];  // key columns first, then the distinct value columns
+  int32_t ncols;
+  int32_t nkeycols;
+  int32_t KU;              // key units
+  int32_t NPAY;            // raw payload units
+  int32_t NACC;            // accumulators
+  int32_t drop_null_keys;  // null_policy::EXCLUDE and some key column is nullable
+  int32_t flags_unit;      // raw unit holding VALVALID (-1: none)
+  int32_t flags_hi;        // 1: in the high half
+  unit_desc unit[MAX_UNITS];
+  uint64_t key_mask[MAX_KU];
+  acc_desc acc[MAX_ACC];
+};
+
+// ---- finalize: partial records -> typed output columns
+enum out_kind : int8_t {
+  OUT_KEY = 0,    // key column `a0` (index into plan cols)
+  OUT_ACC,        // accumulator a0 cast to the target type
+  OUT_MEAN,       // double(acc a0) / acc a1   (a0 class in `cls`)
+  OUT_COUNT       // accumulator a0 as INT32
+};
+struct out_desc {
+  void* data;
+  bitmask_type* mask;   // nullptr: not nullable
+  int32_t* null_count;  // device counter (nullable columns only)
+  int8_t kind;
+  int8_t a0, a1;
+  int8_t valid_acc;     // accumulator whose value > 0 means valid (-1: always valid)
+  int8_t cls;           // accumulator class of a0: elem_class (SINT/UINT/F64)
+  int8_t width;         // output element width
+  int8_t out_cls;       // elem_class of the output type
+  int8_t key_unit, key_hi, key_full;  // OUT_KEY: where the key lives
+  int8_t key_null_bit;  // OUT_KEY with INCLUDE: bit in KEYNULLS (-1 none)
+  int8_t keynulls_unit, keynulls_hi;
+};
+constexpr int MAX_OUT = 40;
+struct finalize_dev {
+  out_desc out[MAX_OUT];
+  int32_t nout;
+};
+
+// ---- launch geometry chosen by the host
+struct part_geom {
+  int32_t nseg;        // input segments (1 for level 1)
+  int32_t slices;      // work items per segment
+  int32_t P;           // partitions per segment (power of two)
+  int32_t shift;       // partition digit = (hash >> shift) & (P - 1)
+  int32_t tile_rows;   // rows staged in LDS per tile
+  int32_t block;       // threads per workgroup
+};
+
+struct agg_geom {
+  int32_t cap;         // LDS table slots per work item
+  int32_t fill_limit;  // groups per table before the item reports overflow
+  int32_t block;
+};
+
+// Input modes of the aggregate kernel.
+enum agg_input : int32_t { IN_COLUMNS = 0, IN_RAW_RECORDS = 1, IN_PARTIAL_RECORDS = 2 };
+// How work item i finds its input records.
+enum seg_mode : int32_t {
+  SEG_ROW_CHUNKS = 0,  // item i = rows [i*chunk, min(n,(i+1)*chunk))          (IN_COLUMNS)
+  SEG_OFFSETS    = 1,  // item i = records [off[i], off[i+1])                   (partitioned records)
+  SEG_STRIDED    = 2   // item i = `fan` sources s = i*fan..: records [s*stride, s*stride+count[s])  (merge)
+};
+
+struct agg_args {
+  plan_dev plan;
+  agg_geom geom;
+  int32_t input;          // agg_input
+  int32_t seg;            // seg_mode
+  int64_t nrows;          // SEG_ROW_CHUNKS
+  int64_t chunk;          // SEG_ROW_CHUNKS
+  int64_t const* offsets; // SEG_OFFSETS (nitems + 1)
+  int32_t const* src_count;  // SEG_STRIDED
+  int64_t src_stride;        // SEG_STRIDED (records)
+  int32_t fan;               // SEG_STRIDED
+  int32_t nsrc;              // SEG_STRIDED: number of source items
+  uint64_t const* records;   // input records (raw or partial)
+  uint64_t* out_records;     // partial records out: item i writes [i*cap, i*cap + out_count[i])
+  int32_t* out_count;        // groups per item
+  int32_t* overflow;         // set to 1 if any item exceeded fill_limit
+  int32_t nitems;
+};
+
+struct part_args {
+  plan_dev plan;
+  part_geom geom;
+  int32_t from_columns;        // 1: source = plan columns, 0: source = raw records
+  int64_t nrows;               // from_columns
+  uint64_t const* in_records;  // !from_columns
+  int64_t const* seg_offsets;  // !from_columns: nseg + 1 record offsets
+  uint32_t* counts;            // [nseg*slices][P] histogram
+  int64_t* item_base;          // [nseg*slices][P] exclusive output offsets (records)
+  int64_t* out_offsets;        // [nseg*P + 1] partition boundaries (records)
+  uint64_t* out_records;
+};
+
+// Launchers (kernels.hip). All asynchronous on `stream`.
+void launch_partition_hist(part_args const& a, hipStream_t stream);
+void launch_partition_scan(part_args const& a, hipStream_t stream);
+void launch_partition_scatter(part_args const& a, hipStream_t stream);
+void launch_aggregate(agg_args const& a, hipStream_t stream);
+// Gathers `total` groups (items' partial records, prefix[] = exclusive scan of the item counts) into the
+// typed output columns.
+void launch_finalize(plan_dev const& plan, finalize_dev const& fin, uint64_t const* records, int64_t cap,
+                     int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream);
+// Distinct-count estimate on a strided sample (linear counting into a bitmap); result written to *d_bits.
+void launch_estimate(plan_dev const& plan, int64_t nrows, int64_t sample, uint32_t* bitmap, int32_t bitmap_bits_log2,
+                     uint32_t* d_bits_set, hipStream_t stream);
+
+std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g);
+std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g);
+
+}  // namespace cudf::groupby::detail

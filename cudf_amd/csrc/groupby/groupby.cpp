@@ -1,0 +1,707 @@
+// SPDX-License-Identifier: Apache-2.0
+// Host side of cudf::groupby::groupby for the hash path: request validation, aggregation flattening, record
+// planning, strategy selection and kernel orchestration.
+// Reference counterparts: cpp/src/groupby/groupby.cu:39-70,186-236 (ctor, validation, dispatch),
+// cpp/src/groupby/hash/groupby.cu:33-147 (hash dispatch), extract_single_pass_aggs.cpp:26-177 (flattening),
+// output_utils.cu:49-224 (result columns), hash_compound_agg_finalizer.cu:92-133 (MEAN).
+#include "engine.hpp"
+
+#include <cudf/groupby.hpp>
+#include <cudf/null_mask.hpp>
+#include <cudf/utilities/error.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace cudf {
+
+// ---------------------------------------------------------------------------------------------------------
+// aggregation descriptors (reference cpp/src/aggregation/aggregation.cpp factories)
+namespace detail {
+class simple_aggregation final : public groupby_aggregation, public reduce_aggregation {
+ public:
+  explicit simple_aggregation(aggregation::Kind k) : aggregation{k} {}
+  [[nodiscard]] std::unique_ptr<aggregation> clone() const override
+  {
+    return std::make_unique<simple_aggregation>(*this);
+  }
+};
+class ddof_aggregation final : public groupby_aggregation, public reduce_aggregation {
+ public:
+  ddof_aggregation(aggregation::Kind k, size_type ddof) : aggregation{k}, _ddof{ddof} {}
+  [[nodiscard]] bool is_equal(aggregation const& other) const override
+  {
+    auto const* o = dynamic_cast<ddof_aggregation const*>(&other);
+    return o != nullptr && aggregation::is_equal(other) && o->_ddof == _ddof;
+  }
+  [[nodiscard]] size_t do_hash() const override { return aggregation::do_hash() ^ std::hash<int>{}(_ddof); }
+  [[nodiscard]] std::unique_ptr<aggregation> clone() const override { return std::make_unique<ddof_aggregation>(*this); }
+  size_type _ddof;
+};
+
+data_type target_type(data_type source, aggregation::Kind k)
+{
+  auto const id  = source.id();
+  auto const cls = class_of(id);
+  bool const plain_numeric = id >= type_id::INT8 && id <= type_id::BOOL8;
+  bool const is_duration   = id >= type_id::DURATION_DAYS && id <= type_id::DURATION_NANOSECONDS;
+  bool const is_decimal    = id == type_id::DECIMAL32 || id == type_id::DECIMAL64;
+  auto const invalid       = data_type{type_id::EMPTY};
+  if (cls == CLS_NONE) return invalid;
+  switch (k) {
+    case aggregation::MIN:
+    case aggregation::MAX: return source;
+    case aggregation::COUNT_VALID:
+    case aggregation::COUNT_ALL:
+    case aggregation::ARGMAX:
+    case aggregation::ARGMIN: return data_type{type_id::INT32};
+    case aggregation::MEAN:
+      if (plain_numeric) return data_type{type_id::FLOAT64};
+      if (is_duration || is_decimal) return source;
+      return invalid;
+    case aggregation::SUM:
+      if (cls == CLS_F32 || cls == CLS_F64) return source;
+      if (plain_numeric) return data_type{type_id::INT64};
+      if (is_duration || is_decimal) return source;
+      return invalid;
+    case aggregation::PRODUCT:
+    case aggregation::SUM_OF_SQUARES:
+      if (cls == CLS_F32 || cls == CLS_F64) return source;
+      if (plain_numeric) return data_type{type_id::INT64};
+      return invalid;
+    case aggregation::M2:
+    case aggregation::VARIANCE:
+    case aggregation::STD: return plain_numeric ? data_type{type_id::FLOAT64} : invalid;
+    case aggregation::NTH_ELEMENT:
+    case aggregation::MEDIAN: return source;
+    default: return invalid;
+  }
+}
+bool is_valid_aggregation(data_type source, aggregation::Kind k) { return target_type(source, k).id() != type_id::EMPTY; }
+
+device_table make_device_table(table_view const& t)
+{
+  CUDF_EXPECTS(t.num_columns() <= MAX_COLS, "Too many columns for the hash path (limit 16).");
+  device_table d{};
+  d.ncols = t.num_columns();
+  d.nrows = t.num_rows();
+  for (int c = 0; c < d.ncols; ++c) {
+    auto const& col = t.column(c);
+    auto const w    = size_of_id(col.type().id());
+    CUDF_EXPECTS(w >= 1 && w <= 8, "Only fixed-width columns of at most 8 bytes are supported on the hash path.");
+    d.col[c] = make_device_column(col);
+    if (!col.has_nulls()) d.col[c].mask = nullptr;
+  }
+  return d;
+}
+}  // namespace detail
+
+#define CUDF_AMD_FACTORY(fn, kind)                                               \
+  template <typename Base>                                                       \
+  std::unique_ptr<Base> fn()                                                     \
+  {                                                                              \
+    return std::make_unique<detail::simple_aggregation>(aggregation::kind);      \
+  }                                                                              \
+  template std::unique_ptr<aggregation> fn<aggregation>();                       \
+  template std::unique_ptr<groupby_aggregation> fn<groupby_aggregation>();
+CUDF_AMD_FACTORY(make_sum_aggregation, SUM)
+CUDF_AMD_FACTORY(make_product_aggregation, PRODUCT)
+CUDF_AMD_FACTORY(make_min_aggregation, MIN)
+CUDF_AMD_FACTORY(make_max_aggregation, MAX)
+CUDF_AMD_FACTORY(make_sum_of_squares_aggregation, SUM_OF_SQUARES)
+CUDF_AMD_FACTORY(make_mean_aggregation, MEAN)
+CUDF_AMD_FACTORY(make_m2_aggregation, M2)
+CUDF_AMD_FACTORY(make_argmax_aggregation, ARGMAX)
+CUDF_AMD_FACTORY(make_argmin_aggregation, ARGMIN)
+CUDF_AMD_FACTORY(make_median_aggregation, MEDIAN)
+#undef CUDF_AMD_FACTORY
+
+template <typename Base>
+std::unique_ptr<Base> make_count_aggregation(null_policy null_handling)
+{
+  return std::make_unique<detail::simple_aggregation>(null_handling == null_policy::INCLUDE ? aggregation::COUNT_ALL
+                                                                                            : aggregation::COUNT_VALID);
+}
+template std::unique_ptr<aggregation> make_count_aggregation<aggregation>(null_policy);
+template std::unique_ptr<groupby_aggregation> make_count_aggregation<groupby_aggregation>(null_policy);
+template <typename Base>
+std::unique_ptr<Base> make_variance_aggregation(size_type ddof)
+{
+  return std::make_unique<detail::ddof_aggregation>(aggregation::VARIANCE, ddof);
+}
+template std::unique_ptr<aggregation> make_variance_aggregation<aggregation>(size_type);
+template std::unique_ptr<groupby_aggregation> make_variance_aggregation<groupby_aggregation>(size_type);
+template <typename Base>
+std::unique_ptr<Base> make_std_aggregation(size_type ddof)
+{
+  return std::make_unique<detail::ddof_aggregation>(aggregation::STD, ddof);
+}
+template std::unique_ptr<aggregation> make_std_aggregation<aggregation>(size_type);
+template std::unique_ptr<groupby_aggregation> make_std_aggregation<groupby_aggregation>(size_type);
+template <typename Base>
+std::unique_ptr<Base> make_nth_element_aggregation(size_type, null_policy)
+{
+  return std::make_unique<detail::simple_aggregation>(aggregation::NTH_ELEMENT);
+}
+template std::unique_ptr<aggregation> make_nth_element_aggregation<aggregation>(size_type, null_policy);
+template std::unique_ptr<groupby_aggregation> make_nth_element_aggregation<groupby_aggregation>(size_type, null_policy);
+
+namespace groupby {
+namespace detail {
+namespace {
+
+using cudf::detail::CLS_BOOL;
+using cudf::detail::CLS_F32;
+using cudf::detail::CLS_F64;
+using cudf::detail::CLS_SINT;
+using cudf::detail::CLS_UINT;
+using cudf::detail::class_of;
+
+int64_t env_i64(char const* name, int64_t dflt)
+{
+  char const* e = std::getenv(name);
+  return (e != nullptr && *e != 0) ? std::strtoll(e, nullptr, 10) : dflt;
+}
+
+// Kinds the hash engine computes (reference groupby/common/utils.hpp:66-85 lists the hashable set; the
+// remaining ones need the sort path, which is out of scope — SURVEY.md §8f rank 4).
+bool is_engine_kind(aggregation::Kind k)
+{
+  switch (k) {
+    case aggregation::SUM:
+    case aggregation::MIN:
+    case aggregation::MAX:
+    case aggregation::COUNT_VALID:
+    case aggregation::COUNT_ALL:
+    case aggregation::MEAN:
+    case aggregation::SUM_OF_SQUARES: return true;
+    default: return false;
+  }
+}
+
+struct result_spec {  // one per (request, aggregation)
+  aggregation::Kind kind;
+  data_type target;
+  int value_idx;  // distinct value column
+  int a0{-1}, a1{-1}, valid_acc{-1};
+  bool nullable{false};
+  int acc_cls{0};
+};
+
+struct host_plan {
+  plan_dev dev{};
+  std::vector<column_view> value_cols;  // distinct
+  std::vector<result_spec> results;     // flattened in request order
+  // key column c -> (unit, half: 0 lo / 1 hi / 2 full)
+  int key_unit[MAX_COLS]{};
+  int key_half[MAX_COLS]{};
+  int keynulls_unit{-1}, keynulls_hi{0};
+};
+
+int find_or_add_acc(plan_dev& p, acc_desc const& d)
+{
+  for (int i = 0; i < p.NACC; ++i) {
+    auto const& e = p.acc[i];
+    if (e.op == d.op && e.src == d.src && e.pay == d.pay && e.valid_bit == d.valid_bit) return i;
+  }
+  CUDF_EXPECTS(p.NACC < MAX_ACC, "Too many distinct accumulators for one hash groupby call (limit 12).");
+  p.acc[p.NACC] = d;
+  return p.NACC++;
+}
+
+host_plan build_plan(table_view const& keys, null_policy policy, std::vector<aggregation_request> const& requests)
+{
+  host_plan hp;
+  auto& p = hp.dev;
+  CUDF_EXPECTS(keys.num_columns() >= 1, "groupby requires at least one key column.");
+  // ---- columns: keys, then distinct value columns
+  for (auto const& r : requests) {
+    bool found = false;
+    for (auto const& v : hp.value_cols) found = found || cudf::detail::is_shallow_equivalent(v, r.values);
+    if (!found) hp.value_cols.push_back(r.values);
+  }
+  CUDF_EXPECTS(static_cast<int>(hp.value_cols.size()) <= MAX_PAY - 1, "Too many distinct value columns (limit 7).");
+  CUDF_EXPECTS(keys.num_columns() + static_cast<int>(hp.value_cols.size()) <= MAX_COLS,
+               "Too many key + value columns for the hash path (limit 16).");
+  std::vector<column_view> all;
+  for (auto const& k : keys) all.push_back(k);
+  for (auto const& v : hp.value_cols) all.push_back(v);
+  auto const dt = cudf::detail::make_device_table(table_view{all});
+  for (int c = 0; c < dt.ncols; ++c) p.cols[c] = dt.col[c];
+  p.ncols    = dt.ncols;
+  p.nkeycols = keys.num_columns();
+
+  bool const keys_have_nulls = cudf::has_nulls(keys);
+  p.drop_null_keys           = keys_have_nulls && policy == null_policy::EXCLUDE;
+  bool const need_keynulls   = keys_have_nulls && policy == null_policy::INCLUDE;
+  bool need_valvalid         = false;
+  for (auto const& v : hp.value_cols) need_valvalid = need_valvalid || v.has_nulls();
+
+  // ---- key units: 8-byte columns take a full unit, narrower ones share units two per unit
+  int u = 0;
+  for (int c = 0; c < p.nkeycols; ++c) {
+    if (p.cols[c].width == 8) {
+      CUDF_EXPECTS(u < MAX_KU, "Key too wide for the hash path (limit 32 bytes).");
+      p.unit[u]       = unit_desc{1, static_cast<int8_t>(c), H_NONE, 1};
+      p.key_mask[u]   = ~uint64_t{0};
+      hp.key_unit[c]  = u;
+      hp.key_half[c]  = 2;
+      ++u;
+    }
+  }
+  int half = 0;  // next free half in unit u (0 = lo of a fresh unit)
+  auto put_half = [&](int8_t src, bool is_key_material) {
+    if (half == 0) {
+      CUDF_EXPECTS(u < MAX_UNITS, "Record too wide.");
+      p.unit[u] = unit_desc{0, src, H_NONE, static_cast<int8_t>(is_key_material)};
+      if (u < MAX_KU) p.key_mask[u] = is_key_material ? 0xffffffffull : 0;
+      half = 1;
+      return std::pair<int, int>{u, 0};
+    }
+    p.unit[u].hi = src;
+    if (is_key_material && u < MAX_KU) p.key_mask[u] |= 0xffffffff00000000ull;
+    half       = 0;
+    int const w = u++;
+    return std::pair<int, int>{w, 1};
+  };
+  for (int c = 0; c < p.nkeycols; ++c) {
+    if (p.cols[c].width < 8) {
+      CUDF_EXPECTS(u < MAX_KU, "Key too wide for the hash path (limit 32 bytes).");
+      auto const [w, h] = put_half(static_cast<int8_t>(c), true);
+      hp.key_unit[c]    = w;
+      hp.key_half[c]    = h;
+    }
+  }
+  if (need_keynulls) {
+    CUDF_EXPECTS(u < MAX_KU, "Key too wide for the hash path (limit 32 bytes).");
+    auto const [w, h]  = put_half(H_KEYNULLS, true);
+    hp.keynulls_unit   = w;
+    hp.keynulls_hi     = h;
+  }
+  p.flags_unit = -1;
+  if (need_valvalid && half == 1) {  // free high half of the last key unit: park VALVALID there (masked out of the key)
+    auto const [w, h] = put_half(H_VALVALID, false);
+    p.flags_unit      = w;
+    p.flags_hi        = h;
+  }
+  if (half == 1) {
+    half = 0;
+    ++u;
+  }
+  p.KU = u;
+  CUDF_EXPECTS(p.KU <= MAX_KU, "Key too wide for the hash path (limit 32 bytes).");
+  // ---- payload units: one per distinct value column, then VALVALID if it still needs a home
+  for (int v = 0; v < static_cast<int>(hp.value_cols.size()); ++v) {
+    CUDF_EXPECTS(u < MAX_UNITS, "Record too wide.");
+    p.unit[u++] = unit_desc{1, static_cast<int8_t>(p.nkeycols + v), H_NONE, 0};
+  }
+  if (need_valvalid && p.flags_unit < 0) {
+    CUDF_EXPECTS(u < MAX_UNITS, "Record too wide.");
+    p.unit[u]    = unit_desc{0, H_VALVALID, H_NONE, 0};
+    p.flags_unit = u;
+    p.flags_hi   = 0;
+    ++u;
+  }
+  p.NPAY = u - p.KU;
+
+  // ---- accumulators
+  p.NACC = 0;
+  for (auto const& r : requests) {
+    int vidx = 0;
+    for (; vidx < static_cast<int>(hp.value_cols.size()); ++vidx)
+      if (cudf::detail::is_shallow_equivalent(hp.value_cols[vidx], r.values)) break;
+    auto const vtype     = r.values.type();
+    int const cls        = class_of(vtype.id());
+    bool const has_nulls = r.values.has_nulls();
+    int8_t const vbit    = has_nulls ? static_cast<int8_t>(vidx) : int8_t{-1};
+    bool const is_float  = cls == CLS_F32 || cls == CLS_F64;
+    auto count_valid_acc = [&]() {
+      return has_nulls ? find_or_add_acc(p, acc_desc{ADD_I64, SRC_ONE_IF_VALID, static_cast<int8_t>(vidx), vbit})
+                       : find_or_add_acc(p, acc_desc{ADD_I64, SRC_ONE, -1, -1});
+    };
+    auto sum_acc = [&](acc_src src) {
+      return find_or_add_acc(p, acc_desc{static_cast<int8_t>(is_float ? ADD_F64 : ADD_I64), static_cast<int8_t>(src),
+                                         static_cast<int8_t>(vidx), vbit});
+    };
+    for (auto const& agg : r.aggregations) {
+      result_spec rs{};
+      rs.kind      = agg->kind;
+      rs.target    = cudf::detail::target_type(vtype, agg->kind);
+      rs.value_idx = vidx;
+      rs.acc_cls   = is_float ? CLS_F64 : (cls == CLS_UINT ? CLS_UINT : CLS_SINT);
+      rs.nullable  = has_nulls;  // reference output_utils.cu:67-68 (COUNT handled below)
+      switch (agg->kind) {
+        case aggregation::SUM: rs.a0 = sum_acc(SRC_VALUE); break;
+        case aggregation::SUM_OF_SQUARES: rs.a0 = sum_acc(SRC_SQUARE); break;
+        case aggregation::MIN:
+          rs.a0 = find_or_add_acc(
+            p, acc_desc{static_cast<int8_t>(is_float ? MIN_F64 : (cls == CLS_SINT ? MIN_I64 : MIN_U64)), SRC_VALUE,
+                        static_cast<int8_t>(vidx), vbit});
+          break;
+        case aggregation::MAX:
+          rs.a0 = find_or_add_acc(
+            p, acc_desc{static_cast<int8_t>(is_float ? MAX_F64 : (cls == CLS_SINT ? MAX_I64 : MAX_U64)), SRC_VALUE,
+                        static_cast<int8_t>(vidx), vbit});
+          break;
+        case aggregation::COUNT_VALID:
+          rs.a0       = count_valid_acc();
+          rs.nullable = false;
+          break;
+        case aggregation::COUNT_ALL:
+          rs.a0       = find_or_add_acc(p, acc_desc{ADD_I64, SRC_ONE, -1, -1});
+          rs.nullable = false;
+          break;
+        case aggregation::MEAN:
+          CUDF_EXPECTS(rs.target.id() == type_id::FLOAT64,
+                       "MEAN of duration/decimal columns is not implemented on the hash path.");
+          rs.a0 = sum_acc(SRC_VALUE);
+          rs.a1 = count_valid_acc();
+          break;
+        default: CUDF_FAIL("Unsupported aggregation on the hash path.");
+      }
+      if (rs.nullable) rs.valid_acc = count_valid_acc();
+      hp.results.push_back(rs);
+    }
+  }
+  return hp;
+}
+
+struct scratch {  // stream-ordered temporaries from the current device resource
+  hipStream_t stream;
+  rmm::device_async_resource_ref mr;
+  std::vector<rmm::device_buffer> bufs;
+  template <typename T>
+  T* alloc(std::size_t n)
+  {
+    bufs.emplace_back(std::max<std::size_t>(n, 1) * sizeof(T), stream, mr);
+    return static_cast<T*>(bufs.back().data());
+  }
+};
+
+}  // namespace
+}  // namespace detail
+
+groupby::groupby(table_view const& keys, null_policy null_handling, sorted keys_are_sorted,
+                 std::vector<order> const& column_order, std::vector<null_order> const& null_precedence)
+  : _keys{keys}, _include_null_keys{null_handling}, _keys_are_sorted{keys_are_sorted}, _column_order{column_order},
+    _null_precedence{null_precedence}
+{
+}
+groupby::~groupby() = default;
+
+std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggregate(
+  std::vector<aggregation_request> const& requests, stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  using namespace detail;
+  // reference groupby.cu:225-229
+  CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
+                           [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
+               "Size mismatch between request values and groupby keys.");
+  // reference groupby.cu:186-201
+  CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
+                           [](auto const& r) {
+                             return std::all_of(r.aggregations.begin(), r.aggregations.end(), [&r](auto const& a) {
+                               return cudf::detail::is_valid_aggregation(r.values.type(), a->kind);
+                             });
+                           }),
+               "Invalid type/aggregation combination.");
+  for (auto const& r : requests)
+    for (auto const& a : r.aggregations)
+      CUDF_EXPECTS(is_engine_kind(a->kind),
+                   "This aggregation needs the sort-based groupby, which this build does not provide.");
+
+  hipStream_t const s = stream.value();
+  auto tmp_mr         = cudf::get_current_device_resource_ref();
+
+  // ---- empty input: typed empty outputs (reference groupby.cu:233, :87-182)
+  if (_keys.num_rows() == 0) {
+    std::vector<aggregation_result> res;
+    for (auto const& r : requests) {
+      aggregation_result ar;
+      for (auto const& a : r.aggregations)
+        ar.results.push_back(make_empty_column(cudf::detail::target_type(r.values.type(), a->kind)));
+      res.push_back(std::move(ar));
+    }
+    _last_path = hash_path::NONE;
+    return {empty_like(_keys), std::move(res)};
+  }
+
+  host_plan hp     = build_plan(_keys, _include_null_keys, requests);
+  plan_dev const& p = hp.dev;
+  int64_t const n   = _keys.num_rows();
+  int const RU = p.KU + p.NPAY, PU = p.KU + p.NACC;
+
+  // ---- geometry
+  agg_geom ag{};
+  int64_t const lds_budget = env_i64("CUDF_AMD_GB_LDS_KB", 72) * 1024;
+  int const slot_bytes     = 8 * PU + 4;
+  ag.cap                   = static_cast<int32_t>(std::min<int64_t>(lds_budget / slot_bytes, 16384));
+  ag.block                 = static_cast<int32_t>(env_i64("CUDF_AMD_GB_AGG_BLOCK", 512));
+  ag.fill_limit            = static_cast<int32_t>(ag.cap * 0.6);
+  CUDF_EXPECTS(ag.cap >= 64, "Aggregation state per group too large for an LDS table.");
+
+  scratch sc{s, tmp_mr, {}};
+  int32_t* d_overflow = sc.alloc<int32_t>(1);
+
+  // ---- distinct-count estimate on a strided sample (skipped when n already fits one table)
+  double est_groups = static_cast<double>(n);
+  if (n > ag.fill_limit) {
+    int64_t const sample = std::min<int64_t>(n, int64_t{1} << 20);
+    int const bits_log2  = 24;
+    uint32_t* bitmap     = sc.alloc<uint32_t>((size_t{1} << bits_log2) / 32);
+    uint32_t* d_set      = sc.alloc<uint32_t>(1);
+    launch_estimate(p, n, sample, bitmap, bits_log2, d_set, s);
+    uint32_t h_set = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_set, d_set, 4, hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    double const m  = std::ldexp(1.0, bits_log2);
+    double const ds = h_set >= m ? m * 20 : -m * std::log(1.0 - h_set / m);  // distinct keys in the sample
+    // population estimate under uniform frequencies: solve G (1 - exp(-S/G)) = ds
+    double const S = static_cast<double>(sample);
+    if (ds >= 0.98 * S || sample == n) {
+      est_groups = sample == n ? ds : static_cast<double>(n);
+    } else {
+      double lo = ds, hi = static_cast<double>(n);
+      for (int it = 0; it < 60; ++it) {
+        double const g = 0.5 * (lo + hi);
+        if (g * (1.0 - std::exp(-S / g)) < ds) lo = g; else hi = g;
+      }
+      est_groups = std::min<double>(hi, static_cast<double>(n));
+    }
+    est_groups = std::max(est_groups, 1.0);
+  }
+  int64_t const forced_p = env_i64("CUDF_AMD_GB_P", 0);
+
+  uint64_t* partial  = nullptr;  // final partial records: item i at [i*cap, i*cap + count[i])
+  int32_t* d_count   = nullptr;
+  int32_t nitems     = 0;
+  double safety      = 1.3;
+
+  for (int attempt = 0;; ++attempt) {
+    CUDF_EXPECTS(attempt < 4, "hash groupby: could not fit the groups into LDS tables (pathological key distribution).");
+    CUDF_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, s));
+    // tables needed; the group count can never exceed the row count
+    double const need = std::min(est_groups * safety, static_cast<double>(n)) / ag.fill_limit;
+    agg_args aa{};
+    aa.plan     = p;
+    aa.geom     = ag;
+    aa.overflow = d_overflow;
+
+    if (need <= 1.0 && forced_p == 0) {
+      // ---------------- path S: every workgroup aggregates a row chunk in LDS, then partials are merged
+      _last_path          = hash_path::LDS_SINGLE_PASS;
+      int64_t const items = std::clamp<int64_t>(n / 16384, 1, env_i64("CUDF_AMD_GB_S_ITEMS", 1024));
+      nitems              = static_cast<int32_t>(items);
+      partial             = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);
+      d_count             = sc.alloc<int32_t>(nitems);
+      aa.input            = IN_COLUMNS;
+      aa.seg              = SEG_ROW_CHUNKS;
+      aa.nrows            = n;
+      aa.chunk            = (n + items - 1) / items;
+      aa.out_records      = partial;
+      aa.out_count        = d_count;
+      aa.nitems           = nitems;
+      launch_aggregate(aa, s);
+      int const fan = 16;
+      while (nitems > 1) {
+        int32_t const next = (nitems + fan - 1) / fan;
+        uint64_t* out      = sc.alloc<uint64_t>(static_cast<size_t>(next) * ag.cap * PU);
+        int32_t* cnt       = sc.alloc<int32_t>(next);
+        agg_args m         = aa;
+        m.input            = IN_PARTIAL_RECORDS;
+        m.seg              = SEG_STRIDED;
+        m.records          = partial;
+        m.src_count        = d_count;
+        m.src_stride       = ag.cap;
+        m.fan              = fan;
+        m.nsrc             = nitems;
+        m.out_records      = out;
+        m.out_count        = cnt;
+        m.nitems           = next;
+        launch_aggregate(m, s);
+        partial = out;
+        d_count = cnt;
+        nitems  = next;
+      }
+    } else {
+      // ---------------- path P: radix-partition raw records on hash bits, then one LDS table per partition
+      _last_path = hash_path::PARTITIONED_LDS;
+      auto pow2_at_least = [](double x) {
+        int64_t v = 1;
+        while (static_cast<double>(v) < x) v <<= 1;
+        return v;
+      };
+      int64_t const maxP1 = 1024;  // LDS: 8192-row stage + P * 12 B + pid must fit 160 KiB
+      int64_t P1 = forced_p ? forced_p : std::clamp<int64_t>(pow2_at_least(need), 256, maxP1);
+      int64_t P2 = 1;
+      if (!forced_p && need > static_cast<double>(maxP1)) {
+        int64_t const tot = pow2_at_least(need);
+        P1 = pow2_at_least(std::sqrt(static_cast<double>(tot)));
+        P2 = tot / P1;
+        P1 = std::min<int64_t>(P1, maxP1);
+        P2 = std::clamp<int64_t>(P2, 2, maxP1);
+      }
+      int log2P1 = 0, log2P2 = 0;
+      while ((int64_t{1} << log2P1) < P1) ++log2P1;
+      while ((int64_t{1} << log2P2) < P2) ++log2P2;
+
+      part_args pa{};
+      pa.plan         = p;
+      pa.geom.nseg    = 1;
+      pa.geom.slices  = static_cast<int32_t>(env_i64("CUDF_AMD_GB_SLICES", 512));
+      pa.geom.P       = static_cast<int32_t>(P1);
+      pa.geom.shift   = 64 - log2P1;
+      pa.geom.block   = 1024;
+      pa.from_columns = 1;
+      pa.nrows        = n;
+      size_t const items1 = static_cast<size_t>(pa.geom.slices);
+      pa.counts       = sc.alloc<uint32_t>(items1 * P1);
+      pa.item_base    = sc.alloc<int64_t>(items1 * P1);
+      pa.out_offsets  = sc.alloc<int64_t>(P1 + 1);
+      uint64_t* recA  = sc.alloc<uint64_t>(static_cast<size_t>(n) * RU);
+      pa.out_records  = recA;
+      launch_partition_hist(pa, s);
+      launch_partition_scan(pa, s);
+      launch_partition_scatter(pa, s);
+      int64_t const* offsets = pa.out_offsets;
+      uint64_t const* recs   = recA;
+      int64_t nparts         = P1;
+      if (P2 > 1) {
+        part_args pb{};
+        pb.plan         = p;
+        pb.geom.nseg    = static_cast<int32_t>(P1);
+        pb.geom.slices  = static_cast<int32_t>(std::max<int64_t>(1, 1024 / P1));
+        pb.geom.P       = static_cast<int32_t>(P2);
+        pb.geom.shift   = 64 - log2P1 - log2P2;
+        pb.geom.block   = 1024;
+        pb.from_columns = 0;
+        pb.in_records   = recA;
+        pb.seg_offsets  = pa.out_offsets;
+        size_t const items2 = static_cast<size_t>(pb.geom.nseg) * pb.geom.slices;
+        pb.counts       = sc.alloc<uint32_t>(items2 * P2);
+        pb.item_base    = sc.alloc<int64_t>(items2 * P2);
+        pb.out_offsets  = sc.alloc<int64_t>(P1 * P2 + 1);
+        uint64_t* recB  = sc.alloc<uint64_t>(static_cast<size_t>(n) * RU);
+        pb.out_records  = recB;
+        launch_partition_hist(pb, s);
+        launch_partition_scan(pb, s);
+        launch_partition_scatter(pb, s);
+        offsets = pb.out_offsets;
+        recs    = recB;
+        nparts  = P1 * P2;
+      }
+      nitems         = static_cast<int32_t>(nparts);
+      partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);
+      d_count        = sc.alloc<int32_t>(nitems);
+      aa.input       = IN_RAW_RECORDS;
+      aa.seg         = SEG_OFFSETS;
+      aa.offsets     = offsets;
+      aa.records     = recs;
+      aa.out_records = partial;
+      aa.out_count   = d_count;
+      aa.nitems      = nitems;
+      launch_aggregate(aa, s);
+    }
+    int32_t h_overflow = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_overflow, d_overflow, 4, hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    if (h_overflow == 0) break;
+    // The estimate was too low (skewed sample): ask for 8x more tables and redo.
+    est_groups = std::min<double>(static_cast<double>(n), std::max(est_groups, static_cast<double>(ag.fill_limit)) * 8);
+    sc.bufs.clear();
+    d_overflow = sc.alloc<int32_t>(1);
+  }
+
+  // ---- group counts -> prefix
+  std::vector<int32_t> h_count(nitems);
+  CUDF_HIP_TRY(hipMemcpyAsync(h_count.data(), d_count, sizeof(int32_t) * nitems, hipMemcpyDeviceToHost, s));
+  CUDF_HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int64_t> h_prefix(nitems + 1, 0);
+  for (int i = 0; i < nitems; ++i) h_prefix[i + 1] = h_prefix[i] + h_count[i];
+  int64_t const G = h_prefix[nitems];
+  CUDF_EXPECTS(G <= std::numeric_limits<size_type>::max(), "group count exceeds size_type");
+  int64_t* d_prefix = sc.alloc<int64_t>(nitems + 1);
+  CUDF_HIP_TRY(hipMemcpyAsync(d_prefix, h_prefix.data(), sizeof(int64_t) * (nitems + 1), hipMemcpyHostToDevice, s));
+
+  // ---- output columns
+  finalize_dev fin{};
+  std::vector<std::unique_ptr<column>> key_cols;
+  std::vector<std::unique_ptr<column>> res_cols;
+  int const nres = static_cast<int>(hp.results.size());
+  CUDF_EXPECTS(p.nkeycols + nres <= MAX_OUT, "Too many output columns for one call (limit 40).");
+  int32_t* d_nulls = sc.alloc<int32_t>(MAX_OUT);
+  CUDF_HIP_TRY(hipMemsetAsync(d_nulls, 0, sizeof(int32_t) * MAX_OUT, s));
+  auto make_out = [&](data_type t, bool nullable) {
+    auto col = std::make_unique<column>(t, static_cast<size_type>(G),
+                                        rmm::device_buffer{static_cast<size_t>(G) * size_of(t), s, mr},
+                                        nullable ? create_null_mask(static_cast<size_type>(G), mask_state::UNINITIALIZED, stream, mr)
+                                                 : rmm::device_buffer{},
+                                        0);
+    return col;
+  };
+  for (int c = 0; c < p.nkeycols; ++c) {
+    auto const& kc = _keys.column(c);
+    auto col       = make_out(kc.type(), kc.nullable());
+    out_desc d{};
+    auto mv       = col->mutable_view();
+    d.data        = mv.head();
+    d.mask        = kc.nullable() ? mv.null_mask() : nullptr;
+    d.null_count  = d_nulls + fin.nout;
+    d.kind        = OUT_KEY;
+    d.a0          = static_cast<int8_t>(c);
+    d.width       = static_cast<int8_t>(p.cols[c].width);
+    d.key_unit    = static_cast<int8_t>(hp.key_unit[c]);
+    d.key_full    = hp.key_half[c] == 2;
+    d.key_hi      = hp.key_half[c] == 1;
+    d.key_null_bit  = (hp.keynulls_unit >= 0 && kc.has_nulls()) ? static_cast<int8_t>(c) : int8_t{-1};
+    d.keynulls_unit = static_cast<int8_t>(hp.keynulls_unit);
+    d.keynulls_hi   = static_cast<int8_t>(hp.keynulls_hi);
+    d.valid_acc     = -1;
+    fin.out[fin.nout++] = d;
+    key_cols.push_back(std::move(col));
+  }
+  for (auto const& rs : hp.results) {
+    auto col = make_out(rs.target, rs.nullable);
+    out_desc d{};
+    auto mv      = col->mutable_view();
+    d.data       = mv.head();
+    d.mask       = rs.nullable ? mv.null_mask() : nullptr;
+    d.null_count = d_nulls + fin.nout;
+    d.kind       = (rs.kind == aggregation::COUNT_VALID || rs.kind == aggregation::COUNT_ALL) ? OUT_COUNT
+                   : rs.kind == aggregation::MEAN                                              ? OUT_MEAN
+                                                                                               : OUT_ACC;
+    d.a0         = static_cast<int8_t>(rs.a0);
+    d.a1         = static_cast<int8_t>(rs.a1);
+    d.valid_acc  = static_cast<int8_t>(rs.valid_acc);
+    d.cls        = static_cast<int8_t>(rs.acc_cls);
+    d.width      = static_cast<int8_t>(size_of(rs.target));
+    d.out_cls    = static_cast<int8_t>(class_of(rs.target.id()));
+    d.key_null_bit = -1;
+    fin.out[fin.nout++] = d;
+    res_cols.push_back(std::move(col));
+  }
+  launch_finalize(p, fin, partial, ag.cap, d_prefix, nitems, G, s);
+  std::vector<int32_t> h_nulls(MAX_OUT, 0);
+  CUDF_HIP_TRY(hipMemcpyAsync(h_nulls.data(), d_nulls, sizeof(int32_t) * MAX_OUT, hipMemcpyDeviceToHost, s));
+  CUDF_HIP_TRY(hipStreamSynchronize(s));
+  int oc = 0;
+  for (auto& k : key_cols) k->set_null_count(h_nulls[oc++]);
+  for (auto& r : res_cols) r->set_null_count(h_nulls[oc++]);
+
+  // ---- hand results back in request order; every (column, aggregation) pair has its own column, so a
+  // repeated pair needs no cache deep copy (reference groupby/common/utils.hpp:39-51 copies instead).
+  std::vector<aggregation_result> results;
+  size_t ri = 0;
+  for (auto const& r : requests) {
+    aggregation_result ar;
+    for (size_t j = 0; j < r.aggregations.size(); ++j) ar.results.push_back(std::move(res_cols[ri++]));
+    results.push_back(std::move(ar));
+  }
+  return {std::make_unique<table>(std::move(key_cols)), std::move(results)};
+}
+
+}  // namespace groupby
+}  // namespace cudf

@@ -1,0 +1,739 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 kernels of the hash-groupby engine (see engine.hpp for the design). Every kernel is HBM- or
+// LDS-bound integer/byte work: 64-lane waves, LDS hash tables with native ds_* atomics, LDS-staged
+// multi-split for coalesced partition writes; no MFMA, no global atomics on the per-row path.
+#include "engine.hpp"
+
+#include <cudf/utilities/error.hpp>
+
+namespace cudf::groupby::detail {
+
+using cudf::detail::col_is_valid;
+using cudf::detail::col_load_acc_bits;
+using cudf::detail::col_load_bits;
+using cudf::detail::mix64;
+using cudf::detail::normalize_key_bits;
+
+namespace {
+
+constexpr uint32_t ST_EMPTY  = 0;
+constexpr uint32_t ST_LOCKED = 1;
+
+__device__ __forceinline__ uint32_t tag_of(uint64_t h) { return (static_cast<uint32_t>(h >> 20) & ~3u) | 2u; }
+
+// ------------------------------------------------------------------ record building from columns
+// Validity words of one row: keynulls bit c = key column c NULL; valvalid bit v = value column v valid.
+__device__ __forceinline__ void row_validity(plan_dev const& p, int64_t row, uint32_t& keynulls, uint32_t& valvalid)
+{
+  keynulls = 0;
+  valvalid = 0;
+  for (int c = 0; c < p.ncols; ++c) {
+    if (p.cols[c].mask == nullptr) {
+      if (c >= p.nkeycols) valvalid |= 1u << (c - p.nkeycols);
+      continue;
+    }
+    bool const v = col_is_valid(p.cols[c], row);
+    if (c < p.nkeycols) {
+      if (!v) keynulls |= 1u << c;
+    } else if (v) {
+      valvalid |= 1u << (c - p.nkeycols);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t half_bits(plan_dev const& p, int8_t src, int64_t row, uint32_t keynulls,
+                                              uint32_t valvalid)
+{
+  if (src == H_NONE) return 0;
+  if (src == H_KEYNULLS) return keynulls;
+  if (src == H_VALVALID) return valvalid;
+  if ((keynulls >> src) & 1u) return 0;  // NULL key element: data zeroed so equal NULLs compare equal
+  return static_cast<uint32_t>(normalize_key_bits(col_load_bits(p.cols[src], row), p.cols[src].cls));
+}
+
+__device__ __forceinline__ uint64_t unit_bits(plan_dev const& p, int u, int64_t row, uint32_t keynulls,
+                                              uint32_t valvalid)
+{
+  unit_desc const d = p.unit[u];
+  if (d.full) {
+    if (d.is_key) {
+      if ((keynulls >> d.lo) & 1u) return 0;
+      return normalize_key_bits(col_load_bits(p.cols[d.lo], row), p.cols[d.lo].cls);
+    }
+    return col_load_acc_bits(p.cols[d.lo], row);
+  }
+  return static_cast<uint64_t>(half_bits(p, d.lo, row, keynulls, valvalid)) |
+         (static_cast<uint64_t>(half_bits(p, d.hi, row, keynulls, valvalid)) << 32);
+}
+
+// Key units of one row from the columns; false if the row is dropped (null_policy::EXCLUDE).
+template <int KUT>
+__device__ __forceinline__ bool build_key_units(plan_dev const& p, int64_t row, uint64_t (&key)[KUT], uint32_t& valvalid)
+{
+  uint32_t keynulls;
+  row_validity(p, row, keynulls, valvalid);
+  if (p.drop_null_keys && keynulls != 0) return false;
+#pragma unroll
+  for (int u = 0; u < KUT; ++u) key[u] = (u < p.KU) ? unit_bits(p, u, row, keynulls, valvalid) : 0;
+  return true;
+}
+
+template <int KUT>
+__device__ __forceinline__ uint64_t hash_key_units(plan_dev const& p, uint64_t const (&key)[KUT])
+{
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+  for (int u = 0; u < KUT; ++u)
+    if (u < p.KU) h = mix64(h ^ (key[u] & p.key_mask[u]));
+  return h;
+}
+
+// ------------------------------------------------------------------ block scan helper
+// Exclusive scan of one uint32 per thread across the block; `total` receives the block sum.
+// `wave_sums` must hold blockDim.x / 64 entries.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_sums, uint32_t& total)
+{
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t const t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t s = lane < nwaves ? wave_sums[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t const t = __shfl_up(s, o);
+      if (lane >= o) s += t;
+    }
+    if (lane < nwaves) wave_sums[lane] = s;  // inclusive
+  }
+  __syncthreads();
+  uint32_t const wave_off = wave == 0 ? 0 : wave_sums[wave - 1];
+  total                   = wave_sums[nwaves - 1];
+  __syncthreads();
+  return wave_off + inc - v;
+}
+
+// ------------------------------------------------------------------ partition: slice bounds
+struct slice_range {
+  int64_t begin, end;
+  int64_t seg_begin;
+};
+__device__ __forceinline__ slice_range slice_of(part_args const& a, int item)
+{
+  int const g = item / a.geom.slices, s = item % a.geom.slices;
+  int64_t const b = a.from_columns ? 0 : a.seg_offsets[g];
+  int64_t const e = a.from_columns ? a.nrows : a.seg_offsets[g + 1];
+  int64_t const per = (e - b + a.geom.slices - 1) / a.geom.slices;
+  slice_range r;
+  r.seg_begin = b;
+  r.begin     = min(e, b + per * s);
+  r.end       = min(e, r.begin + per);
+  return r;
+}
+
+__device__ __forceinline__ uint32_t digit_of(part_args const& a, uint64_t h)
+{
+  return static_cast<uint32_t>(h >> a.geom.shift) & static_cast<uint32_t>(a.geom.P - 1);
+}
+
+// ------------------------------------------------------------------ K_hist
+__global__ void __launch_bounds__(1024) k_partition_hist(part_args a)
+{
+  extern __shared__ uint32_t lds_hist[];
+  int const P = a.geom.P;
+  for (int d = threadIdx.x; d < P; d += blockDim.x) lds_hist[d] = 0;
+  __syncthreads();
+  slice_range const sr = slice_of(a, blockIdx.x);
+  int const U          = a.plan.KU + a.plan.NPAY;
+  for (int64_t r = sr.begin + threadIdx.x; r < sr.end; r += blockDim.x) {
+    uint64_t key[MAX_KU];
+    bool keep = true;
+    if (a.from_columns) {
+      uint32_t vv;
+      keep = build_key_units<MAX_KU>(a.plan, r, key, vv);
+    } else {
+#pragma unroll
+      for (int u = 0; u < MAX_KU; ++u) key[u] = (u < a.plan.KU) ? a.in_records[r * U + u] : 0;
+    }
+    if (keep) atomicAdd(&lds_hist[digit_of(a, hash_key_units<MAX_KU>(a.plan, key))], 1u);
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < P; d += blockDim.x) a.counts[static_cast<int64_t>(blockIdx.x) * P + d] = lds_hist[d];
+}
+
+// ------------------------------------------------------------------ K_scan: one block per segment
+__global__ void __launch_bounds__(1024) k_partition_scan(part_args a)
+{
+  __shared__ uint32_t wave_sums[16];
+  extern __shared__ uint32_t lds_tot[];  // P totals, then P exclusive offsets
+  int const P = a.geom.P, S = a.geom.slices, g = blockIdx.x;
+  int64_t const seg_begin = a.from_columns ? 0 : a.seg_offsets[g];
+  uint32_t* tot  = lds_tot;
+  uint32_t* excl = lds_tot + P;
+  for (int d = threadIdx.x; d < P; d += blockDim.x) {
+    uint32_t t = 0;
+    for (int s = 0; s < S; ++s) t += a.counts[(static_cast<int64_t>(g) * S + s) * P + d];
+    tot[d] = t;
+  }
+  __syncthreads();
+  // exclusive scan of tot over d: each thread owns a contiguous run of E entries
+  int const E = (P + blockDim.x - 1) / blockDim.x;
+  uint32_t local = 0;
+  for (int k = 0; k < E; ++k) {
+    int const d = threadIdx.x * E + k;
+    if (d < P) local += tot[d];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(local, wave_sums, total);
+  for (int k = 0; k < E; ++k) {
+    int const d = threadIdx.x * E + k;
+    if (d < P) {
+      excl[d] = run;
+      run += tot[d];
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < P; d += blockDim.x) {
+    int64_t running = seg_begin + excl[d];
+    a.out_offsets[static_cast<int64_t>(g) * P + d] = running;
+    for (int s = 0; s < S; ++s) {
+      int64_t const idx = (static_cast<int64_t>(g) * S + s) * P + d;
+      a.item_base[idx]  = running;
+      running += a.counts[idx];
+    }
+  }
+  if (g == a.geom.nseg - 1 && threadIdx.x == 0) a.out_offsets[static_cast<int64_t>(a.geom.nseg) * P] = seg_begin + total;
+}
+
+// ------------------------------------------------------------------ K_scatter
+// One workgroup per (segment, slice). Per tile of T = blockDim * RPT rows: rank rows inside their partition
+// with an LDS histogram, exclusive-scan the histogram, stage the records in LDS in partition order and write
+// them out so that consecutive lanes write consecutive records of one partition (runs of T/P records).
+// LDS layout: stage[T*U] u64 | delta[P] i64 | hist[P] u32 | pid[T] u16 | wave_sums[16] u32
+template <int UT, int RPT>
+__global__ void __launch_bounds__(1024) k_partition_scatter(part_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  int const P = a.geom.P, B = blockDim.x, T = B * RPT;
+  int const U = a.plan.KU + a.plan.NPAY;  // <= UT
+  uint64_t* stage     = reinterpret_cast<uint64_t*>(lds_raw);
+  int64_t* delta      = reinterpret_cast<int64_t*>(stage + static_cast<size_t>(T) * U);
+  uint32_t* hist      = reinterpret_cast<uint32_t*>(delta + P);
+  uint16_t* pid       = reinterpret_cast<uint16_t*>(hist + P);
+  uint32_t* wave_sums = reinterpret_cast<uint32_t*>(pid + T + (T & 1));
+
+  int const item       = blockIdx.x;
+  slice_range const sr = slice_of(a, item);
+  // Thread t owns partitions d = t*MAXE + k: their running output cursor lives in registers.
+  constexpr int MAXE = 2;  // P <= 2 * B
+  int64_t cursor[MAXE];
+#pragma unroll
+  for (int k = 0; k < MAXE; ++k) {
+    int const d = threadIdx.x * MAXE + k;
+    cursor[k]   = d < P ? a.item_base[static_cast<int64_t>(item) * P + d] : 0;
+    if (d < P) hist[d] = 0;
+  }
+  __syncthreads();
+
+  for (int64_t tile = sr.begin; tile < sr.end; tile += T) {
+    uint64_t rec[RPT][UT];
+    uint32_t dig[RPT], rank[RPT];
+    bool keep[RPT];
+    // phase 1: load, hash, rank within (tile, partition)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      int64_t const r = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+      keep[k]         = r < sr.end;
+      if (keep[k]) {
+        if (a.from_columns) {
+          uint32_t keynulls, valvalid;
+          row_validity(a.plan, r, keynulls, valvalid);
+          if (a.plan.drop_null_keys && keynulls != 0) keep[k] = false;
+          if (keep[k]) {
+#pragma unroll
+            for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? unit_bits(a.plan, u, r, keynulls, valvalid) : 0;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? a.in_records[r * U + u] : 0;
+        }
+      }
+      if (keep[k]) {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+        for (int u = 0; u < (UT < MAX_KU ? UT : MAX_KU); ++u)
+          if (u < a.plan.KU) h = mix64(h ^ (rec[k][u] & a.plan.key_mask[u]));
+        dig[k]  = digit_of(a, h);
+        rank[k] = atomicAdd(&hist[dig[k]], 1u);
+      }
+    }
+    __syncthreads();
+    // phase 2: hist -> exclusive local offsets (in place); delta = global cursor - local offset
+    uint32_t hv[MAXE], local = 0;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      int const d = threadIdx.x * MAXE + k;
+      hv[k]       = d < P ? hist[d] : 0;
+      local += hv[k];
+    }
+    uint32_t tile_count;
+    uint32_t run = block_exclusive_scan(local, wave_sums, tile_count);
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      int const d = threadIdx.x * MAXE + k;
+      if (d < P) {
+        hist[d]  = run;
+        delta[d] = cursor[k] - static_cast<int64_t>(run);
+        cursor[k] += hv[k];
+        run += hv[k];
+      }
+    }
+    __syncthreads();
+    // phase 3: stage records in partition order
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      if (keep[k]) {
+        uint32_t const pos = hist[dig[k]] + rank[k];
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+          if (u < U) stage[static_cast<size_t>(pos) * U + u] = rec[k][u];
+        pid[pos] = static_cast<uint16_t>(dig[k]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      int const d = threadIdx.x * MAXE + k;
+      if (d < P) hist[d] = 0;
+    }
+    // phase 4: coalesced write-out; consecutive staged records of one partition go to consecutive slots
+    for (uint32_t j = threadIdx.x; j < tile_count; j += B) {
+      int64_t const dst = delta[pid[j]] + static_cast<int64_t>(j);
+#pragma unroll
+      for (int u = 0; u < UT; ++u)
+        if (u < U) a.out_records[dst * U + u] = stage[static_cast<size_t>(j) * U + u];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ K_aggregate
+__device__ __forceinline__ uint64_t acc_identity(int op)
+{
+  switch (op) {
+    case MIN_I64: return static_cast<uint64_t>(INT64_MAX);
+    case MIN_U64: return UINT64_MAX;
+    case MIN_F64: return 0x7ff0000000000000ull;  // +inf
+    case MAX_I64: return static_cast<uint64_t>(INT64_MIN);
+    case MAX_U64: return 0;
+    case MAX_F64: return 0xfff0000000000000ull;  // -inf
+    default: return 0;                            // ADD_I64 / ADD_F64
+  }
+}
+
+__device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
+{
+  switch (op) {
+    case ADD_I64: atomicAdd(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case ADD_F64: atomicAdd(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v))); break;
+    case MIN_I64: atomicMin(reinterpret_cast<long long*>(slot), static_cast<long long>(v)); break;
+    case MIN_U64: atomicMin(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case MAX_I64: atomicMax(reinterpret_cast<long long*>(slot), static_cast<long long>(v)); break;
+    case MAX_U64: atomicMax(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case MIN_F64:
+      __hip_atomic_fetch_min(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    case MAX_F64:
+      __hip_atomic_fetch_max(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+  }
+}
+
+// Finds or claims the slot of `key` in the LDS table. Returns -1 if the table is saturated.
+template <int KUT>
+__device__ __forceinline__ int lds_find_or_insert(plan_dev const& p, uint32_t* st, uint64_t* keys, int cap,
+                                                  uint64_t const (&key)[KUT], uint64_t h, uint32_t* nfilled,
+                                                  int fill_limit, int32_t* overflow_flag)
+{
+  uint32_t const tag = tag_of(h);
+  int slot = static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(h)) * static_cast<uint32_t>(cap)) >> 32);
+  for (int probes = 0; probes < cap; ++probes) {
+    uint32_t s = __hip_atomic_load(&st[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (s == ST_EMPTY) {
+      uint32_t const old = atomicCAS(&st[slot], ST_EMPTY, ST_LOCKED);
+      if (old == ST_EMPTY) {
+#pragma unroll
+        for (int u = 0; u < KUT; ++u)
+          if (u < p.KU) keys[static_cast<size_t>(u) * cap + slot] = key[u] & p.key_mask[u];
+        // publish: key words first, then the tag (LDS executes a wave's accesses in order; the release fence
+        // keeps the compiler from reordering and waits for the key stores)
+        __hip_atomic_store(&st[slot], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t const n = atomicAdd(nfilled, 1u);
+        if (static_cast<int>(n) >= fill_limit) *overflow_flag = 1;
+        return slot;
+      }
+      s = old;
+    }
+    if (s == ST_LOCKED) {
+      --probes;  // owner is publishing: re-read the same slot
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    if (s == tag) {
+      bool eq = true;
+#pragma unroll
+      for (int u = 0; u < KUT; ++u)
+        if (u < p.KU) eq = eq && (keys[static_cast<size_t>(u) * cap + slot] == (key[u] & p.key_mask[u]));
+      if (eq) return slot;
+    }
+    slot = slot + 1 == cap ? 0 : slot + 1;
+  }
+  *overflow_flag = 1;
+  return -1;
+}
+
+template <int KUT>
+__global__ void __launch_bounds__(1024) k_aggregate(agg_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  plan_dev const& p = a.plan;
+  int const cap     = a.geom.cap;
+  int const KU = p.KU, NACC = p.NACC;
+  uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);                 // [KU][cap]
+  uint64_t* accs = keys + static_cast<size_t>(KU) * cap;                   // [NACC][cap]
+  uint32_t* st   = reinterpret_cast<uint32_t*>(accs + static_cast<size_t>(NACC) * cap);  // [cap]
+  __shared__ uint32_t s_nfilled, s_dump;
+  __shared__ int32_t s_overflow;
+
+  if (threadIdx.x == 0) {
+    s_nfilled  = 0;
+    s_dump     = 0;
+    s_overflow = 0;
+  }
+  for (int s = threadIdx.x; s < cap; s += blockDim.x) st[s] = ST_EMPTY;
+  for (int q = 0; q < NACC; ++q) {
+    uint64_t const id = acc_identity(p.acc[q].op);
+    for (int s = threadIdx.x; s < cap; s += blockDim.x) accs[static_cast<size_t>(q) * cap + s] = id;
+  }
+  __syncthreads();
+
+  int const item = blockIdx.x;
+  int const RU   = KU + p.NPAY;  // raw record units
+  int const PU   = KU + NACC;    // partial record units
+  int nsrc = 1, src0 = item;
+  if (a.seg == SEG_STRIDED) {
+    src0 = item * a.fan;
+    nsrc = min(a.fan, a.nsrc - src0);
+  }
+  for (int sidx = 0; sidx < nsrc; ++sidx) {
+    int64_t begin, end;
+    if (a.seg == SEG_ROW_CHUNKS) {
+      begin = static_cast<int64_t>(item) * a.chunk;
+      end   = min(a.nrows, begin + a.chunk);
+    } else if (a.seg == SEG_OFFSETS) {
+      begin = a.offsets[item];
+      end   = a.offsets[item + 1];
+    } else {
+      begin = static_cast<int64_t>(src0 + sidx) * a.src_stride;
+      end   = begin + a.src_count[src0 + sidx];
+    }
+    for (int64_t r = begin + threadIdx.x; r < end; r += blockDim.x) {
+      uint64_t key[KUT];
+      uint32_t valvalid = 0xffffffffu;
+      bool keep         = true;
+      if (a.input == IN_COLUMNS) {
+        keep = build_key_units<KUT>(p, r, key, valvalid);
+      } else {
+        int const U = a.input == IN_RAW_RECORDS ? RU : PU;
+#pragma unroll
+        for (int u = 0; u < KUT; ++u) key[u] = (u < KU) ? a.records[r * U + u] : 0;
+        if (a.input == IN_RAW_RECORDS && p.flags_unit >= 0)
+          valvalid = reinterpret_cast<uint32_t const*>(a.records + r * U + p.flags_unit)[p.flags_hi];
+      }
+      if (!keep) continue;
+      uint64_t const h = hash_key_units<KUT>(p, key);
+      int const slot   = lds_find_or_insert<KUT>(p, st, keys, cap, key, h, &s_nfilled, a.geom.fill_limit, &s_overflow);
+      if (slot < 0) continue;
+      int last_pay   = -1;
+      uint64_t value = 0;
+      for (int q = 0; q < NACC; ++q) {
+        acc_desc const d = p.acc[q];
+        uint64_t* tgt    = accs + static_cast<size_t>(q) * cap + slot;
+        if (a.input == IN_PARTIAL_RECORDS) {
+          lds_merge(tgt, d.op, a.records[r * PU + KU + q]);
+          continue;
+        }
+        bool const valid = d.valid_bit < 0 || ((valvalid >> d.valid_bit) & 1u);
+        if (d.src == SRC_ONE) {
+          lds_merge(tgt, ADD_I64, 1);
+          continue;
+        }
+        if (!valid) continue;
+        if (d.src == SRC_ONE_IF_VALID) {
+          lds_merge(tgt, ADD_I64, 1);
+          continue;
+        }
+        if (d.pay != last_pay) {
+          value    = a.input == IN_COLUMNS ? col_load_acc_bits(p.cols[p.nkeycols + d.pay], r)
+                                           : a.records[r * RU + KU + d.pay];
+          last_pay = d.pay;
+        }
+        uint64_t v = value;
+        if (d.src == SRC_SQUARE) {
+          if (d.op == ADD_F64) {
+            double const x = __longlong_as_double(static_cast<long long>(v));
+            v              = static_cast<uint64_t>(__double_as_longlong(x * x));
+          } else {
+            v = v * v;
+          }
+        }
+        lds_merge(tgt, d.op, v);
+      }
+    }
+  }
+  __syncthreads();
+  // dump the table as compact partial records
+  uint64_t* out = a.out_records + static_cast<int64_t>(item) * cap * PU;
+  for (int s = threadIdx.x; s < cap; s += blockDim.x) {
+    if (st[s] >= 2) {
+      uint32_t const pos = atomicAdd(&s_dump, 1u);
+      uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
+      for (int u = 0; u < KU; ++u) o[u] = keys[static_cast<size_t>(u) * cap + s];
+      for (int q = 0; q < NACC; ++q) o[KU + q] = accs[static_cast<size_t>(q) * cap + s];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.out_count[item] = static_cast<int32_t>(s_dump);
+    if (s_overflow) *a.overflow = 1;
+  }
+}
+
+// ------------------------------------------------------------------ K_finalize
+__device__ __forceinline__ void store_elem(void* base, int64_t i, int width, uint64_t bits)
+{
+  switch (width) {
+    case 1: static_cast<uint8_t*>(base)[i] = static_cast<uint8_t>(bits); break;
+    case 2: static_cast<uint16_t*>(base)[i] = static_cast<uint16_t>(bits); break;
+    case 4: static_cast<uint32_t*>(base)[i] = static_cast<uint32_t>(bits); break;
+    default: static_cast<uint64_t*>(base)[i] = bits;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_finalize(plan_dev p, finalize_dev f, uint64_t const* records, int64_t cap,
+                                                  int64_t const* prefix, int32_t nitems, int64_t total)
+{
+  int64_t const o = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  bool const live = o < total;
+  int const PU    = p.KU + p.NACC;
+  uint64_t const* rec = nullptr;
+  if (live) {
+    // largest item with prefix[item] <= o
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) {
+      int const mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= o) lo = mid; else hi = mid - 1;
+    }
+    rec = records + (static_cast<int64_t>(lo) * cap + (o - prefix[lo])) * PU;
+  }
+  int const lane = threadIdx.x & 63;
+  for (int c = 0; c < f.nout; ++c) {
+    out_desc const d = f.out[c];
+    bool valid       = live;
+    uint64_t bits    = 0;
+    if (live) {
+      if (d.kind == OUT_KEY) {
+        uint64_t const unit = rec[d.key_unit];
+        bits                = d.key_full ? unit : (d.key_hi ? (unit >> 32) : (unit & 0xffffffffull));
+        if (d.key_null_bit >= 0) {
+          uint64_t const kn = rec[d.keynulls_unit];
+          uint32_t const w  = d.keynulls_hi ? static_cast<uint32_t>(kn >> 32) : static_cast<uint32_t>(kn);
+          valid             = !((w >> d.key_null_bit) & 1u);
+        }
+      } else {
+        uint64_t const a0 = rec[p.KU + d.a0];
+        if (d.valid_acc >= 0) valid = static_cast<int64_t>(rec[p.KU + d.valid_acc]) > 0;
+        if (d.kind == OUT_COUNT) {
+          bits = a0;
+        } else if (d.kind == OUT_MEAN) {
+          // MEAN = double(SUM) / COUNT_VALID as FLOAT64 (reference hash_compound_agg_finalizer.cu:92-133)
+          double const s = d.cls == cudf::detail::CLS_F64 ? __longlong_as_double(static_cast<long long>(a0))
+                           : d.cls == cudf::detail::CLS_UINT ? static_cast<double>(a0)
+                                                             : static_cast<double>(static_cast<int64_t>(a0));
+          double const n = static_cast<double>(static_cast<int64_t>(rec[p.KU + d.a1]));
+          bits           = static_cast<uint64_t>(__double_as_longlong(valid ? s / n : 0.0));
+        } else {  // OUT_ACC: accumulator class -> output type
+          if (d.cls == cudf::detail::CLS_F64 && d.out_cls == cudf::detail::CLS_F32) {
+            bits = __float_as_uint(static_cast<float>(__longlong_as_double(static_cast<long long>(a0))));
+          } else {
+            bits = a0;  // integers truncate to the output width; FLOAT64 passes through
+          }
+          if (!valid) bits = 0;
+        }
+      }
+      store_elem(d.data, o, d.width, bits);
+    }
+    if (d.mask != nullptr) {
+      unsigned long long const ballot      = __ballot(valid);  // valid implies live
+      unsigned long long const live_ballot = __ballot(live);
+      if (live && (lane & 31) == 0) d.mask[o >> 5] = static_cast<uint32_t>(ballot >> (lane & 32));
+      int const nulls = __popcll(live_ballot & ~ballot);
+      if (lane == 0 && nulls) atomicAdd(d.null_count, nulls);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K_estimate (linear counting on a sample)
+__global__ void __launch_bounds__(256) k_estimate(plan_dev p, int64_t nrows, int64_t sample, uint32_t* bitmap,
+                                                  int32_t bits_log2)
+{
+  int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= sample) return;
+  int64_t const row = sample >= nrows ? i : static_cast<int64_t>((static_cast<__int128>(i) * nrows) / sample);
+  uint64_t key[MAX_KU];
+  uint32_t vv;
+  if (!build_key_units<MAX_KU>(p, row, key, vv)) return;
+  uint64_t const h   = hash_key_units<MAX_KU>(p, key);
+  uint32_t const bit = static_cast<uint32_t>(h >> (64 - bits_log2));
+  atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+}
+__global__ void __launch_bounds__(256) k_popcount(uint32_t const* bitmap, int64_t nwords, uint32_t* out)
+{
+  int64_t i     = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  uint32_t acc  = 0;
+  for (; i < nwords; i += static_cast<int64_t>(gridDim.x) * blockDim.x) acc += __popc(bitmap[i]);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+inline int next_ut(int u)
+{
+  for (int c : {2, 3, 4, 6, 8, 12, 16})
+    if (u <= c) return c;
+  return -1;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+// Opts a kernel into the full 160 KiB of LDS (static + dynamic) once per process.
+static void allow_full_lds(void const* fn)
+{
+  hipFuncAttributes attr{};
+  CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
+  int const dyn = 160 * 1024 - static_cast<int>(attr.sharedSizeBytes);
+  CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+}
+
+std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g)
+{
+  return static_cast<std::size_t>(g.cap) * (8u * (plan.KU + plan.NACC) + 4u);
+}
+
+static int scatter_rpt(int ut) { return ut <= 2 ? 8 : ut <= 4 ? 4 : ut <= 8 ? 2 : 1; }
+
+std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g)
+{
+  int const U = plan.KU + plan.NPAY;
+  std::size_t const T = g.tile_rows;
+  return T * U * 8 + static_cast<std::size_t>(g.P) * (8 + 4) + (T + (T & 1)) * 2 + 16 * 4;
+}
+
+void launch_partition_hist(part_args const& a, hipStream_t stream)
+{
+  int const items = a.geom.nseg * a.geom.slices;
+  hipLaunchKernelGGL(k_partition_hist, dim3(items), dim3(a.geom.block), a.geom.P * sizeof(uint32_t), stream, a);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_partition_scan(part_args const& a, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_partition_scan, dim3(a.geom.nseg), dim3(1024), 2 * a.geom.P * sizeof(uint32_t), stream, a);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+template <int UT, int RPT>
+static void launch_scatter_t(part_args const& a, hipStream_t stream)
+{
+  part_args b   = a;
+  b.geom.tile_rows = b.geom.block * RPT;
+  auto const lds = partition_lds_bytes(b.plan, b.geom);
+  CUDF_EXPECTS(lds <= 160 * 1024, "partition kernel: LDS budget exceeded (fan-out too large for this record width)");
+  static bool attr_set = false;
+  if (!attr_set) {
+    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter<UT, RPT>));
+    attr_set = true;
+  }
+  int const items = b.geom.nseg * b.geom.slices;
+  hipLaunchKernelGGL((k_partition_scatter<UT, RPT>), dim3(items), dim3(b.geom.block), lds, stream, b);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_partition_scatter(part_args const& a, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.geom.P <= 2 * a.geom.block, "partition fan-out exceeds 2x the block size");
+  int const U = a.plan.KU + a.plan.NPAY;
+  switch (next_ut(U)) {
+    case 2: launch_scatter_t<2, 8>(a, stream); break;
+    case 3: launch_scatter_t<3, 4>(a, stream); break;
+    case 4: launch_scatter_t<4, 4>(a, stream); break;
+    case 6: launch_scatter_t<6, 2>(a, stream); break;
+    case 8: launch_scatter_t<8, 2>(a, stream); break;
+    case 12: launch_scatter_t<12, 1>(a, stream); break;
+    case 16: launch_scatter_t<16, 1>(a, stream); break;
+    default: CUDF_FAIL("record too wide for the partition kernel");
+  }
+}
+
+template <int KUT>
+static void launch_aggregate_t(agg_args const& a, hipStream_t stream)
+{
+  auto const lds = aggregate_lds_bytes(a.plan, a.geom);
+  static bool attr_set = false;
+  if (!attr_set) {
+    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<KUT>));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_aggregate<KUT>), dim3(a.nitems), dim3(a.geom.block), lds, stream, a);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_aggregate(agg_args const& a, hipStream_t stream)
+{
+  if (a.nitems == 0) return;
+  if (a.plan.KU <= 1) launch_aggregate_t<1>(a, stream);
+  else if (a.plan.KU <= 2) launch_aggregate_t<2>(a, stream);
+  else launch_aggregate_t<4>(a, stream);
+}
+
+void launch_finalize(plan_dev const& plan, finalize_dev const& fin, uint64_t const* records, int64_t cap,
+                     int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream)
+{
+  if (total == 0) return;
+  int const block = 256;
+  int64_t const grid = (total + block - 1) / block;
+  hipLaunchKernelGGL(k_finalize, dim3(static_cast<unsigned>(grid)), dim3(block), 0, stream, plan, fin, records, cap, prefix,
+                     nitems, total);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_estimate(plan_dev const& plan, int64_t nrows, int64_t sample, uint32_t* bitmap, int32_t bitmap_bits_log2,
+                     uint32_t* d_bits_set, hipStream_t stream)
+{
+  int64_t const nwords = (int64_t{1} << bitmap_bits_log2) / 32;
+  CUDF_HIP_TRY(hipMemsetAsync(bitmap, 0, nwords * 4, stream));
+  CUDF_HIP_TRY(hipMemsetAsync(d_bits_set, 0, 4, stream));
+  int const block = 256;
+  hipLaunchKernelGGL(k_estimate, dim3(static_cast<unsigned>((sample + block - 1) / block)), dim3(block), 0, stream, plan,
+                     nrows, sample, bitmap, bitmap_bits_log2);
+  hipLaunchKernelGGL(k_popcount, dim3(256), dim3(block), 0, stream, bitmap, nwords, d_bits_set);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cudf::groupby::detail

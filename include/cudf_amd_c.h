@@ -1,0 +1,94 @@
+/* SPDX-License-Identifier: Apache-2.0
+ * Flat C ABI of libcudf_amd.so — plain pointers and sizes, no C++ / torch types.
+ *
+ * The reference has no C ABI: its boundary is the C++ API of libcudf.so that pylibcudf (Cython) and the JNI
+ * layer bind directly. This header is the equivalent a ctypes / cgo / JNI / N-API binding
+ * would use; every entry point names the reference interface it stands for. The same library also exports
+ * the source-compatible C++ API under include/cudf/ (cudf::groupby::groupby, cudf::inner_join, ...), which is
+ * what a Cython .pxd would declare.
+ *
+ * Conventions: all device pointers are HIP device pointers valid on the current device; `stream` is a
+ * hipStream_t passed as void* (NULL = default stream); every function returns a cudf_amd_status and, on
+ * failure, leaves the message in cudf_amd_last_error() (thread-local). Inputs are non-owning views, outputs
+ * are owning handles released with cudf_amd_table_free (ownership rule of reference groupby.hpp:106-108).
+ */
+#ifndef CUDF_AMD_C_H
+#define CUDF_AMD_C_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Maps the C++ exception types of the reference's error convention (cpp/include/cudf/utilities/error.hpp:35,
+ * 63,86,97; pylibcudf exception_handler.pxd:34-64). */
+typedef enum {
+  CUDF_AMD_OK               = 0,
+  CUDF_AMD_LOGIC_ERROR      = 1, /* cudf::logic_error        -> RuntimeError    */
+  CUDF_AMD_INVALID_ARGUMENT = 2, /* std::invalid_argument    -> ValueError      */
+  CUDF_AMD_DATA_TYPE_ERROR  = 3, /* cudf::data_type_error    -> TypeError       */
+  CUDF_AMD_DEVICE_ERROR     = 4, /* cudf::cuda_error (HIP)   -> RuntimeError    */
+  CUDF_AMD_BAD_ALLOC        = 5, /* std::bad_alloc           -> MemoryError     */
+  CUDF_AMD_OTHER_ERROR      = 6
+} cudf_amd_status;
+
+/* cudf::column_view (reference cpp/include/cudf/column/column_view.hpp:236-244): element i at
+ * data[(offset+i)], validity bit (offset+i) of null_mask (LSB-first, 1 = valid); null_mask NULL = all valid. */
+typedef struct {
+  int32_t type_id; /* cudf::type_id (reference types.hpp:185-217) */
+  int32_t size;
+  const void* data;
+  const uint32_t* null_mask;
+  int32_t null_count;
+  int32_t offset;
+  int32_t scale; /* fixed-point scale, 0 otherwise */
+} cudf_amd_column_view;
+
+/* cudf::groupby::aggregation_request (reference groupby.hpp:54-57); kinds = cudf::aggregation::Kind values
+ * (aggregation.hpp:78-121). */
+typedef struct {
+  cudf_amd_column_view values;
+  const int32_t* kinds;
+  int32_t num_kinds;
+} cudf_amd_aggregation_request;
+
+/* Owning cudf::table / vector of cudf::column. */
+typedef struct cudf_amd_table_s* cudf_amd_table_t;
+/* Owning cudf::hash_join. */
+typedef struct cudf_amd_hash_join_s* cudf_amd_hash_join_t;
+
+const char* cudf_amd_last_error(void);
+const char* cudf_amd_version(void);
+
+/* ---- device memory / stream plumbing for bindings without a device allocator of their own */
+cudf_amd_status cudf_amd_malloc(void** ptr, size_t bytes, void* stream);
+cudf_amd_status cudf_amd_free(void* ptr, void* stream);
+/* kind: 0 host->device, 1 device->host, 2 device->device; asynchronous on `stream`. */
+cudf_amd_status cudf_amd_memcpy(void* dst, const void* src, size_t bytes, int32_t kind, void* stream);
+cudf_amd_status cudf_amd_memset(void* dst, int32_t value, size_t bytes, void* stream);
+cudf_amd_status cudf_amd_stream_synchronize(void* stream);
+/* Live / peak bytes handed out by the library's current device resource since load. */
+cudf_amd_status cudf_amd_memory_stats(uint64_t* current_bytes, uint64_t* peak_bytes);
+
+/* ---- owning tables */
+int32_t cudf_amd_table_num_columns(cudf_amd_table_t t);
+int32_t cudf_amd_table_num_rows(cudf_amd_table_t t);
+cudf_amd_status cudf_amd_table_column(cudf_amd_table_t t, int32_t i, cudf_amd_column_view* out);
+void cudf_amd_table_free(cudf_amd_table_t t);
+
+/* ---- cudf::groupby::groupby(keys, null_handling, keys_are_sorted).aggregate(requests, stream, mr)
+ * (reference cpp/include/cudf/groupby.hpp:121-125,181-184; src/groupby/groupby.cu:219-236).
+ * include_null_keys: 0 = null_policy::EXCLUDE, 1 = INCLUDE. out_results holds the result columns of all requests
+ * flattened in request order (results[i].results[j]). out_path (optional) reports which kernel family ran
+ * (cudf::groupby::hash_path). */
+cudf_amd_status cudf_amd_groupby_aggregate(const cudf_amd_column_view* keys, int32_t num_keys,
+                                           int32_t include_null_keys, int32_t keys_are_sorted,
+                                           const cudf_amd_aggregation_request* requests, int32_t num_requests,
+                                           void* stream, cudf_amd_table_t* out_keys, cudf_amd_table_t* out_results,
+                                           int32_t* out_path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUDF_AMD_C_H */

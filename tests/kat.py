@@ -1,0 +1,190 @@
+"""Shared KAT / parity harness. Restates the reference's test harness rules:
+ - groupby: sort expected and actual by key, keys EQUAL, values EQUIVALENT
+   (cpp/tests/groupby/groupby_test_util.cpp:36-48,82-89);
+ - join: gather both tables by the returned index vectors, sort rows, compare
+   (cpp/tests/join/join_tests.cpp:70-101,318-345,1250-1252);
+ - floats: |x-y| <= 4*eps*|x+y|, inf/NaN exact (cpp/tests/utilities/column_utilities.cu:436-440).
+A "backend" is anything with groupby(keys, requests, include_null_keys) / join(left, right, nulls_equal, kind)
+taking oracle.HostColumn inputs and returning the oracle's tuple shapes.
+"""
+import json
+import os
+
+import numpy as np
+
+from oracle.oracle import KIND, NP_OF_TYPE_ID, TYPE_ID, HostColumn
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FP_ULPS = 4
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def _num(x):
+    return {"inf": np.inf, "-inf": -np.inf, "nan": np.nan}.get(x, x) if isinstance(x, str) else x
+
+
+def host_col(values, type_name, valid=None):
+    npt = NP_OF_TYPE_ID[TYPE_ID[type_name]]
+    arr = np.array([_num(v) for v in values], dtype=np.float64 if "float" in type_name else np.int64).astype(npt)
+    return HostColumn(arr, None if valid is None else np.array(valid, dtype=bool), type_name)
+
+
+def expected_type_id(value_type, agg):
+    integral = value_type in ("int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "bool")
+    if agg in ("count_valid", "count_all"):
+        return TYPE_ID["int32"]
+    if agg == "mean":
+        return TYPE_ID["float64"]
+    if agg in ("sum", "sum_of_squares", "product"):
+        return TYPE_ID["int64"] if integral else TYPE_ID[value_type]
+    return TYPE_ID[value_type]
+
+
+def equivalent(a, b, is_float, atol=0.0):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    if not is_float:
+        return bool(np.array_equal(a, b))
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        return _equivalent_f64(a, b, atol)
+
+
+def _equivalent_f64(a, b, atol=0.0):
+    nan_ok = np.isnan(a) == np.isnan(b)
+    inf = np.isinf(a) | np.isinf(b)
+    inf_ok = np.where(inf, a == b, True)
+    eps = np.finfo(np.float64).eps
+    fin = ~(np.isnan(a) | np.isnan(b) | inf)
+    close = np.where(fin, np.abs(a - b) <= FP_ULPS * eps * np.abs(a + b) + atol, True)
+    return bool(np.all(nan_ok & inf_ok & close))
+
+
+def equivalent_f32(a, b, atol=0.0):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    eps = np.finfo(np.float32).eps
+    fin = np.isfinite(a) & np.isfinite(b)
+    with np.errstate(invalid="ignore"):
+        ok = np.where(fin, np.abs(a - b) <= FP_ULPS * eps * np.abs(a + b) + atol, (a == b) | (np.isnan(a) & np.isnan(b)))
+    return bool(np.all(ok))
+
+
+def sort_groups(key_cols, result_cols):
+    """Sort rows by the key columns (nulls last), returning permuted copies."""
+    n = len(key_cols[0][0]) if key_cols else 0
+    if n == 0:
+        return key_cols, result_cols
+    sort_keys = []
+    for data, valid, _ in reversed(key_cols):
+        d = np.where(np.isnan(data.astype(np.float64)), np.inf, data) if data.dtype.kind == "f" else data
+        if valid is not None:
+            d = np.where(valid, d, 0)
+            sort_keys.append(d)
+            sort_keys.append(~valid)
+        else:
+            sort_keys.append(d)
+    order = np.lexsort(sort_keys)
+    perm = lambda col: (col[0][order], None if col[1] is None else col[1][order], col[2])
+    return [perm(c) for c in key_cols], [[perm(c) for c in req] for req in result_cols]
+
+
+def sum_atol(max_terms, max_abs):
+    """Worst-case error bound of summing `max_terms` float64 values of magnitude <= max_abs in ANY order:
+    (m-1) * eps * sum|v_i| <= m^2 * eps * max|v| (Higham, Accuracy and Stability, eq. 4.4). The reference sums with
+    unordered atomics (device_atomics.cuh:36-139), so two correct results may differ by this much; the
+    reference's 4-ulp rule (column_utilities.cu:436-440) is kept for everything that is not an order-dependent sum."""
+    return float(max_terms) ** 2 * np.finfo(np.float64).eps * float(max_abs)
+
+
+def compare_columns(actual, expected, what="", atol=0.0):
+    a_data, a_valid, a_tid = actual
+    e_data, e_valid, e_tid = expected
+    assert a_tid == e_tid, f"{what}: type id {a_tid} != {e_tid}"
+    assert len(a_data) == len(e_data), f"{what}: size {len(a_data)} != {len(e_data)}"
+    av = np.ones(len(a_data), bool) if a_valid is None else a_valid
+    ev = np.ones(len(e_data), bool) if e_valid is None else e_valid
+    assert np.array_equal(av, ev), f"{what}: validity differs {av} vs {ev}"
+    is_float = np.dtype(NP_OF_TYPE_ID[a_tid]).kind == "f"
+    a = a_data[av]
+    e = e_data[ev]
+    if a_tid == TYPE_ID["float32"]:
+        assert equivalent_f32(a, e, atol), f"{what}: values differ\n{a}\n{e}"
+    else:
+        assert equivalent(a, e, is_float, atol), f"{what}: values differ\n{a}\n{e}"
+
+
+def groupby_cases():
+    doc = load("kat_groupby.json")
+    for c in doc["cases"]:
+        for kt in c["key_types"]:
+            for vt in c["value_types"]:
+                yield f'{c["name"]}[{kt}-{vt}]', c, kt, vt
+
+
+def run_groupby_case(backend, c, kt, vt):
+    keys = [host_col(c["keys"], kt, c["keys_valid"])]
+    vals = host_col(c["values"], vt, c["values_valid"])
+    kc, rc = backend.groupby(keys, [(vals, [c["agg"]])], include_null_keys=(c["null_policy"] == "include"))
+    kc, rc = sort_groups(kc, rc)
+    if c.get("only_num_groups") is not None:
+        assert len(kc[0][0]) == c["only_num_groups"]
+        return
+    ek = host_col(c["expect_keys"], kt, c["expect_keys_valid"])
+    exp_tid = expected_type_id(vt, c["agg"])
+    exp_np = NP_OF_TYPE_ID[exp_tid]
+    ev_data = np.array([_num(v) for v in c["expect"]], dtype=np.float64 if np.dtype(exp_np).kind == "f" else np.int64).astype(exp_np)
+    ev_valid = None if c["expect_valid"] is None else np.array(c["expect_valid"], dtype=bool)
+    ekc, erc = sort_groups([(ek.data, ek.valid, ek.type_id)], [[(ev_data, ev_valid, exp_tid)]])
+    compare_columns(kc[0], ekc[0], "keys")
+    compare_columns(rc[0][0], erc[0][0], "values")
+
+
+# ---------------------------------------------------------------- joins
+def table_cols(t):
+    return [host_col(col, ty, v) for col, ty, v in zip(t["cols"], t["types"], t["valid"])]
+
+
+def gather_rows(cols, idx):
+    """Rows of `cols` at idx as tuples with None for NULL (idx == JoinNoMatch -> all NULL)."""
+    out = []
+    for i in idx:
+        if i == -2**31:
+            out.append(tuple(None for _ in cols))
+        else:
+            out.append(tuple(None if (c.valid is not None and not c.valid[i]) else c.data[i].item() for c in cols))
+    return out
+
+
+def _row_key(r):
+    return tuple((x is None, 0 if x is None else x) for x in r)
+
+
+def run_join_table_case(backend, c):
+    left, right = table_cols(c["left"]), table_cols(c["right"])
+    lk = [left[i] for i in c["left_on"]]
+    rk = [right[i] for i in c["right_on"]]
+    li, ri = backend.join(lk, rk, nulls_equal=(c["nulls"] == "equal"), kind=c["kind"])
+    assert len(li) == len(ri)
+    if "expect_num_rows" in c:
+        assert len(li) == c["expect_num_rows"]
+        return
+    got = sorted((l + r for l, r in zip(gather_rows(left, li), gather_rows(right, ri))), key=_row_key)
+    g = c["gold"]
+    n = len(g["cols"][0])
+    gold = []
+    for i in range(n):
+        gold.append(tuple(None if (g["valid"][j] is not None and not g["valid"][j][i]) else g["cols"][j][i]
+                          for j in range(len(g["cols"]))))
+    gold = sorted(gold, key=_row_key)
+    assert got == gold, f"join rows differ:\n{got}\n{gold}"
+
+
+def sorted_pairs(li, ri):
+    return sorted(zip([int(x) for x in li], [int(x) for x in ri]))

@@ -1,0 +1,206 @@
+"""GPU parity tests for cudf::groupby::groupby::aggregate (hash path) through the C ABI: the reference's own
+KATs, then seeded random inputs against the CPU oracle on every kernel family (LDS single pass, one- and
+two-level partitioned), then size-independent properties at large sizes."""
+import os
+
+import numpy as np
+import pytest
+
+import kat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(gpu):
+    import gpu_backend
+    return gpu_backend
+
+
+@pytest.mark.parametrize("name,c,kt,vt", list(kat.groupby_cases()), ids=[x[0] for x in kat.groupby_cases()])
+def test_groupby_kat(G, name, c, kt, vt):
+    kat.run_groupby_case(G, c, kt, vt)
+
+
+def test_groupby_generated_kats(G):
+    k = np.arange(512, dtype=np.int32)  # max_tests.cpp:554-574
+    kc, rc = kat.sort_groups(*G.groupby([k], [(k, ["max"])]))
+    assert np.array_equal(kc[0][0], k) and np.array_equal(rc[0][0][0], k)
+    rng = np.random.default_rng(0)  # max_tests.cpp:576-597
+    k = np.tile(np.arange(128, dtype=np.int32), 10000)
+    rng.shuffle(k)
+    kc, rc = kat.sort_groups(*G.groupby([k], [(k, ["max"])]))
+    assert np.array_equal(kc[0][0], np.arange(128)) and np.array_equal(rc[0][0][0], np.arange(128))
+    K10 = np.array([1, 2, 3, 1, 2, 2, 1, 3, 3, 2], np.int32)  # keys_tests.cpp:355-409
+    V10 = np.arange(10, dtype=np.int32)
+    kc, rc = kat.sort_groups(*G.groupby([K10], [(V10, ["sum", "sum"])]))
+    assert [list(c[0]) for c in rc[0]] == [[9, 19, 17], [9, 19, 17]]
+    kc, rc = kat.sort_groups(*G.groupby([K10], [(V10, ["sum"]), (V10, ["sum"])]))
+    assert list(rc[0][0][0]) == [9, 19, 17] and list(rc[1][0][0]) == [9, 19, 17]
+
+
+def test_groupby_errors(G):
+    from cudf_amd._lib import CudfAmdError
+    K = np.array([1, 2, 3], np.int32)
+    with pytest.raises(CudfAmdError, match="Size mismatch"):  # groupby.cu:225-229 -> cudf::logic_error
+        G.groupby([K], [(np.arange(4, dtype=np.int32), ["sum"])])
+    from oracle.oracle import HostColumn
+    with pytest.raises(CudfAmdError, match="Invalid type/aggregation"):  # groupby.cu:186-201
+        G.groupby([K], [(HostColumn(np.arange(3, dtype=np.int64), None, "timestamp_s"), ["sum"])])
+    with pytest.raises(CudfAmdError, match="sort-based"):  # sort-path aggregation: out of scope, fails loudly
+        G.groupby([K], [(K, ["nth_element"])])
+
+
+def _check_against_oracle(G, O, keys, requests, include=False, expect_path=None):
+    got = kat.sort_groups(*G.groupby(keys, requests, include_null_keys=include))
+    if expect_path is not None:
+        assert G.last_path.name == expect_path, G.last_path
+    exp = kat.sort_groups(*O.groupby(keys, requests, include_null_keys=include))
+    assert len(got[0]) == len(exp[0])
+    for a, e in zip(got[0], exp[0]):
+        kat.compare_columns(a, e, "keys")
+    # order-dependent float sums: worst-case bound for the largest group (see kat.sum_atol)
+    cnt = O.groupby(keys, [(requests[0][0], ["count_all"])], include_null_keys=include)[1][0][0][0]
+    m = int(cnt.max()) if len(cnt) else 1
+    for (vals, kinds), ra, re_ in zip(requests, got[1], exp[1]):
+        h = G.to_host_column(vals)
+        scale = float(np.max(np.abs(h.data.astype(np.float64)))) if h.size else 0.0
+        for kind, a, e in zip(kinds, ra, re_):
+            is_fsum = kind in ("sum", "mean", "sum_of_squares") and np.dtype(h.data.dtype).kind == "f"
+            kat.compare_columns(a, e, f"result[{kind}]", atol=kat.sum_atol(m, scale) if is_fsum else 0.0)
+
+
+ALL_AGGS = ["sum", "count_valid", "count_all", "min", "max", "mean"]
+
+
+@pytest.mark.parametrize("n,groups,path", [(1000, 7, "LDS_SINGLE_PASS"), (200_000, 300, "LDS_SINGLE_PASS"),
+                                           (300_000, 50_000, "PARTITIONED_LDS"),
+                                           (2_000_000, 1_000_000, "PARTITIONED_LDS")])
+def test_random_int64_key_f64_value(G, oracle, n, groups, path):
+    rng = np.random.default_rng(42)
+    k = rng.integers(0, groups, n, dtype=np.int64) * 7919 - 3  # arbitrary, non-dense int64 keys
+    v = rng.random(n)
+    _check_against_oracle(G, oracle, [k], [(v, ALL_AGGS)], expect_path=path)
+
+
+@pytest.mark.parametrize("include", [False, True])
+@pytest.mark.parametrize("n,g0,g1", [(5000, 10, 5), (400_000, 2000, 300)])
+def test_random_multikey_nulls(G, oracle, n, g0, g1, include):
+    """C4 shape at small size: keys (int64, int32) with 10% nulls on k1 and on the value column."""
+    rng = np.random.default_rng(46)
+    k0 = rng.integers(0, g0, n, dtype=np.int64)
+    k1 = rng.integers(0, g1, n, dtype=np.int32)
+    k1v = rng.random(n) > 0.1
+    v = rng.random(n)
+    vv = rng.random(n) > 0.1
+    _check_against_oracle(G, oracle, [k0, (k1, k1v)], [((v, vv), ["mean", "min", "max", "sum", "count_valid", "count_all"])],
+                          include=include)
+
+
+@pytest.mark.parametrize("vt", ["int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float32",
+                                "float64", "bool"])
+def test_value_types(G, oracle, vt):
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(7)
+    n = 50_000
+    k = rng.integers(0, 97, n, dtype=np.int32)
+    npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
+    if vt == "bool":
+        v = rng.integers(0, 2, n).astype(np.uint8)
+    elif np.dtype(npt).kind == "f":
+        v = (rng.random(n) * 1000 - 500).astype(npt)
+    else:
+        info = np.iinfo(npt)
+        v = rng.integers(max(info.min, -2**40), min(info.max, 2**40), n, dtype=np.int64).astype(npt)
+    vv = rng.random(n) > 0.2
+    aggs = ["sum", "min", "max", "count_valid", "mean"]
+    _check_against_oracle(G, oracle, [k], [(HostColumn(v, vv, vt), aggs)])
+
+
+@pytest.mark.parametrize("kt", ["int8", "int16", "uint32", "uint64", "bool", "timestamp_ms", "duration_days", "decimal64"])
+def test_key_types(G, oracle, kt):
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(9)
+    n = 30_000
+    npt = NP_OF_TYPE_ID[TYPE_ID[kt]]
+    k = rng.integers(0, 2 if kt == "bool" else 100, n).astype(np.uint8 if kt == "bool" else npt)
+    kv = rng.random(n) > 0.05
+    v = rng.integers(-1000, 1000, n, dtype=np.int64)
+    for include in (False, True):
+        _check_against_oracle(G, oracle, [HostColumn(k, kv, kt)], [(v, ["sum", "count_all"])], include=include)
+
+
+def test_sliced_columns_offset(G, oracle):
+    """Arrow offset: element i at data[offset+i], validity at bit offset+i."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(3)
+    n, off = 10_000, 37
+    k = rng.integers(0, 50, n, dtype=np.int64)
+    kv = rng.random(n) > 0.1
+    v = rng.random(n)
+    vv = rng.random(n) > 0.1
+    keys = [HostColumn(k, kv, "int64", offset=off)]
+    reqs = [(HostColumn(v, vv, "float64", offset=off), ["sum", "count_valid", "max"])]
+    _check_against_oracle(G, oracle, keys, reqs)
+    _check_against_oracle(G, oracle, keys, reqs, include=True)
+
+
+def test_all_rows_one_group_and_all_distinct(G, oracle):
+    n = 100_000
+    v = np.arange(n, dtype=np.float64)
+    _check_against_oracle(G, oracle, [np.zeros(n, np.int64)], [(v, ALL_AGGS)])
+    _check_against_oracle(G, oracle, [np.arange(n, dtype=np.int64)], [(v, ["sum", "count_all"])])
+
+
+def test_skewed_keys_retry(G, oracle):
+    """A sample-based cardinality estimate that is too low must be repaired by the overflow retry."""
+    rng = np.random.default_rng(11)
+    n = 1_500_000
+    k = np.zeros(n, np.int64)
+    k[-400_000:] = rng.integers(1, 300_000, 400_000)  # distinct tail the strided sample under-represents
+    v = rng.random(n)
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all"])])
+
+
+def test_two_level_partition_forced(G, oracle, monkeypatch):
+    """Forces the two-level radix partition (C4's regime) at a size the oracle can check."""
+    rng = np.random.default_rng(13)
+    n = 3_000_000
+    k = rng.integers(0, 2_500_000, n, dtype=np.int64)
+    v = rng.random(n)
+    monkeypatch.setenv("CUDF_AMD_GB_LDS_KB", "4")  # tiny tables -> needs > 2048 partitions -> two levels
+    try:
+        _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all", "max"])], expect_path="PARTITIONED_LDS")
+    finally:
+        monkeypatch.delenv("CUDF_AMD_GB_LDS_KB")
+
+
+def test_large_properties(G):
+    """Size-independent properties at 100M rows (the oracle is too slow here): count sums to n, sum of sums
+    matches a float64 reduction, every key appears exactly once, min <= mean <= max."""
+    import torch
+    import cudf_amd
+    from cudf_amd import aggregation as agg, groupby as gb
+    from cudf_amd.types import NullPolicy
+    n, groups = 100_000_000, 1_000_000
+    g = torch.Generator(device="cuda").manual_seed(42)
+    k = torch.randint(0, groups, (n,), generator=g, device="cuda", dtype=torch.int64)
+    v = torch.rand(n, generator=g, device="cuda", dtype=torch.float64)
+    req = gb.GroupByRequest(cudf_amd.Column.from_torch(v), [agg.sum(), agg.count(NullPolicy.EXCLUDE), agg.min(), agg.max(), agg.mean()])
+    grp = gb.GroupBy(cudf_amd.Table([cudf_amd.Column.from_torch(k)]))
+    keys, res = grp.aggregate([req], stream=torch.cuda.current_stream())
+    assert grp.last_path.name == "PARTITIONED_LDS"
+    kk = keys.columns()[0].to_numpy()[0]
+    s, c, mn, mx, me = [x.to_numpy()[0] for x in res[0].columns()]
+    assert len(kk) == len(np.unique(kk)) == int(torch.unique(k).numel())
+    assert int(c.sum()) == n
+    total = float(v.sum(dtype=torch.float64))
+    assert abs(float(s.sum()) - total) <= 1e-9 * total
+    assert np.all(mn <= me + 1e-15) and np.all(me <= mx + 1e-15)
+    # spot-check 50 groups exactly against torch
+    order = np.argsort(kk)
+    for gi in order[:: max(1, len(order) // 50)][:50]:
+        sel = v[k == int(kk[gi])]
+        assert int(c[gi]) == sel.numel()
+        assert abs(float(sel.sum(dtype=torch.float64)) - s[gi]) <= 4 * np.finfo(np.float64).eps * abs(float(sel.sum()) + s[gi]) * 8
+        assert float(sel.min()) == mn[gi] and float(sel.max()) == mx[gi]
