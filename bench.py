@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): rows/s of hash-groupby SUM+COUNT over 1B int64-key / float64-value rows
+with 1M groups (configs[1], "C2"), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic rows already resident in HBM:
+  N == 1: cudf::groupby::groupby(keys).aggregate({values, [SUM, COUNT_VALID]}) through the C ABI.
+  N  > 1: configs[4] ("C5", weak scaling, 1B rows per GPU): hash-range partition of the local rows by destination
+          rank -> RCCL all-to-all (torch.distributed, backend nccl == RCCL over xGMI) -> local groupby on the rows
+          received. Groups are disjoint across ranks by construction, so there is no final merge.
+Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events on the launch stream (the library's
+per-kernel profiler); `cpu_baseline` times the CPU oracle (oracle/, test infrastructure) on a bounded sample of the
+same workload on this box's host cores, plus pandas/Arrow on configs[0] (10M rows).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
+BYTES_PER_ROW = 16     # algorithmic bytes per row of C2: 8 B key + 8 B value
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=int(os.environ.get("BENCH_ROWS", 1_000_000_000)))
+    ap.add_argument("--groups", type=int, default=int(os.environ.get("BENCH_GROUPS", 1_000_000)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=60_000_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(groups, sample_rows):
+    """Times the CPU oracle (kind "port", 1 core) on a bounded sample of the C2 workload, and pandas / Arrow on
+    configs[0] (10M rows) for the north_star's "reference CPU Arrow/pandas" comparison."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(42)
+    k = rng.integers(0, groups, sample_rows, dtype=np.int64)
+    v = rng.random(sample_rows)
+    t0 = time.perf_counter()
+    O.groupby([k], [(v, ["sum", "count_valid"])])
+    dt = time.perf_counter() - t0
+    out = {"value": sample_rows / dt, "unit": "rows/s", "cores": 1, "kind": "port",
+           "sample": f"{sample_rows} rows of the same int64-key/float64-value workload, {groups} groups, "
+                     f"oracle/oracle.c groupby SUM+COUNT_VALID, {dt:.1f} s",
+           "host_cores": os.cpu_count()}
+    try:
+        import pandas as pd
+        import pyarrow as pa
+        n = 10_000_000
+        kk, vv = k[:n], v[:n]
+        df = pd.DataFrame({"k": kk, "v": vv})
+        best = min(_timeit(lambda: df.groupby("k", sort=False)["v"].sum()) for _ in range(3))
+        out["pandas_rows_per_s"] = n / best
+        tb = pa.table({"k": kk, "v": vv})
+        best = min(_timeit(lambda: tb.group_by("k", use_threads=True).aggregate([("v", "sum")])) for _ in range(3))
+        out["arrow_rows_per_s"] = n / best
+        out["arrow_threads"] = pa.cpu_count()
+        out["pandas_arrow_sample"] = f"configs[0]: {n} rows, {groups} groups, best of 3 (pandas {pd.__version__}, pyarrow {pa.__version__})"
+    except Exception as e:  # pandas/pyarrow are optional on the box
+        out["pandas_arrow_error"] = repr(e)
+    return out
+
+
+def _timeit(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cudf_amd
+    from cudf_amd import _lib, aggregation as agg, groupby as gb
+    from cudf_amd.types import NullPolicy
+
+    n, groups = args.rows, args.groups
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    keys = torch.randint(0, groups, (n,), generator=gen, device=dev, dtype=torch.int64)
+    gen.manual_seed(43 + rank)
+    vals = torch.rand(n, generator=gen, device=dev, dtype=torch.float64)
+    stream = torch.cuda.current_stream()
+
+    if world == 1:
+        kcol, vcol = cudf_amd.Column.from_torch(keys), cudf_amd.Column.from_torch(vals)
+
+        def step():
+            g = gb.GroupBy(cudf_amd.Table([kcol]))
+            out = g.aggregate([gb.GroupByRequest(vcol, [agg.sum(), agg.count(NullPolicy.EXCLUDE)])], stream=stream)
+            return g, out
+    else:
+        from cudf_amd import distributed as D
+
+        def step():
+            return D.distributed_groupby_sum_count(keys, vals, stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_report()
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        total_rows = n * world
+        value = total_rows * args.steps / dt
+        # dominant kernel by total time in the timed region
+        roof = None
+        if prof:
+            name, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+            avg_ms = total_ms / launches
+            achieved = BYTES_PER_ROW * n / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_launch": BYTES_PER_ROW * n,
+                    "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items())},
+                    "whole_call_frac": BYTES_PER_ROW * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        line = {
+            "metric": "rows/s hash-groupby-sum, 1B int64 rows/1M groups",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("C2: 1xMI355X hash-groupby SUM+COUNT_VALID, single int64 key, float64 value, no nulls"
+                                    if world == 1 else
+                                    "C5: hash-range partition + RCCL all-to-all + per-GPU groupby SUM+COUNT_VALID"),
+                       "rows_per_gpu": n, "groups": groups, "key": "int64 uniform [0, groups)", "value": "float64 uniform [0,1)",
+                       "path": (last[0].last_path.name if world == 1 else "PARTITION+ALLTOALL+GROUPBY")},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(groups, args.cpu_sample_rows)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,9 @@ SYMBOLS = {
     "cudf_amd_memset": (C.c_int, [_P, C.c_int32, C.c_size_t, _P]),
     "cudf_amd_stream_synchronize": (C.c_int, [_P]),
     "cudf_amd_memory_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cudf_amd_profile_enable": (C.c_int, [C.c_int32]),
+    "cudf_amd_profile_reset": (C.c_int, []),
+    "cudf_amd_profile_report": (C.c_int, [C.c_char_p, C.c_size_t]),
     "cudf_amd_table_num_columns": (C.c_int32, [_P]),
     "cudf_amd_table_num_rows": (C.c_int32, [_P]),
     "cudf_amd_table_column": (C.c_int, [_P, C.c_int32, C.POINTER(ColumnView)]),
@@ -72,3 +75,22 @@ def check(status):
     if status == 5:
         raise MemoryError(msg)
     raise CudfAmdError(msg)
+
+
+def profile_enable(on: bool):
+    check(load().cudf_amd_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    check(load().cudf_amd_profile_reset())
+
+
+def profile_report():
+    """{kernel name: (launches, total_ms)} since the last reset (HIP events on the launch stream)."""
+    buf = C.create_string_buffer(1 << 16)
+    check(load().cudf_amd_profile_report(buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, ms = line.split()
+        out[name] = (int(n), float(ms))
+    return out

@@ -3,10 +3,14 @@
 // codes (pylibcudf does the same mapping in exception_handler.pxd:34-64).
 #include <cudf_amd_c.h>
 
+#include "common/profiler.hpp"
+
 #include <cudf/groupby.hpp>
 #include <cudf/table/table.hpp>
 #include <cudf/utilities/error.hpp>
 
+#include <algorithm>
+#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
@@ -20,7 +24,7 @@ thread_local std::string g_last_error;
 
 rmm::mr::statistics_resource_adaptor& stats_mr()
 {
-  static rmm::mr::hip_async_memory_resource base{};
+  static rmm::mr::pool_memory_resource base{};
   static rmm::mr::statistics_resource_adaptor stats{&base};
   return stats;
 }
@@ -138,6 +142,28 @@ cudf_amd_status cudf_amd_memory_stats(uint64_t* current_bytes, uint64_t* peak_by
   return guarded([&] {
     *current_bytes = stats_mr().current_bytes();
     *peak_bytes    = stats_mr().peak_bytes();
+  });
+}
+
+cudf_amd_status cudf_amd_profile_enable(int32_t on)
+{
+  return guarded([&] { cudf::detail::prof::enable(on != 0); });
+}
+cudf_amd_status cudf_amd_profile_reset(void)
+{
+  return guarded([&] { cudf::detail::prof::reset(); });
+}
+cudf_amd_status cudf_amd_profile_report(char* buf, size_t n)
+{
+  return guarded([&] {
+    std::string out;
+    for (auto const& k : cudf::detail::prof::collect())
+      out += k.name + " " + std::to_string(k.launches) + " " + std::to_string(k.total_ms) + "\n";
+    if (n > 0) {
+      auto const len = std::min(out.size(), n - 1);
+      std::memcpy(buf, out.data(), len);
+      buf[len] = 0;
+    }
   });
 }
 

@@ -65,11 +65,28 @@ device_table make_device_table(table_view const& t);
 
 #if defined(__HIPCC__)
 
+// Pointers read out of an argument struct are generic ("flat") to the compiler; flat loads count on BOTH
+// vmcnt and lgkmcnt and so serialise against LDS traffic. Everything the path reads from HBM goes through
+// these explicit global-address-space accessors instead (global_load_* / global_store_*).
+#define CUDF_AMD_GLOBAL_AS __attribute__((address_space(1)))
+// one 16-byte record: moves as global_load/store_dwordx4 and ds_read/write_b128
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ T gload(T const* p)
+{
+  return *(CUDF_AMD_GLOBAL_AS T const*)(p);
+}
+template <typename T>
+__device__ __forceinline__ void gstore(T* p, T v)
+{
+  *(CUDF_AMD_GLOBAL_AS T*)(p) = v;
+}
+
 __device__ __forceinline__ bool col_is_valid(device_column const& c, int64_t i)
 {
   if (c.mask == nullptr) return true;
   int64_t const b = static_cast<int64_t>(c.offset) + i;
-  return (c.mask[b >> 5] >> (b & 31)) & 1u;
+  return (gload(c.mask + (b >> 5)) >> (b & 31)) & 1u;
 }
 
 // Raw element bits, zero-extended to 64 bits.
@@ -77,10 +94,10 @@ __device__ __forceinline__ uint64_t col_load_bits(device_column const& c, int64_
 {
   int64_t const e = static_cast<int64_t>(c.offset) + i;
   switch (c.width) {
-    case 1: return static_cast<uint8_t const*>(c.head)[e];
-    case 2: return static_cast<uint16_t const*>(c.head)[e];
-    case 4: return static_cast<uint32_t const*>(c.head)[e];
-    default: return static_cast<uint64_t const*>(c.head)[e];
+    case 1: return gload(static_cast<uint8_t const*>(c.head) + e);
+    case 2: return gload(static_cast<uint16_t const*>(c.head) + e);
+    case 4: return gload(static_cast<uint32_t const*>(c.head) + e);
+    default: return gload(static_cast<uint64_t const*>(c.head) + e);
   }
 }
 

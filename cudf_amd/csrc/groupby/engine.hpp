@@ -67,6 +67,10 @@ struct plan_dev {
   unit_desc unit[MAX_UNITS];
   uint64_t key_mask[MAX_KU];
   acc_desc acc[MAX_ACC];
+  // Fast path: every record unit is an 8-byte column without nulls that needs no conversion or normalisation
+  // (int64/uint64/float64 values, 8-byte integer keys): unit u of row r is simple_base[u][r].
+  int32_t simple;
+  uint64_t const* simple_base[MAX_UNITS];
 };
 
 // ---- finalize: partial records -> typed output columns
@@ -153,18 +157,26 @@ struct part_args {
   uint64_t* out_records;
 };
 
-// Launchers (kernels.hip). All asynchronous on `stream`.
-void launch_partition_hist(part_args const& a, hipStream_t stream);
-void launch_partition_scan(part_args const& a, hipStream_t stream);
-void launch_partition_scatter(part_args const& a, hipStream_t stream);
-void launch_aggregate(agg_args const& a, hipStream_t stream);
+// Launchers (kernels.hip). All asynchronous on `stream`. Kernel arguments live in DEVICE memory (`d_args`,
+// one slot per launch family, written by a one-thread kernel on the same stream): passed by value, the
+// dynamically indexed column descriptors were copied to scratch by the compiler (792 B/lane) and every
+// descriptor access became a vector memory load.
+void store_args(part_args const& a, part_args* d_args, hipStream_t stream);
+void launch_partition_hist(part_args const& a, part_args const* d_args, hipStream_t stream);
+void launch_partition_scan(part_args const& a, part_args const* d_args, hipStream_t stream);
+void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream);
+void launch_aggregate(agg_args const& a, agg_args* d_args, hipStream_t stream);
 // Gathers `total` groups (items' partial records, prefix[] = exclusive scan of the item counts) into the
 // typed output columns.
-void launch_finalize(plan_dev const& plan, finalize_dev const& fin, uint64_t const* records, int64_t cap,
+struct finalize_args {
+  plan_dev plan;
+  finalize_dev fin;
+};
+void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t const* records, int64_t cap,
                      int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream);
 // Distinct-count estimate on a strided sample (linear counting into a bitmap); result written to *d_bits.
-void launch_estimate(plan_dev const& plan, int64_t nrows, int64_t sample, uint32_t* bitmap, int32_t bitmap_bits_log2,
-                     uint32_t* d_bits_set, hipStream_t stream);
+void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
+                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, hipStream_t stream);
 
 std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g);
 std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g);

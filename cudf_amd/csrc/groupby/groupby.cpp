@@ -366,6 +366,19 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
       hp.results.push_back(rs);
     }
   }
+  // ---- fast path: all units are plain 8-byte columns (no nulls, no conversion, no normalisation)
+  p.simple = 1;
+  for (int w = 0; w < p.KU + p.NPAY; ++w) {
+    auto const& d = p.unit[w];
+    if (!d.full) { p.simple = 0; break; }
+    auto const& c = p.cols[d.lo];
+    bool const plain = c.width == 8 && c.mask == nullptr &&
+                       (d.is_key ? (c.cls == CLS_SINT || c.cls == CLS_UINT)
+                                 : (c.cls == CLS_SINT || c.cls == CLS_UINT || c.cls == CLS_F64));
+    if (!plain) { p.simple = 0; break; }
+    p.simple_base[w] = static_cast<uint64_t const*>(c.head) + c.offset;
+  }
+  if (env_i64("CUDF_AMD_GB_NO_SIMPLE", 0)) p.simple = 0;
   return hp;
 }
 
@@ -453,7 +466,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     int const bits_log2  = 24;
     uint32_t* bitmap     = sc.alloc<uint32_t>((size_t{1} << bits_log2) / 32);
     uint32_t* d_set      = sc.alloc<uint32_t>(1);
-    launch_estimate(p, n, sample, bitmap, bits_log2, d_set, s);
+    launch_estimate(p, sc.alloc<plan_dev>(1), n, sample, bitmap, bits_log2, d_set, s);
     uint32_t h_set = 0;
     CUDF_HIP_TRY(hipMemcpyAsync(&h_set, d_set, 4, hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipStreamSynchronize(s));
@@ -504,7 +517,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       aa.out_records      = partial;
       aa.out_count        = d_count;
       aa.nitems           = nitems;
-      launch_aggregate(aa, s);
+      launch_aggregate(aa, sc.alloc<agg_args>(1), s);
       int const fan = 16;
       while (nitems > 1) {
         int32_t const next = (nitems + fan - 1) / fan;
@@ -521,7 +534,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         m.out_records      = out;
         m.out_count        = cnt;
         m.nitems           = next;
-        launch_aggregate(m, s);
+        launch_aggregate(m, sc.alloc<agg_args>(1), s);
         partial = out;
         d_count = cnt;
         nitems  = next;
@@ -563,9 +576,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       pa.out_offsets  = sc.alloc<int64_t>(P1 + 1);
       uint64_t* recA  = sc.alloc<uint64_t>(static_cast<size_t>(n) * RU);
       pa.out_records  = recA;
-      launch_partition_hist(pa, s);
-      launch_partition_scan(pa, s);
-      launch_partition_scatter(pa, s);
+      part_args* d_pa = sc.alloc<part_args>(1);
+      store_args(pa, d_pa, s);
+      launch_partition_hist(pa, d_pa, s);
+      launch_partition_scan(pa, d_pa, s);
+      launch_partition_scatter(pa, d_pa, s);
       int64_t const* offsets = pa.out_offsets;
       uint64_t const* recs   = recA;
       int64_t nparts         = P1;
@@ -586,9 +601,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         pb.out_offsets  = sc.alloc<int64_t>(P1 * P2 + 1);
         uint64_t* recB  = sc.alloc<uint64_t>(static_cast<size_t>(n) * RU);
         pb.out_records  = recB;
-        launch_partition_hist(pb, s);
-        launch_partition_scan(pb, s);
-        launch_partition_scatter(pb, s);
+        part_args* d_pb = sc.alloc<part_args>(1);
+        store_args(pb, d_pb, s);
+        launch_partition_hist(pb, d_pb, s);
+        launch_partition_scan(pb, d_pb, s);
+        launch_partition_scatter(pb, d_pb, s);
         offsets = pb.out_offsets;
         recs    = recB;
         nparts  = P1 * P2;
@@ -603,7 +620,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       aa.out_records = partial;
       aa.out_count   = d_count;
       aa.nitems      = nitems;
-      launch_aggregate(aa, s);
+      launch_aggregate(aa, sc.alloc<agg_args>(1), s);
     }
     int32_t h_overflow = 0;
     CUDF_HIP_TRY(hipMemcpyAsync(&h_overflow, d_overflow, 4, hipMemcpyDeviceToHost, s));
@@ -627,7 +644,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   CUDF_HIP_TRY(hipMemcpyAsync(d_prefix, h_prefix.data(), sizeof(int64_t) * (nitems + 1), hipMemcpyHostToDevice, s));
 
   // ---- output columns
-  finalize_dev fin{};
+  finalize_args fa{};
+  fa.plan           = p;
+  finalize_dev& fin = fa.fin;
   std::vector<std::unique_ptr<column>> key_cols;
   std::vector<std::unique_ptr<column>> res_cols;
   int const nres = static_cast<int>(hp.results.size());
@@ -683,7 +702,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     fin.out[fin.nout++] = d;
     res_cols.push_back(std::move(col));
   }
-  launch_finalize(p, fin, partial, ag.cap, d_prefix, nitems, G, s);
+  launch_finalize(fa, sc.alloc<finalize_args>(1), partial, ag.cap, d_prefix, nitems, G, s);
   std::vector<int32_t> h_nulls(MAX_OUT, 0);
   CUDF_HIP_TRY(hipMemcpyAsync(h_nulls.data(), d_nulls, sizeof(int32_t) * MAX_OUT, hipMemcpyDeviceToHost, s));
   CUDF_HIP_TRY(hipStreamSynchronize(s));

@@ -2,7 +2,9 @@
 // gfx950 kernels of the hash-groupby engine (see engine.hpp for the design). Every kernel is HBM- or
 // LDS-bound integer/byte work: 64-lane waves, LDS hash tables with native ds_* atomics, LDS-staged
 // multi-split for coalesced partition writes; no MFMA, no global atomics on the per-row path.
+// Kernel arguments are read through a pointer to device memory (scalar loads), never by value.
 #include "engine.hpp"
+#include "../common/profiler.hpp"
 
 #include <cudf/utilities/error.hpp>
 
@@ -11,8 +13,11 @@ namespace cudf::groupby::detail {
 using cudf::detail::col_is_valid;
 using cudf::detail::col_load_acc_bits;
 using cudf::detail::col_load_bits;
+using cudf::detail::gload;
+using cudf::detail::gstore;
 using cudf::detail::mix64;
 using cudf::detail::normalize_key_bits;
+using cudf::detail::u64x2;
 
 namespace {
 
@@ -20,6 +25,12 @@ constexpr uint32_t ST_EMPTY  = 0;
 constexpr uint32_t ST_LOCKED = 1;
 
 __device__ __forceinline__ uint32_t tag_of(uint64_t h) { return (static_cast<uint32_t>(h >> 20) & ~3u) | 2u; }
+
+template <typename T>
+__global__ void k_store_args(T v, T* dst)
+{
+  *dst = v;
+}
 
 // ------------------------------------------------------------------ record building from columns
 // Validity words of one row: keynulls bit c = key column c NULL; valvalid bit v = value column v valid.
@@ -54,7 +65,13 @@ __device__ __forceinline__ uint32_t half_bits(plan_dev const& p, int8_t src, int
 __device__ __forceinline__ uint64_t unit_bits(plan_dev const& p, int u, int64_t row, uint32_t keynulls,
                                               uint32_t valvalid)
 {
-  unit_desc const d = p.unit[u];
+  // one aligned 32-bit scalar load instead of four byte loads
+  uint32_t const w = reinterpret_cast<uint32_t const*>(p.unit)[u];
+  unit_desc d;
+  d.full   = static_cast<int8_t>(w);
+  d.lo     = static_cast<int8_t>(w >> 8);
+  d.hi     = static_cast<int8_t>(w >> 16);
+  d.is_key = static_cast<int8_t>(w >> 24);
   if (d.full) {
     if (d.is_key) {
       if ((keynulls >> d.lo) & 1u) return 0;
@@ -67,15 +84,22 @@ __device__ __forceinline__ uint64_t unit_bits(plan_dev const& p, int u, int64_t 
 }
 
 // Key units of one row from the columns; false if the row is dropped (null_policy::EXCLUDE).
-template <int KUT>
+template <int KUT, bool SIMPLE>
 __device__ __forceinline__ bool build_key_units(plan_dev const& p, int64_t row, uint64_t (&key)[KUT], uint32_t& valvalid)
 {
-  uint32_t keynulls;
-  row_validity(p, row, keynulls, valvalid);
-  if (p.drop_null_keys && keynulls != 0) return false;
+  if constexpr (SIMPLE) {
+    valvalid = 0xffffffffu;
 #pragma unroll
-  for (int u = 0; u < KUT; ++u) key[u] = (u < p.KU) ? unit_bits(p, u, row, keynulls, valvalid) : 0;
-  return true;
+    for (int u = 0; u < KUT; ++u) key[u] = (u < p.KU) ? gload(p.simple_base[u] + row) : 0;
+    return true;
+  } else {
+    uint32_t keynulls;
+    row_validity(p, row, keynulls, valvalid);
+    if (p.drop_null_keys && keynulls != 0) return false;
+#pragma unroll
+    for (int u = 0; u < KUT; ++u) key[u] = (u < p.KU) ? unit_bits(p, u, row, keynulls, valvalid) : 0;
+    return true;
+  }
 }
 
 template <int KUT>
@@ -136,41 +160,56 @@ __device__ __forceinline__ slice_range slice_of(part_args const& a, int item)
   return r;
 }
 
-__device__ __forceinline__ uint32_t digit_of(part_args const& a, uint64_t h)
-{
-  return static_cast<uint32_t>(h >> a.geom.shift) & static_cast<uint32_t>(a.geom.P - 1);
-}
-
 // ------------------------------------------------------------------ K_hist
-__global__ void __launch_bounds__(1024) k_partition_hist(part_args a)
+template <bool SIMPLE>
+__global__ void __launch_bounds__(1024) k_partition_hist(part_args const* __restrict__ ap)
 {
   extern __shared__ uint32_t lds_hist[];
-  int const P = a.geom.P;
+  part_args const& a = *ap;
+  plan_dev const& p  = a.plan;
+  int const P = a.geom.P, shift = a.geom.shift;
   for (int d = threadIdx.x; d < P; d += blockDim.x) lds_hist[d] = 0;
   __syncthreads();
   slice_range const sr = slice_of(a, blockIdx.x);
-  int const U          = a.plan.KU + a.plan.NPAY;
-  for (int64_t r = sr.begin + threadIdx.x; r < sr.end; r += blockDim.x) {
-    uint64_t key[MAX_KU];
-    bool keep = true;
-    if (a.from_columns) {
-      uint32_t vv;
-      keep = build_key_units<MAX_KU>(a.plan, r, key, vv);
-    } else {
+  int const U          = p.KU + p.NPAY;
+  int const from_cols  = a.from_columns;
+  constexpr int R      = 4;
+  int64_t const B      = blockDim.x;
+  for (int64_t base = sr.begin; base < sr.end; base += R * B) {
+    uint64_t key[R][MAX_KU];
+    bool keep[R];
 #pragma unroll
-      for (int u = 0; u < MAX_KU; ++u) key[u] = (u < a.plan.KU) ? a.in_records[r * U + u] : 0;
+    for (int k = 0; k < R; ++k) {
+      int64_t const r = base + k * B + threadIdx.x;
+      keep[k]         = r < sr.end;
+      if (keep[k]) {
+        if (from_cols) {
+          uint32_t vv;
+          keep[k] = build_key_units<MAX_KU, SIMPLE>(p, r, key[k], vv);
+        } else {
+#pragma unroll
+          for (int u = 0; u < MAX_KU; ++u) key[k][u] = (u < p.KU) ? gload(a.in_records + r * U + u) : 0;
+        }
+      }
     }
-    if (keep) atomicAdd(&lds_hist[digit_of(a, hash_key_units<MAX_KU>(a.plan, key))], 1u);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (keep[k]) {
+        uint64_t const h = hash_key_units<MAX_KU>(p, key[k]);
+        atomicAdd(&lds_hist[static_cast<uint32_t>(h >> shift) & static_cast<uint32_t>(P - 1)], 1u);
+      }
+    }
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < P; d += blockDim.x) a.counts[static_cast<int64_t>(blockIdx.x) * P + d] = lds_hist[d];
+  for (int d = threadIdx.x; d < P; d += blockDim.x) gstore(a.counts + static_cast<int64_t>(blockIdx.x) * P + d, lds_hist[d]);
 }
 
 // ------------------------------------------------------------------ K_scan: one block per segment
-__global__ void __launch_bounds__(1024) k_partition_scan(part_args a)
+__global__ void __launch_bounds__(1024) k_partition_scan(part_args const* __restrict__ ap)
 {
   __shared__ uint32_t wave_sums[16];
   extern __shared__ uint32_t lds_tot[];  // P totals, then P exclusive offsets
+  part_args const& a = *ap;
   int const P = a.geom.P, S = a.geom.slices, g = blockIdx.x;
   int64_t const seg_begin = a.from_columns ? 0 : a.seg_offsets[g];
   uint32_t* tot  = lds_tot;
@@ -215,12 +254,17 @@ __global__ void __launch_bounds__(1024) k_partition_scan(part_args a)
 // with an LDS histogram, exclusive-scan the histogram, stage the records in LDS in partition order and write
 // them out so that consecutive lanes write consecutive records of one partition (runs of T/P records).
 // LDS layout: stage[T*U] u64 | delta[P] i64 | hist[P] u32 | pid[T] u16 | wave_sums[16] u32
-template <int UT, int RPT>
-__global__ void __launch_bounds__(1024) k_partition_scatter(part_args a)
+// EXACT: the record has exactly UT units (all `u < U` predicates fold away; 16-byte records move as one
+// ds_write_b128 / global_store_dwordx4).
+template <int UT, int RPT, bool SIMPLE, bool EXACT>
+__global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  int const P = a.geom.P, B = blockDim.x, T = B * RPT;
-  int const U = a.plan.KU + a.plan.NPAY;  // <= UT
+  part_args const& a = *ap;
+  plan_dev const& p  = a.plan;
+  int const P = a.geom.P, shift = a.geom.shift, B = blockDim.x, T = B * RPT;
+  int const U  = EXACT ? UT : (p.KU + p.NPAY);  // <= UT
+  int const KU = p.KU;
   uint64_t* stage     = reinterpret_cast<uint64_t*>(lds_raw);
   int64_t* delta      = reinterpret_cast<int64_t*>(stage + static_cast<size_t>(T) * U);
   uint32_t* hist      = reinterpret_cast<uint32_t*>(delta + P);
@@ -229,6 +273,17 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args a)
 
   int const item       = blockIdx.x;
   slice_range const sr = slice_of(a, item);
+  int const from_cols  = a.from_columns;
+  uint64_t const* in_records = a.in_records;
+  uint64_t* out_records      = a.out_records;
+  uint64_t kmask[UT < MAX_KU ? UT : MAX_KU];
+#pragma unroll
+  for (int u = 0; u < (UT < MAX_KU ? UT : MAX_KU); ++u) kmask[u] = u < KU ? p.key_mask[u] : 0;
+  uint64_t const* sbase[UT];
+  if constexpr (SIMPLE) {
+#pragma unroll
+    for (int u = 0; u < UT; ++u) sbase[u] = u < U ? p.simple_base[u] : nullptr;
+  }
   // Thread t owns partitions d = t*MAXE + k: their running output cursor lives in registers.
   constexpr int MAXE = 2;  // P <= 2 * B
   int64_t cursor[MAXE];
@@ -244,31 +299,42 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args a)
     uint64_t rec[RPT][UT];
     uint32_t dig[RPT], rank[RPT];
     bool keep[RPT];
-    // phase 1: load, hash, rank within (tile, partition)
+    // phase 1a: issue all loads of the tile
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       int64_t const r = tile + static_cast<int64_t>(k) * B + threadIdx.x;
       keep[k]         = r < sr.end;
       if (keep[k]) {
-        if (a.from_columns) {
+        if constexpr (SIMPLE) {
+#pragma unroll
+          for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? gload(sbase[u] + r) : 0;
+        } else if (from_cols) {
           uint32_t keynulls, valvalid;
-          row_validity(a.plan, r, keynulls, valvalid);
-          if (a.plan.drop_null_keys && keynulls != 0) keep[k] = false;
+          row_validity(p, r, keynulls, valvalid);
+          if (p.drop_null_keys && keynulls != 0) keep[k] = false;
           if (keep[k]) {
 #pragma unroll
-            for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? unit_bits(a.plan, u, r, keynulls, valvalid) : 0;
+            for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? unit_bits(p, u, r, keynulls, valvalid) : 0;
           }
+        } else if constexpr (EXACT && UT == 2) {
+          u64x2 const v = gload(reinterpret_cast<u64x2 const*>(in_records) + r);
+          rec[k][0]          = v.x;
+          rec[k][1]          = v.y;
         } else {
 #pragma unroll
-          for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? a.in_records[r * U + u] : 0;
+          for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? gload(in_records + r * U + u) : 0;
         }
       }
+    }
+    // phase 1b: hash and rank within (tile, partition)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
       if (keep[k]) {
         uint64_t h = 0x9e3779b97f4a7c15ull;
 #pragma unroll
         for (int u = 0; u < (UT < MAX_KU ? UT : MAX_KU); ++u)
-          if (u < a.plan.KU) h = mix64(h ^ (rec[k][u] & a.plan.key_mask[u]));
-        dig[k]  = digit_of(a, h);
+          if (u < KU) h = mix64(h ^ (rec[k][u] & kmask[u]));
+        dig[k]  = static_cast<uint32_t>(h >> shift) & static_cast<uint32_t>(P - 1);
         rank[k] = atomicAdd(&hist[dig[k]], 1u);
       }
     }
@@ -299,9 +365,13 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args a)
     for (int k = 0; k < RPT; ++k) {
       if (keep[k]) {
         uint32_t const pos = hist[dig[k]] + rank[k];
+        if constexpr (EXACT && UT == 2) {
+          reinterpret_cast<u64x2*>(stage)[pos] = u64x2{rec[k][0], rec[k][1]};
+        } else {
 #pragma unroll
-        for (int u = 0; u < UT; ++u)
-          if (u < U) stage[static_cast<size_t>(pos) * U + u] = rec[k][u];
+          for (int u = 0; u < UT; ++u)
+            if (u < U) stage[static_cast<size_t>(pos) * U + u] = rec[k][u];
+        }
         pid[pos] = static_cast<uint16_t>(dig[k]);
       }
     }
@@ -314,9 +384,13 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args a)
     // phase 4: coalesced write-out; consecutive staged records of one partition go to consecutive slots
     for (uint32_t j = threadIdx.x; j < tile_count; j += B) {
       int64_t const dst = delta[pid[j]] + static_cast<int64_t>(j);
+      if constexpr (EXACT && UT == 2) {
+        gstore(reinterpret_cast<u64x2*>(out_records) + dst, reinterpret_cast<u64x2 const*>(stage)[j]);
+      } else {
 #pragma unroll
-      for (int u = 0; u < UT; ++u)
-        if (u < U) a.out_records[dst * U + u] = stage[static_cast<size_t>(j) * U + u];
+        for (int u = 0; u < UT; ++u)
+          if (u < U) gstore(out_records + dst * U + u, stage[static_cast<size_t>(j) * U + u]);
+      }
     }
     __syncthreads();
   }
@@ -358,8 +432,8 @@ __device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
 
 // Finds or claims the slot of `key` in the LDS table. Returns -1 if the table is saturated.
 template <int KUT>
-__device__ __forceinline__ int lds_find_or_insert(plan_dev const& p, uint32_t* st, uint64_t* keys, int cap,
-                                                  uint64_t const (&key)[KUT], uint64_t h, uint32_t* nfilled,
+__device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask)[KUT], uint32_t* st, uint64_t* keys,
+                                                  int cap, uint64_t const (&key)[KUT], uint64_t h, uint32_t* nfilled,
                                                   int fill_limit, int32_t* overflow_flag)
 {
   uint32_t const tag = tag_of(h);
@@ -371,7 +445,7 @@ __device__ __forceinline__ int lds_find_or_insert(plan_dev const& p, uint32_t* s
       if (old == ST_EMPTY) {
 #pragma unroll
         for (int u = 0; u < KUT; ++u)
-          if (u < p.KU) keys[static_cast<size_t>(u) * cap + slot] = key[u] & p.key_mask[u];
+          if (u < KU) keys[static_cast<size_t>(u) * cap + slot] = key[u] & kmask[u];
         // publish: key words first, then the tag (LDS executes a wave's accesses in order; the release fence
         // keeps the compiler from reordering and waits for the key stores)
         __hip_atomic_store(&st[slot], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -390,7 +464,7 @@ __device__ __forceinline__ int lds_find_or_insert(plan_dev const& p, uint32_t* s
       bool eq = true;
 #pragma unroll
       for (int u = 0; u < KUT; ++u)
-        if (u < p.KU) eq = eq && (keys[static_cast<size_t>(u) * cap + slot] == (key[u] & p.key_mask[u]));
+        if (u < KU) eq = eq && (keys[static_cast<size_t>(u) * cap + slot] == (key[u] & kmask[u]));
       if (eq) return slot;
     }
     slot = slot + 1 == cap ? 0 : slot + 1;
@@ -399,13 +473,17 @@ __device__ __forceinline__ int lds_find_or_insert(plan_dev const& p, uint32_t* s
   return -1;
 }
 
-template <int KUT>
-__global__ void __launch_bounds__(1024) k_aggregate(agg_args a)
+// INPUT: agg_input. KUT: key units held in registers. PAYT: payload units of a RECORD prefetched into
+// registers together with the key (0 = payload fetched lazily per accumulator: column input, wide records).
+// EXACT: the input record has exactly KUT + PAYT units (a 16-byte record is one global_load_dwordx4).
+template <int INPUT, int KUT, int PAYT, bool SIMPLE, bool EXACT>
+__global__ void __launch_bounds__(1024) k_aggregate(agg_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  agg_args const& a = *ap;
   plan_dev const& p = a.plan;
   int const cap     = a.geom.cap;
-  int const KU = p.KU, NACC = p.NACC;
+  int const KU = EXACT ? KUT : p.KU, NACC = p.NACC;
   uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);                 // [KU][cap]
   uint64_t* accs = keys + static_cast<size_t>(KU) * cap;                   // [NACC][cap]
   uint32_t* st   = reinterpret_cast<uint32_t*>(accs + static_cast<size_t>(NACC) * cap);  // [cap]
@@ -422,16 +500,25 @@ __global__ void __launch_bounds__(1024) k_aggregate(agg_args a)
     uint64_t const id = acc_identity(p.acc[q].op);
     for (int s = threadIdx.x; s < cap; s += blockDim.x) accs[static_cast<size_t>(q) * cap + s] = id;
   }
+  uint64_t kmask[KUT];
+#pragma unroll
+  for (int u = 0; u < KUT; ++u) kmask[u] = u < KU ? p.key_mask[u] : 0;
   __syncthreads();
 
-  int const item = blockIdx.x;
-  int const RU   = KU + p.NPAY;  // raw record units
-  int const PU   = KU + NACC;    // partial record units
+  int const item  = blockIdx.x;
+  int const RU    = KU + p.NPAY;  // raw record units
+  int const PU    = KU + NACC;    // partial record units
+  int const U     = EXACT ? (KUT + PAYT) : (INPUT == IN_RAW_RECORDS ? RU : PU);
+  int const fill_limit = a.geom.fill_limit;
+  int const flags_unit = p.flags_unit, flags_hi = p.flags_hi;
+  uint64_t const* records = a.records;
   int nsrc = 1, src0 = item;
   if (a.seg == SEG_STRIDED) {
     src0 = item * a.fan;
     nsrc = min(a.fan, a.nsrc - src0);
   }
+  constexpr int R = 4;  // rows in flight per thread
+  int64_t const B = blockDim.x;
   for (int sidx = 0; sidx < nsrc; ++sidx) {
     int64_t begin, end;
     if (a.seg == SEG_ROW_CHUNKS) {
@@ -444,57 +531,103 @@ __global__ void __launch_bounds__(1024) k_aggregate(agg_args a)
       begin = static_cast<int64_t>(src0 + sidx) * a.src_stride;
       end   = begin + a.src_count[src0 + sidx];
     }
-    for (int64_t r = begin + threadIdx.x; r < end; r += blockDim.x) {
-      uint64_t key[KUT];
-      uint32_t valvalid = 0xffffffffu;
-      bool keep         = true;
-      if (a.input == IN_COLUMNS) {
-        keep = build_key_units<KUT>(p, r, key, valvalid);
-      } else {
-        int const U = a.input == IN_RAW_RECORDS ? RU : PU;
+    for (int64_t base = begin; base < end; base += R * B) {
+      uint64_t key[R][KUT];
+      uint64_t pay[R][PAYT > 0 ? PAYT : 1];
+      uint32_t valvalid[R];
+      bool keep[R];
+      // ---- loads for R rows first (bytes in flight), then the LDS work
 #pragma unroll
-        for (int u = 0; u < KUT; ++u) key[u] = (u < KU) ? a.records[r * U + u] : 0;
-        if (a.input == IN_RAW_RECORDS && p.flags_unit >= 0)
-          valvalid = reinterpret_cast<uint32_t const*>(a.records + r * U + p.flags_unit)[p.flags_hi];
-      }
-      if (!keep) continue;
-      uint64_t const h = hash_key_units<KUT>(p, key);
-      int const slot   = lds_find_or_insert<KUT>(p, st, keys, cap, key, h, &s_nfilled, a.geom.fill_limit, &s_overflow);
-      if (slot < 0) continue;
-      int last_pay   = -1;
-      uint64_t value = 0;
-      for (int q = 0; q < NACC; ++q) {
-        acc_desc const d = p.acc[q];
-        uint64_t* tgt    = accs + static_cast<size_t>(q) * cap + slot;
-        if (a.input == IN_PARTIAL_RECORDS) {
-          lds_merge(tgt, d.op, a.records[r * PU + KU + q]);
-          continue;
-        }
-        bool const valid = d.valid_bit < 0 || ((valvalid >> d.valid_bit) & 1u);
-        if (d.src == SRC_ONE) {
-          lds_merge(tgt, ADD_I64, 1);
-          continue;
-        }
-        if (!valid) continue;
-        if (d.src == SRC_ONE_IF_VALID) {
-          lds_merge(tgt, ADD_I64, 1);
-          continue;
-        }
-        if (d.pay != last_pay) {
-          value    = a.input == IN_COLUMNS ? col_load_acc_bits(p.cols[p.nkeycols + d.pay], r)
-                                           : a.records[r * RU + KU + d.pay];
-          last_pay = d.pay;
-        }
-        uint64_t v = value;
-        if (d.src == SRC_SQUARE) {
-          if (d.op == ADD_F64) {
-            double const x = __longlong_as_double(static_cast<long long>(v));
-            v              = static_cast<uint64_t>(__double_as_longlong(x * x));
+      for (int k = 0; k < R; ++k) {
+        int64_t const r = base + k * B + threadIdx.x;
+        keep[k]         = r < end;
+        valvalid[k]     = 0xffffffffu;
+        if (keep[k]) {
+          if constexpr (INPUT == IN_COLUMNS) {
+            keep[k] = build_key_units<KUT, SIMPLE>(p, r, key[k], valvalid[k]);
+          } else if constexpr (EXACT && KUT == 1 && PAYT == 1) {
+            u64x2 const v = gload(reinterpret_cast<u64x2 const*>(records) + r);
+            key[k][0]          = v.x;
+            pay[k][0]          = v.y;
           } else {
-            v = v * v;
+#pragma unroll
+            for (int u = 0; u < KUT; ++u) key[k][u] = (u < KU) ? gload(records + r * U + u) : 0;
+            if constexpr (PAYT > 0) {
+#pragma unroll
+              for (int v = 0; v < PAYT; ++v) pay[k][v] = gload(records + r * U + KU + v);
+            }
+            if (INPUT == IN_RAW_RECORDS && flags_unit >= 0)
+              valvalid[k] = gload(reinterpret_cast<uint32_t const*>(records + r * U + flags_unit) + flags_hi);
           }
         }
-        lds_merge(tgt, d.op, v);
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (!keep[k]) continue;
+        int64_t const r = base + k * B + threadIdx.x;
+        uint64_t h      = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+        for (int u = 0; u < KUT; ++u)
+          if (u < KU) h = mix64(h ^ (key[k][u] & kmask[u]));
+        int const slot = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h, &s_nfilled, fill_limit, &s_overflow);
+        if (slot < 0) continue;
+        int last_pay   = -1;
+        uint64_t value = 0;
+        for (int q = 0; q < NACC; ++q) {
+          uint32_t const dw = reinterpret_cast<uint32_t const*>(p.acc)[q];  // one scalar load
+          acc_desc d;
+          d.op        = static_cast<int8_t>(dw);
+          d.src       = static_cast<int8_t>(dw >> 8);
+          d.pay       = static_cast<int8_t>(dw >> 16);
+          d.valid_bit = static_cast<int8_t>(dw >> 24);
+          uint64_t* tgt = accs + static_cast<size_t>(q) * cap + slot;
+          if constexpr (INPUT == IN_PARTIAL_RECORDS) {
+            uint64_t v;
+            if constexpr (PAYT > 0) {
+              v = 0;
+#pragma unroll
+              for (int w = 0; w < PAYT; ++w)
+                if (q == w) v = pay[k][w];
+            } else {
+              v = gload(records + r * U + KU + q);
+            }
+            lds_merge(tgt, d.op, v);
+            continue;
+          }
+          if (d.src == SRC_ONE) {
+            lds_merge(tgt, ADD_I64, 1);
+            continue;
+          }
+          bool const valid = d.valid_bit < 0 || ((valvalid[k] >> d.valid_bit) & 1u);
+          if (!valid) continue;
+          if (d.src == SRC_ONE_IF_VALID) {
+            lds_merge(tgt, ADD_I64, 1);
+            continue;
+          }
+          if (d.pay != last_pay) {
+            if constexpr (INPUT == IN_COLUMNS) {
+              if constexpr (SIMPLE) value = gload(p.simple_base[KU + d.pay] + r);
+              else value = col_load_acc_bits(p.cols[p.nkeycols + d.pay], r);
+            } else if constexpr (PAYT > 0) {
+#pragma unroll
+              for (int w = 0; w < PAYT; ++w)
+                if (d.pay == w) value = pay[k][w];
+            } else {
+              value = gload(records + r * U + KU + d.pay);
+            }
+            last_pay = d.pay;
+          }
+          uint64_t v = value;
+          if (d.src == SRC_SQUARE) {
+            if (d.op == ADD_F64) {
+              double const x = __longlong_as_double(static_cast<long long>(v));
+              v              = static_cast<uint64_t>(__double_as_longlong(x * x));
+            } else {
+              v = v * v;
+            }
+          }
+          lds_merge(tgt, d.op, v);
+        }
       }
     }
   }
@@ -505,8 +638,8 @@ __global__ void __launch_bounds__(1024) k_aggregate(agg_args a)
     if (st[s] >= 2) {
       uint32_t const pos = atomicAdd(&s_dump, 1u);
       uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
-      for (int u = 0; u < KU; ++u) o[u] = keys[static_cast<size_t>(u) * cap + s];
-      for (int q = 0; q < NACC; ++q) o[KU + q] = accs[static_cast<size_t>(q) * cap + s];
+      for (int u = 0; u < KU; ++u) gstore(o + u, keys[static_cast<size_t>(u) * cap + s]);
+      for (int q = 0; q < NACC; ++q) gstore(o + KU + q, accs[static_cast<size_t>(q) * cap + s]);
     }
   }
   __syncthreads();
@@ -527,9 +660,11 @@ __device__ __forceinline__ void store_elem(void* base, int64_t i, int width, uin
   }
 }
 
-__global__ void __launch_bounds__(256) k_finalize(plan_dev p, finalize_dev f, uint64_t const* records, int64_t cap,
-                                                  int64_t const* prefix, int32_t nitems, int64_t total)
+__global__ void __launch_bounds__(256) k_finalize(finalize_args const* __restrict__ fa, uint64_t const* records,
+                                                  int64_t cap, int64_t const* prefix, int32_t nitems, int64_t total)
 {
+  plan_dev const& p     = fa->plan;
+  finalize_dev const& f = fa->fin;
   int64_t const o = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   bool const live = o < total;
   int const PU    = p.KU + p.NACC;
@@ -591,15 +726,16 @@ __global__ void __launch_bounds__(256) k_finalize(plan_dev p, finalize_dev f, ui
 }
 
 // ------------------------------------------------------------------ K_estimate (linear counting on a sample)
-__global__ void __launch_bounds__(256) k_estimate(plan_dev p, int64_t nrows, int64_t sample, uint32_t* bitmap,
-                                                  int32_t bits_log2)
+__global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
+                                                  uint32_t* bitmap, int32_t bits_log2)
 {
-  int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  plan_dev const& p = *pp;
+  int64_t const i   = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= sample) return;
   int64_t const row = sample >= nrows ? i : static_cast<int64_t>((static_cast<__int128>(i) * nrows) / sample);
   uint64_t key[MAX_KU];
   uint32_t vv;
-  if (!build_key_units<MAX_KU>(p, row, key, vv)) return;
+  if (!build_key_units<MAX_KU, false>(p, row, key, vv)) return;
   uint64_t const h   = hash_key_units<MAX_KU>(p, key);
   uint32_t const bit = static_cast<uint32_t>(h >> (64 - bits_log2));
   atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
@@ -619,24 +755,22 @@ inline int next_ut(int u)
     if (u <= c) return c;
   return -1;
 }
-}  // namespace
 
-// ------------------------------------------------------------------ launchers
 // Opts a kernel into the full 160 KiB of LDS (static + dynamic) once per process.
-static void allow_full_lds(void const* fn)
+void allow_full_lds(void const* fn)
 {
   hipFuncAttributes attr{};
   CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
   int const dyn = 160 * 1024 - static_cast<int>(attr.sharedSizeBytes);
   CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
 }
+}  // namespace
 
+// ------------------------------------------------------------------ launchers
 std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g)
 {
   return static_cast<std::size_t>(g.cap) * (8u * (plan.KU + plan.NACC) + 4u);
 }
-
-static int scatter_rpt(int ut) { return ut <= 2 ? 8 : ut <= 4 ? 4 : ut <= 8 ? 2 : 1; }
 
 std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g)
 {
@@ -645,92 +779,131 @@ std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g)
   return T * U * 8 + static_cast<std::size_t>(g.P) * (8 + 4) + (T + (T & 1)) * 2 + 16 * 4;
 }
 
-void launch_partition_hist(part_args const& a, hipStream_t stream)
+void store_args(part_args const& a, part_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<part_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_partition_hist(part_args const& a, part_args const* d_args, hipStream_t stream)
 {
   int const items = a.geom.nseg * a.geom.slices;
-  hipLaunchKernelGGL(k_partition_hist, dim3(items), dim3(a.geom.block), a.geom.P * sizeof(uint32_t), stream, a);
+  cudf::detail::prof::scope prof_{"partition_hist", stream};
+  if (a.plan.simple && a.from_columns)
+    hipLaunchKernelGGL(k_partition_hist<true>, dim3(items), dim3(a.geom.block), a.geom.P * sizeof(uint32_t), stream, d_args);
+  else
+    hipLaunchKernelGGL(k_partition_hist<false>, dim3(items), dim3(a.geom.block), a.geom.P * sizeof(uint32_t), stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
-void launch_partition_scan(part_args const& a, hipStream_t stream)
+void launch_partition_scan(part_args const& a, part_args const* d_args, hipStream_t stream)
 {
-  hipLaunchKernelGGL(k_partition_scan, dim3(a.geom.nseg), dim3(1024), 2 * a.geom.P * sizeof(uint32_t), stream, a);
+  cudf::detail::prof::scope prof_{"partition_scan", stream};
+  hipLaunchKernelGGL(k_partition_scan, dim3(a.geom.nseg), dim3(1024), 2 * a.geom.P * sizeof(uint32_t), stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
-template <int UT, int RPT>
-static void launch_scatter_t(part_args const& a, hipStream_t stream)
+template <int UT, int RPT, bool SIMPLE, bool EXACT>
+static void launch_scatter_t(part_args const& a, part_args const* d_args, hipStream_t stream)
 {
-  part_args b   = a;
-  b.geom.tile_rows = b.geom.block * RPT;
-  auto const lds = partition_lds_bytes(b.plan, b.geom);
+  part_geom g  = a.geom;
+  g.tile_rows  = g.block * RPT;
+  auto const lds = partition_lds_bytes(a.plan, g);
   CUDF_EXPECTS(lds <= 160 * 1024, "partition kernel: LDS budget exceeded (fan-out too large for this record width)");
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter<UT, RPT>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter<UT, RPT, SIMPLE, EXACT>));
     attr_set = true;
   }
-  int const items = b.geom.nseg * b.geom.slices;
-  hipLaunchKernelGGL((k_partition_scatter<UT, RPT>), dim3(items), dim3(b.geom.block), lds, stream, b);
+  int const items = g.nseg * g.slices;
+  cudf::detail::prof::scope prof_{"partition_scatter", stream};
+  hipLaunchKernelGGL((k_partition_scatter<UT, RPT, SIMPLE, EXACT>), dim3(items), dim3(g.block), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
-void launch_partition_scatter(part_args const& a, hipStream_t stream)
+void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream)
 {
   CUDF_EXPECTS(a.geom.P <= 2 * a.geom.block, "partition fan-out exceeds 2x the block size");
-  int const U = a.plan.KU + a.plan.NPAY;
+  int const U       = a.plan.KU + a.plan.NPAY;
+  bool const simple = a.plan.simple && a.from_columns;
   switch (next_ut(U)) {
-    case 2: launch_scatter_t<2, 8>(a, stream); break;
-    case 3: launch_scatter_t<3, 4>(a, stream); break;
-    case 4: launch_scatter_t<4, 4>(a, stream); break;
-    case 6: launch_scatter_t<6, 2>(a, stream); break;
-    case 8: launch_scatter_t<8, 2>(a, stream); break;
-    case 12: launch_scatter_t<12, 1>(a, stream); break;
-    case 16: launch_scatter_t<16, 1>(a, stream); break;
+    case 2: simple ? launch_scatter_t<2, 8, true, true>(a, d_args, stream) : launch_scatter_t<2, 8, false, true>(a, d_args, stream); break;
+    case 3: simple ? launch_scatter_t<3, 4, true, true>(a, d_args, stream) : launch_scatter_t<3, 4, false, true>(a, d_args, stream); break;
+    case 4: simple ? launch_scatter_t<4, 4, true, true>(a, d_args, stream) : launch_scatter_t<4, 4, false, true>(a, d_args, stream); break;
+    case 6: launch_scatter_t<6, 2, false, false>(a, d_args, stream); break;
+    case 8: launch_scatter_t<8, 2, false, false>(a, d_args, stream); break;
+    case 12: launch_scatter_t<12, 1, false, false>(a, d_args, stream); break;
+    case 16: launch_scatter_t<16, 1, false, false>(a, d_args, stream); break;
     default: CUDF_FAIL("record too wide for the partition kernel");
   }
 }
 
-template <int KUT>
-static void launch_aggregate_t(agg_args const& a, hipStream_t stream)
+template <int INPUT, int KUT, int PAYT, bool SIMPLE, bool EXACT>
+static void launch_aggregate_t(agg_args const& a, agg_args* d_args, hipStream_t stream)
 {
   auto const lds = aggregate_lds_bytes(a.plan, a.geom);
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<KUT>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<INPUT, KUT, PAYT, SIMPLE, EXACT>));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_aggregate<KUT>), dim3(a.nitems), dim3(a.geom.block), lds, stream, a);
+  hipLaunchKernelGGL(k_store_args<agg_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"aggregate", stream};
+  hipLaunchKernelGGL((k_aggregate<INPUT, KUT, PAYT, SIMPLE, EXACT>), dim3(a.nitems), dim3(a.geom.block), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
-void launch_aggregate(agg_args const& a, hipStream_t stream)
+template <int INPUT>
+static void launch_aggregate_records(agg_args const& a, agg_args* d_args, hipStream_t stream)
 {
-  if (a.nitems == 0) return;
-  if (a.plan.KU <= 1) launch_aggregate_t<1>(a, stream);
-  else if (a.plan.KU <= 2) launch_aggregate_t<2>(a, stream);
-  else launch_aggregate_t<4>(a, stream);
+  int const KU   = a.plan.KU;
+  int const npay = INPUT == IN_RAW_RECORDS ? a.plan.NPAY : a.plan.NACC;
+  // exact shapes get the payload prefetched with the key; everything else fetches it lazily
+  if (KU == 1 && npay == 1) return launch_aggregate_t<INPUT, 1, 1, false, true>(a, d_args, stream);
+  if (KU == 1 && npay == 2) return launch_aggregate_t<INPUT, 1, 2, false, true>(a, d_args, stream);
+  if (KU == 2 && npay == 1) return launch_aggregate_t<INPUT, 2, 1, false, true>(a, d_args, stream);
+  if (KU == 2 && npay == 2) return launch_aggregate_t<INPUT, 2, 2, false, true>(a, d_args, stream);
+  if (KU == 2 && npay == 4) return launch_aggregate_t<INPUT, 2, 4, false, true>(a, d_args, stream);
+  if (KU <= 1) return launch_aggregate_t<INPUT, 1, 0, false, false>(a, d_args, stream);
+  if (KU <= 2) return launch_aggregate_t<INPUT, 2, 0, false, false>(a, d_args, stream);
+  return launch_aggregate_t<INPUT, 4, 0, false, false>(a, d_args, stream);
 }
 
-void launch_finalize(plan_dev const& plan, finalize_dev const& fin, uint64_t const* records, int64_t cap,
+void launch_aggregate(agg_args const& a, agg_args* d_args, hipStream_t stream)
+{
+  if (a.nitems == 0) return;
+  int const KU = a.plan.KU;
+  if (a.input == IN_RAW_RECORDS) return launch_aggregate_records<IN_RAW_RECORDS>(a, d_args, stream);
+  if (a.input == IN_PARTIAL_RECORDS) return launch_aggregate_records<IN_PARTIAL_RECORDS>(a, d_args, stream);
+  bool const simple = a.plan.simple;
+  if (KU <= 1) simple ? launch_aggregate_t<IN_COLUMNS, 1, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 1, 0, false, false>(a, d_args, stream);
+  else if (KU <= 2) simple ? launch_aggregate_t<IN_COLUMNS, 2, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 2, 0, false, false>(a, d_args, stream);
+  else simple ? launch_aggregate_t<IN_COLUMNS, 4, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 4, 0, false, false>(a, d_args, stream);
+}
+
+void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t const* records, int64_t cap,
                      int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream)
 {
   if (total == 0) return;
   int const block = 256;
   int64_t const grid = (total + block - 1) / block;
-  hipLaunchKernelGGL(k_finalize, dim3(static_cast<unsigned>(grid)), dim3(block), 0, stream, plan, fin, records, cap, prefix,
+  hipLaunchKernelGGL(k_store_args<finalize_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"finalize", stream};
+  hipLaunchKernelGGL(k_finalize, dim3(static_cast<unsigned>(grid)), dim3(block), 0, stream, d_args, records, cap, prefix,
                      nitems, total);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
-void launch_estimate(plan_dev const& plan, int64_t nrows, int64_t sample, uint32_t* bitmap, int32_t bitmap_bits_log2,
-                     uint32_t* d_bits_set, hipStream_t stream)
+void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
+                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, hipStream_t stream)
 {
   int64_t const nwords = (int64_t{1} << bitmap_bits_log2) / 32;
   CUDF_HIP_TRY(hipMemsetAsync(bitmap, 0, nwords * 4, stream));
   CUDF_HIP_TRY(hipMemsetAsync(d_bits_set, 0, 4, stream));
   int const block = 256;
-  hipLaunchKernelGGL(k_estimate, dim3(static_cast<unsigned>((sample + block - 1) / block)), dim3(block), 0, stream, plan,
+  hipLaunchKernelGGL(k_store_args<plan_dev>, dim3(1), dim3(1), 0, stream, plan, d_plan);
+  cudf::detail::prof::scope prof_{"estimate", stream};
+  hipLaunchKernelGGL(k_estimate, dim3(static_cast<unsigned>((sample + block - 1) / block)), dim3(block), 0, stream, d_plan,
                      nrows, sample, bitmap, bitmap_bits_log2);
   hipLaunchKernelGGL(k_popcount, dim3(256), dim3(block), 0, stream, bitmap, nwords, d_bits_set);
   CUDF_HIP_TRY(hipGetLastError());

@@ -11,7 +11,10 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 #include <new>
 #include <string>
 
@@ -290,6 +293,98 @@ void hip_async_memory_resource::do_deallocate(void* p, std::size_t, hipStream_t 
   (void)hipFreeAsync(p, stream);
 }
 
+// ---- caching pool
+struct pool_memory_resource::impl {
+  struct block {
+    void* ptr;
+    std::size_t size;
+    hipEvent_t freed;      // recorded on `stream` when the block was returned
+    hipStream_t stream;
+  };
+  std::mutex mu;
+  std::map<std::size_t, std::vector<block>> free_lists;  // rounded size -> blocks
+  std::unordered_map<void*, block> live;
+  std::size_t cached{0};
+};
+
+static std::size_t round_pool_size(std::size_t bytes)
+{
+  constexpr std::size_t small = 256, big = std::size_t{2} << 20;
+  if (bytes < (std::size_t{1} << 20)) return (bytes + small - 1) / small * small;
+  return (bytes + big - 1) / big * big;
+}
+
+pool_memory_resource::pool_memory_resource() : _impl{new impl} {}
+pool_memory_resource::~pool_memory_resource()
+{
+  // Process teardown: the HIP runtime may already be gone; leak the device memory deliberately.
+  delete _impl;
+}
+std::size_t pool_memory_resource::cached_bytes() const { return _impl->cached; }
+void pool_memory_resource::trim()
+{
+  std::lock_guard<std::mutex> g{_impl->mu};
+  for (auto& [sz, v] : _impl->free_lists) {
+    for (auto& b : v) {
+      (void)hipEventSynchronize(b.freed);
+      (void)hipEventDestroy(b.freed);
+      (void)hipFree(b.ptr);
+    }
+  }
+  _impl->free_lists.clear();
+  _impl->cached = 0;
+}
+void* pool_memory_resource::do_allocate(std::size_t bytes, hipStream_t stream)
+{
+  std::size_t const sz = round_pool_size(bytes);
+  {
+    std::lock_guard<std::mutex> g{_impl->mu};
+    auto it = _impl->free_lists.find(sz);
+    if (it != _impl->free_lists.end() && !it->second.empty()) {
+      auto b = it->second.back();
+      it->second.pop_back();
+      _impl->cached -= sz;
+      if (b.stream != stream) {
+        auto const e = hipStreamWaitEvent(stream, b.freed, 0);
+        if (e != hipSuccess) cudf::detail::throw_hip_error(e, __FILE__, __LINE__);
+      }
+      b.stream           = stream;
+      _impl->live[b.ptr] = b;
+      return b.ptr;
+    }
+  }
+  void* p = nullptr;
+  auto e  = hipMalloc(&p, sz);
+  if (e == hipErrorOutOfMemory) {  // give cached blocks back and retry once
+    (void)hipGetLastError();
+    trim();
+    e = hipMalloc(&p, sz);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (e == hipErrorOutOfMemory) throw std::bad_alloc{};
+    cudf::detail::throw_hip_error(e, __FILE__, __LINE__);
+  }
+  impl::block b{p, sz, nullptr, stream};
+  e = hipEventCreateWithFlags(&b.freed, hipEventDisableTiming);
+  if (e != hipSuccess) cudf::detail::throw_hip_error(e, __FILE__, __LINE__);
+  std::lock_guard<std::mutex> g{_impl->mu};
+  _impl->live[p] = b;
+  return p;
+}
+void pool_memory_resource::do_deallocate(void* p, std::size_t, hipStream_t stream) noexcept
+{
+  std::lock_guard<std::mutex> g{_impl->mu};
+  auto it = _impl->live.find(p);
+  if (it == _impl->live.end()) return;  // not ours (should not happen)
+  auto b   = it->second;
+  b.stream = stream;
+  _impl->live.erase(it);
+  (void)hipEventRecord(b.freed, stream);
+  _impl->free_lists[b.size].push_back(b);
+  _impl->cached += b.size;
+}
+
 namespace {
 device_memory_resource*& current_slot()
 {
@@ -308,7 +403,7 @@ device_memory_resource* get_current_device_resource()
   std::lock_guard<std::mutex> g{slot_mutex()};
   auto*& cur = current_slot();
   if (cur == nullptr) {
-    static hip_async_memory_resource default_mr{};
+    static pool_memory_resource default_mr{};
     cur = &default_mr;
   }
   return cur;

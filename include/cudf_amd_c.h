@@ -71,6 +71,12 @@ cudf_amd_status cudf_amd_stream_synchronize(void* stream);
 /* Live / peak bytes handed out by the library's current device resource since load. */
 cudf_amd_status cudf_amd_memory_stats(uint64_t* current_bytes, uint64_t* peak_bytes);
 
+/* ---- per-kernel timing (HIP events on the launch stream); off by default.
+ * report: one line per kernel "name launches total_ms\n" written into buf (NUL-terminated, truncated to n). */
+cudf_amd_status cudf_amd_profile_enable(int32_t on);
+cudf_amd_status cudf_amd_profile_reset(void);
+cudf_amd_status cudf_amd_profile_report(char* buf, size_t n);
+
 /* ---- owning tables */
 int32_t cudf_amd_table_num_columns(cudf_amd_table_t t);
 int32_t cudf_amd_table_num_rows(cudf_amd_table_t t);

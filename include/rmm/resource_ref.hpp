@@ -35,6 +35,26 @@ class hip_async_memory_resource final : public device_memory_resource {
   void do_deallocate(void* p, std::size_t bytes, hipStream_t stream) noexcept override;
 };
 
+// Caching pool over hipMalloc: freed blocks are kept in exact-size free lists (sizes rounded to 256 B classes
+// below 1 MiB and to 2 MiB multiples above) and handed back stream-ordered — a block freed on stream A and
+// reused on stream B makes B wait for the event recorded at the free. This is the default resource: on
+// ROCm 7.2 the hipMallocAsync default pool re-maps multi-GB blocks (0.1-0.9 s per 16 GB allocation) once small
+// allocations have fragmented it, which dwarfs the 30 ms groupby it serves. 288 GB of HBM3E make holding the
+// working set resident the right trade; trim() returns everything to the driver.
+class pool_memory_resource final : public device_memory_resource {
+ public:
+  pool_memory_resource();
+  ~pool_memory_resource() override;
+  void trim();
+  [[nodiscard]] std::size_t cached_bytes() const;
+
+ private:
+  void* do_allocate(std::size_t bytes, hipStream_t stream) override;
+  void do_deallocate(void* p, std::size_t bytes, hipStream_t stream) noexcept override;
+  struct impl;
+  impl* _impl;
+};
+
 // Counts live/peak bytes on top of another resource (benchmarks and leak tests).
 class statistics_resource_adaptor final : public device_memory_resource {
  public:
