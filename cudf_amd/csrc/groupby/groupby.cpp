@@ -452,7 +452,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   int64_t const lds_budget = env_i64("CUDF_AMD_GB_LDS_KB", 72) * 1024;
   int const slot_bytes     = 8 * PU + 4;
   ag.cap                   = static_cast<int32_t>(std::min<int64_t>(lds_budget / slot_bytes, 16384));
-  ag.block                 = static_cast<int32_t>(env_i64("CUDF_AMD_GB_AGG_BLOCK", 512));
+  ag.block                 = static_cast<int32_t>(env_i64("CUDF_AMD_GB_AGG_BLOCK", 1024));
   ag.fill_limit            = static_cast<int32_t>(ag.cap * 0.6);
   CUDF_EXPECTS(ag.cap >= 64, "Aggregation state per group too large for an LDS table.");
 

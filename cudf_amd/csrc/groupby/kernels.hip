@@ -445,7 +445,7 @@ __device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask
       if (old == ST_EMPTY) {
 #pragma unroll
         for (int u = 0; u < KUT; ++u)
-          if (u < KU) keys[static_cast<size_t>(u) * cap + slot] = key[u] & kmask[u];
+          if (u < KU) keys[static_cast<uint32_t>(u * cap + slot)] = key[u] & kmask[u];
         // publish: key words first, then the tag (LDS executes a wave's accesses in order; the release fence
         // keeps the compiler from reordering and waits for the key stores)
         __hip_atomic_store(&st[slot], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -464,7 +464,7 @@ __device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask
       bool eq = true;
 #pragma unroll
       for (int u = 0; u < KUT; ++u)
-        if (u < KU) eq = eq && (keys[static_cast<size_t>(u) * cap + slot] == (key[u] & kmask[u]));
+        if (u < KU) eq = eq && (keys[static_cast<uint32_t>(u * cap + slot)] == (key[u] & kmask[u]));
       if (eq) return slot;
     }
     slot = slot + 1 == cap ? 0 : slot + 1;
@@ -475,9 +475,10 @@ __device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask
 
 // INPUT: agg_input. KUT: key units held in registers. PAYT: payload units of a RECORD prefetched into
 // registers together with the key (0 = payload fetched lazily per accumulator: column input, wide records).
+// NACCT: compile-time bound of the accumulator loop (descriptors sit in registers, statically indexed).
 // EXACT: the input record has exactly KUT + PAYT units (a 16-byte record is one global_load_dwordx4).
-template <int INPUT, int KUT, int PAYT, bool SIMPLE, bool EXACT>
-__global__ void __launch_bounds__(1024) k_aggregate(agg_args const* __restrict__ ap)
+template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT>
+__global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggregate(agg_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   agg_args const& a = *ap;
@@ -503,6 +504,16 @@ __global__ void __launch_bounds__(1024) k_aggregate(agg_args const* __restrict__
   uint64_t kmask[KUT];
 #pragma unroll
   for (int u = 0; u < KUT; ++u) kmask[u] = u < KU ? p.key_mask[u] : 0;
+  // accumulator descriptors live in (scalar) registers for the whole kernel: no memory access per row
+  int acc_op[NACCT], acc_src[NACCT], acc_pay[NACCT], acc_vbit[NACCT];
+#pragma unroll
+  for (int j = 0; j < NACCT; ++j) {
+    uint32_t const w = j < NACC ? reinterpret_cast<uint32_t const*>(p.acc)[j] : 0u;
+    acc_op[j]        = static_cast<int8_t>(w);
+    acc_src[j]       = static_cast<int8_t>(w >> 8);
+    acc_pay[j]       = static_cast<int8_t>(w >> 16);
+    acc_vbit[j]      = static_cast<int8_t>(w >> 24);
+  }
   __syncthreads();
 
   int const item  = blockIdx.x;
@@ -512,12 +523,99 @@ __global__ void __launch_bounds__(1024) k_aggregate(agg_args const* __restrict__
   int const fill_limit = a.geom.fill_limit;
   int const flags_unit = p.flags_unit, flags_hi = p.flags_hi;
   uint64_t const* records = a.records;
+
+  // accumulators of one row whose LDS slot is known
+  auto accumulate = [&](int64_t r, int slot, uint64_t const (&pay)[PAYT > 0 ? PAYT : 1], uint32_t valvalid) {
+    int last_pay   = -1;
+    uint64_t value = 0;
+#pragma unroll
+    for (int q = 0; q < NACCT; ++q) {
+      if (q >= NACC) break;
+      uint64_t* tgt = accs + (static_cast<uint32_t>(q) * static_cast<uint32_t>(cap) + static_cast<uint32_t>(slot));
+      if constexpr (INPUT == IN_PARTIAL_RECORDS) {
+        uint64_t v;
+        if constexpr (PAYT > 0) v = q < PAYT ? pay[q < PAYT ? q : 0] : 0;
+        else v = gload(records + r * U + KU + q);
+        lds_merge(tgt, acc_op[q], v);
+      } else {
+        if (acc_src[q] == SRC_ONE) {
+          lds_merge(tgt, ADD_I64, 1);
+          continue;
+        }
+        bool const valid = acc_vbit[q] < 0 || ((valvalid >> acc_vbit[q]) & 1u);
+        if (!valid) continue;
+        if (acc_src[q] == SRC_ONE_IF_VALID) {
+          lds_merge(tgt, ADD_I64, 1);
+          continue;
+        }
+        if (acc_pay[q] != last_pay) {
+          if constexpr (INPUT == IN_COLUMNS) {
+            if constexpr (SIMPLE) value = gload(p.simple_base[KU + acc_pay[q]] + r);
+            else value = col_load_acc_bits(p.cols[p.nkeycols + acc_pay[q]], r);
+          } else if constexpr (PAYT > 0) {
+#pragma unroll
+            for (int w = 0; w < PAYT; ++w)
+              if (acc_pay[q] == w) value = pay[w];
+          } else {
+            value = gload(records + r * U + KU + acc_pay[q]);
+          }
+          last_pay = acc_pay[q];
+        }
+        uint64_t v = value;
+        if (acc_src[q] == SRC_SQUARE) {
+          if (acc_op[q] == ADD_F64) {
+            double const x = __longlong_as_double(static_cast<long long>(v));
+            v              = static_cast<uint64_t>(__double_as_longlong(x * x));
+          } else {
+            v = v * v;
+          }
+        }
+        lds_merge(tgt, acc_op[q], v);
+      }
+    }
+  };
+  auto hash_of = [&](uint64_t const (&key)[KUT]) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int u = 0; u < KUT; ++u)
+      if (u < KU) h = mix64(h ^ (key[u] & kmask[u]));
+    return h;
+  };
+  // one row, unbatched (tail rows)
+  auto process = [&](int64_t r, uint64_t const (&key)[KUT], uint64_t const (&pay)[PAYT > 0 ? PAYT : 1], uint32_t valvalid) {
+    uint64_t const h = hash_of(key);
+    int const slot   = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key, h, &s_nfilled, fill_limit, &s_overflow);
+    if (slot >= 0) accumulate(r, slot, pay, valvalid);
+  };
+  // loads one row; false if the row is dropped
+  auto load_row = [&](int64_t r, uint64_t (&key)[KUT], uint64_t (&pay)[PAYT > 0 ? PAYT : 1], uint32_t& valvalid) -> bool {
+    valvalid = 0xffffffffu;
+    if constexpr (INPUT == IN_COLUMNS) {
+      return build_key_units<KUT, SIMPLE>(p, r, key, valvalid);
+    } else if constexpr (EXACT && KUT == 1 && PAYT == 1) {
+      u64x2 const v = gload(reinterpret_cast<u64x2 const*>(records) + r);
+      key[0]        = v.x;
+      pay[0]        = v.y;
+      return true;
+    } else {
+#pragma unroll
+      for (int u = 0; u < KUT; ++u) key[u] = (u < KU) ? gload(records + r * U + u) : 0;
+      if constexpr (PAYT > 0) {
+#pragma unroll
+        for (int v = 0; v < PAYT; ++v) pay[v] = gload(records + r * U + KU + v);
+      }
+      if (INPUT == IN_RAW_RECORDS && flags_unit >= 0)
+        valvalid = gload(reinterpret_cast<uint32_t const*>(records + r * U + flags_unit) + flags_hi);
+      return true;
+    }
+  };
+
   int nsrc = 1, src0 = item;
   if (a.seg == SEG_STRIDED) {
     src0 = item * a.fan;
     nsrc = min(a.fan, a.nsrc - src0);
   }
-  constexpr int R = 4;  // rows in flight per thread
+  constexpr int R = (KUT + PAYT <= 2) ? 4 : 2;  // rows in flight per thread
   int64_t const B = blockDim.x;
   for (int sidx = 0; sidx < nsrc; ++sidx) {
     int64_t begin, end;
@@ -531,104 +629,48 @@ __global__ void __launch_bounds__(1024) k_aggregate(agg_args const* __restrict__
       begin = static_cast<int64_t>(src0 + sidx) * a.src_stride;
       end   = begin + a.src_count[src0 + sidx];
     }
-    for (int64_t base = begin; base < end; base += R * B) {
+    int64_t base = begin;
+    // main loop: R full rows per thread, all loads issued before the LDS work
+    for (; base + R * B <= end; base += R * B) {
       uint64_t key[R][KUT];
       uint64_t pay[R][PAYT > 0 ? PAYT : 1];
       uint32_t valvalid[R];
       bool keep[R];
-      // ---- loads for R rows first (bytes in flight), then the LDS work
+#pragma unroll
+      for (int k = 0; k < R; ++k) keep[k] = load_row(base + k * B + threadIdx.x, key[k], pay[k], valvalid[k]);
+      // Batched first probe: the state word and the stored key words of the home slot of all R rows are read
+      // with independent ds_reads (one LDS round trip for the common "group already present" case); only
+      // rows that miss walk the full claim/probe protocol.
+      uint64_t h[R];
+      int slot[R];
+      uint32_t s0[R];
+      uint64_t k0[R][KUT];
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        int64_t const r = base + k * B + threadIdx.x;
-        keep[k]         = r < end;
-        valvalid[k]     = 0xffffffffu;
-        if (keep[k]) {
-          if constexpr (INPUT == IN_COLUMNS) {
-            keep[k] = build_key_units<KUT, SIMPLE>(p, r, key[k], valvalid[k]);
-          } else if constexpr (EXACT && KUT == 1 && PAYT == 1) {
-            u64x2 const v = gload(reinterpret_cast<u64x2 const*>(records) + r);
-            key[k][0]          = v.x;
-            pay[k][0]          = v.y;
-          } else {
+        h[k]    = hash_of(key[k]);
+        slot[k] = static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(h[k])) * static_cast<uint32_t>(cap)) >> 32);
+        s0[k]   = __hip_atomic_load(&st[slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-            for (int u = 0; u < KUT; ++u) key[k][u] = (u < KU) ? gload(records + r * U + u) : 0;
-            if constexpr (PAYT > 0) {
-#pragma unroll
-              for (int v = 0; v < PAYT; ++v) pay[k][v] = gload(records + r * U + KU + v);
-            }
-            if (INPUT == IN_RAW_RECORDS && flags_unit >= 0)
-              valvalid[k] = gload(reinterpret_cast<uint32_t const*>(records + r * U + flags_unit) + flags_hi);
-          }
-        }
+        for (int u = 0; u < KUT; ++u) k0[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + slot[k])] : 0;
       }
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         if (!keep[k]) continue;
-        int64_t const r = base + k * B + threadIdx.x;
-        uint64_t h      = 0x9e3779b97f4a7c15ull;
+        bool hit = s0[k] == tag_of(h[k]);
 #pragma unroll
         for (int u = 0; u < KUT; ++u)
-          if (u < KU) h = mix64(h ^ (key[k][u] & kmask[u]));
-        int const slot = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h, &s_nfilled, fill_limit, &s_overflow);
-        if (slot < 0) continue;
-        int last_pay   = -1;
-        uint64_t value = 0;
-        for (int q = 0; q < NACC; ++q) {
-          uint32_t const dw = reinterpret_cast<uint32_t const*>(p.acc)[q];  // one scalar load
-          acc_desc d;
-          d.op        = static_cast<int8_t>(dw);
-          d.src       = static_cast<int8_t>(dw >> 8);
-          d.pay       = static_cast<int8_t>(dw >> 16);
-          d.valid_bit = static_cast<int8_t>(dw >> 24);
-          uint64_t* tgt = accs + static_cast<size_t>(q) * cap + slot;
-          if constexpr (INPUT == IN_PARTIAL_RECORDS) {
-            uint64_t v;
-            if constexpr (PAYT > 0) {
-              v = 0;
-#pragma unroll
-              for (int w = 0; w < PAYT; ++w)
-                if (q == w) v = pay[k][w];
-            } else {
-              v = gload(records + r * U + KU + q);
-            }
-            lds_merge(tgt, d.op, v);
-            continue;
-          }
-          if (d.src == SRC_ONE) {
-            lds_merge(tgt, ADD_I64, 1);
-            continue;
-          }
-          bool const valid = d.valid_bit < 0 || ((valvalid[k] >> d.valid_bit) & 1u);
-          if (!valid) continue;
-          if (d.src == SRC_ONE_IF_VALID) {
-            lds_merge(tgt, ADD_I64, 1);
-            continue;
-          }
-          if (d.pay != last_pay) {
-            if constexpr (INPUT == IN_COLUMNS) {
-              if constexpr (SIMPLE) value = gload(p.simple_base[KU + d.pay] + r);
-              else value = col_load_acc_bits(p.cols[p.nkeycols + d.pay], r);
-            } else if constexpr (PAYT > 0) {
-#pragma unroll
-              for (int w = 0; w < PAYT; ++w)
-                if (d.pay == w) value = pay[k][w];
-            } else {
-              value = gload(records + r * U + KU + d.pay);
-            }
-            last_pay = d.pay;
-          }
-          uint64_t v = value;
-          if (d.src == SRC_SQUARE) {
-            if (d.op == ADD_F64) {
-              double const x = __longlong_as_double(static_cast<long long>(v));
-              v              = static_cast<uint64_t>(__double_as_longlong(x * x));
-            } else {
-              v = v * v;
-            }
-          }
-          lds_merge(tgt, d.op, v);
-        }
+          if (u < KU) hit = hit && (k0[k][u] == (key[k][u] & kmask[u]));
+        int sl = slot[k];
+        if (!hit) sl = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
+        if (sl >= 0) accumulate(base + k * B + threadIdx.x, sl, pay[k], valvalid[k]);
       }
+    }
+    // tail
+    for (int64_t r = base + threadIdx.x; r < end; r += B) {
+      uint64_t key[KUT];
+      uint64_t pay[PAYT > 0 ? PAYT : 1];
+      uint32_t valvalid;
+      if (load_row(r, key, pay, valvalid)) process(r, key, pay, valvalid);
     }
   }
   __syncthreads();
@@ -838,19 +880,28 @@ void launch_partition_scatter(part_args const& a, part_args const* d_args, hipSt
   }
 }
 
-template <int INPUT, int KUT, int PAYT, bool SIMPLE, bool EXACT>
-static void launch_aggregate_t(agg_args const& a, agg_args* d_args, hipStream_t stream)
+template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT>
+static void launch_aggregate_n(agg_args const& a, agg_args* d_args, hipStream_t stream)
 {
   auto const lds = aggregate_lds_bytes(a.plan, a.geom);
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<INPUT, KUT, PAYT, SIMPLE, EXACT>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT>));
     attr_set = true;
   }
   hipLaunchKernelGGL(k_store_args<agg_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"aggregate", stream};
-  hipLaunchKernelGGL((k_aggregate<INPUT, KUT, PAYT, SIMPLE, EXACT>), dim3(a.nitems), dim3(a.geom.block), lds, stream, d_args);
+  hipLaunchKernelGGL((k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT>), dim3(a.nitems), dim3(a.geom.block), lds, stream,
+                     d_args);
   CUDF_HIP_TRY(hipGetLastError());
+}
+
+template <int INPUT, int KUT, int PAYT, bool SIMPLE, bool EXACT>
+static void launch_aggregate_t(agg_args const& a, agg_args* d_args, hipStream_t stream)
+{
+  if (a.plan.NACC <= 2) return launch_aggregate_n<INPUT, KUT, PAYT, 2, SIMPLE, EXACT>(a, d_args, stream);
+  if (a.plan.NACC <= 4) return launch_aggregate_n<INPUT, KUT, PAYT, 4, SIMPLE, EXACT>(a, d_args, stream);
+  return launch_aggregate_n<INPUT, KUT, PAYT, MAX_ACC, SIMPLE, EXACT>(a, d_args, stream);
 }
 
 template <int INPUT>
@@ -862,7 +913,6 @@ static void launch_aggregate_records(agg_args const& a, agg_args* d_args, hipStr
   if (KU == 1 && npay == 1) return launch_aggregate_t<INPUT, 1, 1, false, true>(a, d_args, stream);
   if (KU == 1 && npay == 2) return launch_aggregate_t<INPUT, 1, 2, false, true>(a, d_args, stream);
   if (KU == 2 && npay == 1) return launch_aggregate_t<INPUT, 2, 1, false, true>(a, d_args, stream);
-  if (KU == 2 && npay == 2) return launch_aggregate_t<INPUT, 2, 2, false, true>(a, d_args, stream);
   if (KU == 2 && npay == 4) return launch_aggregate_t<INPUT, 2, 4, false, true>(a, d_args, stream);
   if (KU <= 1) return launch_aggregate_t<INPUT, 1, 0, false, false>(a, d_args, stream);
   if (KU <= 2) return launch_aggregate_t<INPUT, 2, 0, false, false>(a, d_args, stream);
