@@ -37,6 +37,14 @@ SYMBOLS = {
     "cudf_amd_groupby_aggregate": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.c_int32, C.c_int32,
                                              C.POINTER(AggregationRequest), C.c_int32, _P, C.POINTER(_P),
                                              C.POINTER(_P), C.POINTER(C.c_int32)]),
+    "cudf_amd_join": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.POINTER(ColumnView), C.c_int32, C.c_int32, C.c_int32,
+                                _P, C.POINTER(_P)]),
+    "cudf_amd_hash_join_create": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.c_int32, C.c_int32, C.c_double, _P,
+                                            C.POINTER(_P)]),
+    "cudf_amd_hash_join_destroy": (None, [_P]),
+    "cudf_amd_hash_join_probe": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.c_int32, C.c_int64, _P,
+                                           C.POINTER(_P)]),
+    "cudf_amd_hash_join_size": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.c_int32, _P, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

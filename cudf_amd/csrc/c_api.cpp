@@ -6,17 +6,23 @@
 #include "common/profiler.hpp"
 
 #include <cudf/groupby.hpp>
+#include <cudf/join/hash_join.hpp>
+#include <cudf/join/join.hpp>
 #include <cudf/table/table.hpp>
 #include <cudf/utilities/error.hpp>
 
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <optional>
 #include <string>
 #include <vector>
 
 struct cudf_amd_table_s {
   std::vector<std::unique_ptr<cudf::column>> cols;
+};
+struct cudf_amd_hash_join_s {
+  std::unique_ptr<cudf::hash_join> hj;
 };
 
 namespace {
@@ -212,6 +218,75 @@ cudf_amd_status cudf_amd_groupby_aggregate(const cudf_amd_column_view* keys, int
     if (out_path) *out_path = static_cast<int32_t>(gb.last_path());
     *out_keys    = kh.release();
     *out_results = rh.release();
+  });
+}
+
+static cudf_amd_table_t indices_to_table(cudf::join_index_pair&& p)
+{
+  auto t = std::make_unique<cudf_amd_table_s>();
+  t->cols.push_back(std::make_unique<cudf::column>(std::move(*p.first), rmm::device_buffer{}, 0));
+  t->cols.push_back(std::make_unique<cudf::column>(std::move(*p.second), rmm::device_buffer{}, 0));
+  return t.release();
+}
+
+cudf_amd_status cudf_amd_join(const cudf_amd_column_view* left_keys, int32_t num_left,
+                              const cudf_amd_column_view* right_keys, int32_t num_right, int32_t nulls_equal,
+                              int32_t kind, void* stream, cudf_amd_table_t* out_indices)
+{
+  return guarded([&] {
+    *out_indices  = nullptr;
+    auto const l  = to_table(left_keys, num_left);
+    auto const r  = to_table(right_keys, num_right);
+    auto const eq = nulls_equal ? cudf::null_equality::EQUAL : cudf::null_equality::UNEQUAL;
+    cudf::stream_ref const s{as_stream(stream)};
+    CUDF_EXPECTS(kind >= 0 && kind <= 2, "join kind must be 0 (inner), 1 (left) or 2 (full)", std::invalid_argument);
+    auto p = kind == 0 ? cudf::inner_join(l, r, eq, s) : kind == 1 ? cudf::left_join(l, r, eq, s) : cudf::full_join(l, r, eq, s);
+    *out_indices = indices_to_table(std::move(p));
+  });
+}
+
+cudf_amd_status cudf_amd_hash_join_create(const cudf_amd_column_view* right_keys, int32_t num_right, int32_t has_nulls,
+                                          int32_t nulls_equal, double load_factor, void* stream,
+                                          cudf_amd_hash_join_t* out)
+{
+  return guarded([&] {
+    *out          = nullptr;
+    auto const r  = to_table(right_keys, num_right);
+    auto const eq = nulls_equal ? cudf::null_equality::EQUAL : cudf::null_equality::UNEQUAL;
+    cudf::stream_ref const s{as_stream(stream)};
+    auto h = std::make_unique<cudf_amd_hash_join_s>();
+    if (has_nulls < 0) h->hj = std::make_unique<cudf::hash_join>(r, eq, s);
+    else h->hj = std::make_unique<cudf::hash_join>(r, has_nulls ? cudf::nullable_join::YES : cudf::nullable_join::NO, eq, load_factor, s);
+    *out = h.release();
+  });
+}
+void cudf_amd_hash_join_destroy(cudf_amd_hash_join_t h) { delete h; }
+
+cudf_amd_status cudf_amd_hash_join_probe(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys, int32_t num_left,
+                                         int32_t kind, int64_t output_size, void* stream, cudf_amd_table_t* out_indices)
+{
+  return guarded([&] {
+    *out_indices = nullptr;
+    CUDF_EXPECTS(h != nullptr && h->hj != nullptr, "null hash_join handle", std::invalid_argument);
+    auto const l = to_table(left_keys, num_left);
+    cudf::stream_ref const s{as_stream(stream)};
+    std::optional<std::size_t> sz;
+    if (output_size >= 0) sz = static_cast<std::size_t>(output_size);
+    CUDF_EXPECTS(kind >= 0 && kind <= 2, "join kind must be 0 (inner), 1 (left) or 2 (full)", std::invalid_argument);
+    auto p = kind == 0 ? h->hj->inner_join(l, sz, s) : kind == 1 ? h->hj->left_join(l, sz, s) : h->hj->full_join(l, sz, s);
+    *out_indices = indices_to_table(std::move(p));
+  });
+}
+
+cudf_amd_status cudf_amd_hash_join_size(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys, int32_t num_left,
+                                        int32_t kind, void* stream, uint64_t* out_size)
+{
+  return guarded([&] {
+    CUDF_EXPECTS(h != nullptr && h->hj != nullptr, "null hash_join handle", std::invalid_argument);
+    auto const l = to_table(left_keys, num_left);
+    cudf::stream_ref const s{as_stream(stream)};
+    CUDF_EXPECTS(kind >= 0 && kind <= 2, "join kind must be 0 (inner), 1 (left) or 2 (full)", std::invalid_argument);
+    *out_size = kind == 0 ? h->hj->inner_join_size(l, s) : kind == 1 ? h->hj->left_join_size(l, s) : h->hj->full_join_size(l, s);
   });
 }
 }  // extern "C"

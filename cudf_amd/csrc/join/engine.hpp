@@ -1,0 +1,42 @@
+// SPDX-License-Identifier: Apache-2.0
+// Hash-join engine for MI355X: open-addressing multiset of {32-bit hash tag, build row} packed in one 64-bit
+// slot, linear probing, built with global 64-bit CAS (27 G CAS/s measured, profiles/microbench_r1.txt) and
+// probed with 64-lane wave-aggregated output allocation (one global atomic per wave and round instead of the
+// reference's 32-lane ballot + per-warp LDS staging buffer, partitioned_retrieve_kernels.cuh:57-211).
+// Replaces cuco::static_multiset<pair<u32,i32>> with double hashing / CG 2 / bucket 2
+// (cpp/src/join/hash_join/hash_join_impl.cuh:17-60, hash_join.cu:62-149, retrieve_impl.cuh:29-133,
+// size_impl.cuh:26-61).
+#pragma once
+#include "../common/device_table.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace cudf::detail::join {
+
+constexpr uint64_t EMPTY_SLOT = ~uint64_t{0};
+
+struct join_args {
+  device_table build;
+  device_table probe;
+  uint64_t* table;         // capacity slots
+  uint64_t capacity;
+  int32_t nulls_equal;     // null_equality::EQUAL
+  int32_t check_nulls;     // some key column (either side) has nulls
+  int32_t kind;            // 0 inner, 1 left, 2 full
+  int32_t single64;        // fast path: one 8-byte integer key column, no nulls on either side
+  // outputs
+  unsigned long long* total;   // match-pair counter (count pass) / output cursor (retrieve pass)
+  size_type* out_probe;        // probe-side row of each pair
+  size_type* out_build;        // build-side row of each pair (JoinNoMatch for unmatched probe rows)
+  uint64_t out_capacity;       // pairs that fit in out_probe/out_build
+  uint8_t* build_matched;      // full join: build rows seen by some probe row
+};
+
+void launch_build(join_args const& a, join_args* d_args, hipStream_t stream);
+void launch_count(join_args const& a, join_args* d_args, hipStream_t stream);
+void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream);
+// full join: appends (JoinNoMatch, r) for every build row with build_matched[r] == 0
+void launch_complement(join_args const& a, join_args* d_args, hipStream_t stream);
+
+}  // namespace cudf::detail::join

@@ -1,0 +1,333 @@
+// SPDX-License-Identifier: Apache-2.0
+// Host side of cudf::hash_join and cudf::inner_join / left_join / full_join.
+// Reference counterparts: cpp/src/join/join.cu:30-118 (build on the smaller side, swap results),
+// cpp/src/join/hash_join/hash_join.cu:32-59 (is_trivial_join, validate_hash_join_probe), :113-149 (ctor/build),
+// retrieve_impl.cuh:169-222 (probe entry), size_impl.cuh:26-61 (size), join_utils.cu:45-221 (trivial left join,
+// full-join complement), join_common_utils.hpp:25-32 (load-factor check).
+#include "engine.hpp"
+
+#include <cudf/join/hash_join.hpp>
+#include <cudf/join/join.hpp>
+#include <cudf/utilities/error.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+
+namespace cudf {
+namespace detail {
+
+using join::join_args;
+
+namespace {
+double checked_load_factor(double load_factor)
+{
+  CUDF_EXPECTS(load_factor > 0, "Invalid load factor: must be greater than 0.", std::invalid_argument);
+  CUDF_EXPECTS(load_factor <= 1, "Invalid load factor: must be less than or equal to 1.", std::invalid_argument);
+  return load_factor;
+}
+
+bool is_trivial_join(table_view const& left, table_view const& right, join_kind kind)
+{
+  if (left.is_empty() || right.is_empty()) return true;
+  if (kind == join_kind::LEFT_JOIN && left.num_rows() == 0) return true;
+  if (kind == join_kind::INNER_JOIN && (left.num_rows() == 0 || right.num_rows() == 0)) return true;
+  return false;
+}
+
+bool same_types(table_view const& a, table_view const& b)
+{
+  if (a.num_columns() != b.num_columns()) return false;
+  for (size_type i = 0; i < a.num_columns(); ++i)
+    if (a.column(i).type() != b.column(i).type()) return false;
+  return true;
+}
+
+bool is_single64(table_view const& t)
+{
+  if (t.num_columns() != 1 || t.column(0).has_nulls()) return false;
+  auto const id  = t.column(0).type().id();
+  auto const cls = class_of(id);
+  return size_of_id(id) == 8 && (cls == CLS_SINT || cls == CLS_UINT);
+}
+
+template <typename T>
+struct dev_scalar {  // one T in device memory, stream ordered
+  rmm::device_buffer buf;
+  hipStream_t s;
+  dev_scalar(T init, hipStream_t stream) : buf{sizeof(T), stream, cudf::get_current_device_resource_ref()}, s{stream}
+  {
+    static_assert(sizeof(T) <= 8);
+    T host = init;
+    CUDF_HIP_TRY(hipMemcpyAsync(buf.data(), &host, sizeof(T), hipMemcpyHostToDevice, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+  }
+  T* ptr() { return static_cast<T*>(buf.data()); }
+  T value()
+  {
+    T host{};
+    CUDF_HIP_TRY(hipMemcpyAsync(&host, buf.data(), sizeof(T), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    return host;
+  }
+};
+}  // namespace
+
+class hash_join_impl {
+ public:
+  hash_join_impl(table_view const& right, bool has_nulls, null_equality compare_nulls, double load_factor,
+                 stream_ref stream, rmm::device_async_resource_ref mr)
+    : _right{right}, _has_nulls{has_nulls}, _nulls_equal{compare_nulls}, _is_empty{right.num_rows() == 0}
+  {
+    CUDF_EXPECTS(0 != right.num_columns(), "Hash join right table is empty", std::invalid_argument);
+    load_factor = checked_load_factor(load_factor);
+    if (_is_empty) return;
+    _build_dev        = make_device_table(right);
+    auto const rows   = static_cast<uint64_t>(right.num_rows());
+    uint64_t capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / load_factor));
+    capacity          = std::clamp<uint64_t>(capacity, rows + 1, (uint64_t{1} << 32) - 1);  // always one empty slot
+    _capacity         = capacity;
+    _table            = rmm::device_buffer{capacity * sizeof(uint64_t), stream.value(), mr};
+    CUDF_HIP_TRY(hipMemsetAsync(_table.data(), 0xff, capacity * sizeof(uint64_t), stream.value()));
+    join_args a = base_args(right, 0);
+    rmm::device_buffer d_args{sizeof(join_args), stream.value(), cudf::get_current_device_resource_ref()};
+    join::launch_build(a, static_cast<join_args*>(d_args.data()), stream.value());
+    CUDF_HIP_TRY(hipStreamSynchronize(stream.value()));  // d_args goes out of scope; build is done for probes on any stream
+  }
+
+  [[nodiscard]] std::size_t join_size(table_view const& left, join_kind kind, stream_ref stream,
+                                      std::vector<uint8_t>* /*unused*/ = nullptr) const
+  {
+    validate_probe(left);
+    if (kind == join_kind::INNER_JOIN) {
+      if (is_trivial_join(left, _right, kind)) return 0;
+    } else {
+      if (_is_empty) return kind == join_kind::FULL_JOIN ? left.num_rows() : left.num_rows();
+      if (is_trivial_join(left, _right, kind)) return kind == join_kind::FULL_JOIN ? _right.num_rows() : 0;
+    }
+    if (kind == join_kind::FULL_JOIN) {
+      // needs the matched set of the build side: run the real join and take its size
+      auto r = probe(left, kind, std::nullopt, stream, cudf::get_current_device_resource_ref());
+      return r.first->size();
+    }
+    join_args a = base_args(left, kind == join_kind::INNER_JOIN ? 0 : 1);
+    dev_scalar<unsigned long long> total{0, stream.value()};
+    a.total = total.ptr();
+    rmm::device_buffer d_args{sizeof(join_args), stream.value(), cudf::get_current_device_resource_ref()};
+    join::launch_count(a, static_cast<join_args*>(d_args.data()), stream.value());
+    return static_cast<std::size_t>(total.value());
+  }
+
+  [[nodiscard]] join_index_pair probe(table_view const& left, join_kind kind, std::optional<std::size_t> output_size,
+                                      stream_ref stream, rmm::device_async_resource_ref mr) const
+  {
+    validate_probe(left);
+    auto empty_pair = [&] {
+      return join_index_pair{std::make_unique<rmm::device_uvector<size_type>>(0, stream.value(), mr),
+                             std::make_unique<rmm::device_uvector<size_type>>(0, stream.value(), mr)};
+    };
+    if (kind == join_kind::INNER_JOIN) {
+      if (is_trivial_join(left, _right, kind)) return empty_pair();
+    } else {
+      if (_is_empty) return trivial_left(left, stream, mr);
+      if (is_trivial_join(left, _right, kind)) {
+        // left side has no rows: a full join still returns every right row unmatched
+        if (kind == join_kind::FULL_JOIN && !left.is_empty() && _right.num_rows() > 0) return trivial_right(stream, mr);
+        return empty_pair();
+      }
+    }
+    int const k = kind == join_kind::INNER_JOIN ? 0 : kind == join_kind::LEFT_JOIN ? 1 : 2;
+    hipStream_t const s = stream.value();
+    rmm::device_buffer d_args{sizeof(join_args), s, cudf::get_current_device_resource_ref()};
+    // ---- size: given, or counted with one probe pass (reference: compute_join_output_size, size_impl.cuh:26-61)
+    std::size_t pairs = 0;
+    if (output_size.has_value() && kind != join_kind::FULL_JOIN) {
+      pairs = *output_size;
+    } else {
+      join_args c = base_args(left, k == 0 ? 0 : 1);
+      dev_scalar<unsigned long long> total{0, s};
+      c.total = total.ptr();
+      join::launch_count(c, static_cast<join_args*>(d_args.data()), s);
+      pairs = static_cast<std::size_t>(total.value());
+    }
+    std::size_t const complement_room = kind == join_kind::FULL_JOIN ? static_cast<std::size_t>(_right.num_rows()) : 0;
+    std::size_t const room            = pairs + complement_room;
+    CUDF_EXPECTS(room <= static_cast<std::size_t>(std::numeric_limits<size_type>::max()),
+                 "Join result exceeds the maximum column size; use the *_join_size API and chunk the probe side.",
+                 std::overflow_error);
+    auto out_l = std::make_unique<rmm::device_uvector<size_type>>(room, s, mr);
+    auto out_r = std::make_unique<rmm::device_uvector<size_type>>(room, s, mr);
+    join_args a = base_args(left, k);
+    dev_scalar<unsigned long long> cursor{0, s};
+    a.total        = cursor.ptr();
+    a.out_probe    = out_l->data();
+    a.out_build    = out_r->data();
+    a.out_capacity = room;
+    rmm::device_buffer matched{};
+    if (kind == join_kind::FULL_JOIN) {
+      matched = rmm::device_buffer{static_cast<std::size_t>(_right.num_rows()), s, cudf::get_current_device_resource_ref()};
+      CUDF_HIP_TRY(hipMemsetAsync(matched.data(), 0, matched.size(), s));
+      a.build_matched = static_cast<uint8_t*>(matched.data());
+    }
+    join::launch_retrieve(a, static_cast<join_args*>(d_args.data()), s);
+    if (kind == join_kind::FULL_JOIN) {
+      rmm::device_buffer d_args2{sizeof(join_args), s, cudf::get_current_device_resource_ref()};
+      join::launch_complement(a, static_cast<join_args*>(d_args2.data()), s);
+      std::size_t const total = static_cast<std::size_t>(cursor.value());
+      if (total != room) {  // exact-size outputs
+        auto l2 = std::make_unique<rmm::device_uvector<size_type>>(total, s, mr);
+        auto r2 = std::make_unique<rmm::device_uvector<size_type>>(total, s, mr);
+        CUDF_HIP_TRY(hipMemcpyAsync(l2->data(), out_l->data(), total * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+        CUDF_HIP_TRY(hipMemcpyAsync(r2->data(), out_r->data(), total * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+        CUDF_HIP_TRY(hipStreamSynchronize(s));
+        return {std::move(l2), std::move(r2)};
+      }
+      return {std::move(out_l), std::move(out_r)};
+    }
+    std::size_t const written = static_cast<std::size_t>(cursor.value());  // also orders d_args' lifetime
+    CUDF_EXPECTS(written == pairs, "hash join: output_size does not match the number of matches", std::invalid_argument);
+    return {std::move(out_l), std::move(out_r)};
+  }
+
+ private:
+  void validate_probe(table_view const& left) const
+  {
+    // reference validate_hash_join_probe, hash_join.cu:47-59
+    CUDF_EXPECTS(0 != left.num_columns(), "Hash join left table is empty", std::invalid_argument);
+    CUDF_EXPECTS(_right.num_columns() == left.num_columns(), "Mismatch in number of columns to be joined on",
+                 std::invalid_argument);
+    CUDF_EXPECTS(_has_nulls || !cudf::has_nulls(left),
+                 "Left table has nulls while right table was not hashed with null check.", std::invalid_argument);
+    CUDF_EXPECTS(same_types(_right, left), "Mismatch in joining column data types", cudf::data_type_error);
+  }
+
+  join_args base_args(table_view const& probe, int kind) const
+  {
+    join_args a{};
+    a.build       = _build_dev;
+    a.probe       = make_device_table(probe);
+    a.table       = const_cast<uint64_t*>(static_cast<uint64_t const*>(_table.data()));
+    a.capacity    = _capacity;
+    a.nulls_equal = _nulls_equal == null_equality::EQUAL;
+    a.check_nulls = _has_nulls && (cudf::has_nulls(_right) || cudf::has_nulls(probe));
+    a.kind        = kind;
+    a.single64    = !a.check_nulls && is_single64(_right) && is_single64(probe);
+    return a;
+  }
+
+  // right side empty: every left row pairs with JoinNoMatch (reference get_trivial_left_join_indices)
+  static join_index_pair trivial_left(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr)
+  {
+    auto const n = static_cast<std::size_t>(left.num_rows());
+    std::vector<size_type> l(n), r(n, JoinNoMatch);
+    for (std::size_t i = 0; i < n; ++i) l[i] = static_cast<size_type>(i);
+    auto out_l = std::make_unique<rmm::device_uvector<size_type>>(n, stream.value(), mr);
+    auto out_r = std::make_unique<rmm::device_uvector<size_type>>(n, stream.value(), mr);
+    if (n) {
+      CUDF_HIP_TRY(hipMemcpyAsync(out_l->data(), l.data(), n * sizeof(size_type), hipMemcpyHostToDevice, stream.value()));
+      CUDF_HIP_TRY(hipMemcpyAsync(out_r->data(), r.data(), n * sizeof(size_type), hipMemcpyHostToDevice, stream.value()));
+      CUDF_HIP_TRY(hipStreamSynchronize(stream.value()));
+    }
+    return {std::move(out_l), std::move(out_r)};
+  }
+  join_index_pair trivial_right(stream_ref stream, rmm::device_async_resource_ref mr) const
+  {
+    auto const n = static_cast<std::size_t>(_right.num_rows());
+    std::vector<size_type> l(n, JoinNoMatch), r(n);
+    for (std::size_t i = 0; i < n; ++i) r[i] = static_cast<size_type>(i);
+    auto out_l = std::make_unique<rmm::device_uvector<size_type>>(n, stream.value(), mr);
+    auto out_r = std::make_unique<rmm::device_uvector<size_type>>(n, stream.value(), mr);
+    if (n) {
+      CUDF_HIP_TRY(hipMemcpyAsync(out_l->data(), l.data(), n * sizeof(size_type), hipMemcpyHostToDevice, stream.value()));
+      CUDF_HIP_TRY(hipMemcpyAsync(out_r->data(), r.data(), n * sizeof(size_type), hipMemcpyHostToDevice, stream.value()));
+      CUDF_HIP_TRY(hipStreamSynchronize(stream.value()));
+    }
+    return {std::move(out_l), std::move(out_r)};
+  }
+
+  table_view _right;
+  bool _has_nulls;
+  null_equality _nulls_equal;
+  bool _is_empty;
+  device_table _build_dev{};
+  uint64_t _capacity{0};
+  rmm::device_buffer _table{};
+};
+}  // namespace detail
+
+// ---------------------------------------------------------------- cudf::hash_join
+hash_join::~hash_join() = default;
+
+hash_join::hash_join(table_view const& right, null_equality compare_nulls, stream_ref stream,
+                     rmm::device_async_resource_ref mr)
+  // If we cannot know beforehand about null existence then let's assume that there are nulls (reference hash_join.cu:190-199)
+  : hash_join{right, nullable_join::YES, compare_nulls, 0.5, stream, mr}
+{
+}
+
+hash_join::hash_join(table_view const& right, nullable_join has_nulls, null_equality compare_nulls, double load_factor,
+                     stream_ref stream, rmm::device_async_resource_ref mr)
+  : _impl{std::make_unique<detail::hash_join_impl const>(right, has_nulls == nullable_join::YES, compare_nulls, load_factor,
+                                                         stream, mr)}
+{
+}
+
+join_index_pair hash_join::inner_join(table_view const& left, std::optional<std::size_t> output_size, stream_ref stream,
+                                      rmm::device_async_resource_ref mr) const
+{
+  return _impl->probe(left, join_kind::INNER_JOIN, output_size, stream, mr);
+}
+join_index_pair hash_join::left_join(table_view const& left, std::optional<std::size_t> output_size, stream_ref stream,
+                                     rmm::device_async_resource_ref mr) const
+{
+  return _impl->probe(left, join_kind::LEFT_JOIN, output_size, stream, mr);
+}
+join_index_pair hash_join::full_join(table_view const& left, std::optional<std::size_t> output_size, stream_ref stream,
+                                     rmm::device_async_resource_ref mr) const
+{
+  return _impl->probe(left, join_kind::FULL_JOIN, output_size, stream, mr);
+}
+std::size_t hash_join::inner_join_size(table_view const& left, stream_ref stream) const
+{
+  return _impl->join_size(left, join_kind::INNER_JOIN, stream);
+}
+std::size_t hash_join::left_join_size(table_view const& left, stream_ref stream) const
+{
+  return _impl->join_size(left, join_kind::LEFT_JOIN, stream);
+}
+std::size_t hash_join::full_join_size(table_view const& left, stream_ref stream, rmm::device_async_resource_ref) const
+{
+  return _impl->join_size(left, join_kind::FULL_JOIN, stream);
+}
+
+// ---------------------------------------------------------------- free functions
+join_index_pair inner_join(table_view const& left, table_view const& right, null_equality compare_nulls, stream_ref stream,
+                           rmm::device_async_resource_ref mr)
+{
+  auto const has_nulls = (cudf::has_nulls(left) || cudf::has_nulls(right)) ? nullable_join::YES : nullable_join::NO;
+  // build on the smaller table; ties build on right (reference join.cu:50-57)
+  if (right.num_rows() > left.num_rows()) {
+    hash_join hj{left, has_nulls, compare_nulls, 0.5, stream};
+    auto [right_result, left_result] = hj.inner_join(right, std::nullopt, stream, mr);
+    return {std::move(left_result), std::move(right_result)};
+  }
+  hash_join hj{right, has_nulls, compare_nulls, 0.5, stream};
+  return hj.inner_join(left, std::nullopt, stream, mr);
+}
+
+join_index_pair left_join(table_view const& left, table_view const& right, null_equality compare_nulls, stream_ref stream,
+                          rmm::device_async_resource_ref mr)
+{
+  auto const has_nulls = (cudf::has_nulls(left) || cudf::has_nulls(right)) ? nullable_join::YES : nullable_join::NO;
+  hash_join hj{right, has_nulls, compare_nulls, 0.5, stream};
+  return hj.left_join(left, std::nullopt, stream, mr);
+}
+
+join_index_pair full_join(table_view const& left, table_view const& right, null_equality compare_nulls, stream_ref stream,
+                          rmm::device_async_resource_ref mr)
+{
+  auto const has_nulls = (cudf::has_nulls(left) || cudf::has_nulls(right)) ? nullable_join::YES : nullable_join::NO;
+  hash_join hj{right, has_nulls, compare_nulls, 0.5, stream};
+  return hj.full_join(left, std::nullopt, stream, mr);
+}
+}  // namespace cudf

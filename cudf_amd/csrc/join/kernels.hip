@@ -1,0 +1,243 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 kernels of the hash-join engine (see engine.hpp).
+#include "engine.hpp"
+#include "../common/profiler.hpp"
+
+#include <cudf/join/join.hpp>
+#include <cudf/utilities/error.hpp>
+
+namespace cudf::detail::join {
+namespace {
+
+template <typename T>
+__global__ void k_store_args(T v, T* dst)
+{
+  *dst = v;
+}
+
+// 64-bit row hash of the join keys (the engine's own; results do not depend on it). A NULL element hashes
+// to a constant so that NULL == NULL rows meet under null_equality::EQUAL.
+__device__ __forceinline__ uint64_t join_row_hash(device_table const& t, int64_t i, bool check_nulls)
+{
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+  for (int c = 0; c < t.ncols; ++c) {
+    uint64_t bits = 0x6a09e667f3bcc909ull;
+    if (!check_nulls || col_is_valid(t.col[c], i)) bits = normalize_key_bits(col_load_bits(t.col[c], i), t.col[c].cls);
+    h = mix64(h ^ bits);
+  }
+  return h;
+}
+__device__ __forceinline__ uint64_t hash64_single(uint64_t key) { return mix64(0x9e3779b97f4a7c15ull ^ key); }
+
+__device__ __forceinline__ uint64_t home_slot(uint64_t h, uint64_t capacity)
+{
+  return (static_cast<uint64_t>(static_cast<uint32_t>(h)) * capacity) >> 32;  // capacity < 2^32
+}
+__device__ __forceinline__ uint64_t make_entry(uint64_t h, int64_t row)
+{
+  return ((h >> 32) << 32) | static_cast<uint32_t>(row);
+}
+
+// ------------------------------------------------------------------ build
+template <bool SINGLE64>
+__global__ void __launch_bounds__(256) k_build(join_args const* __restrict__ ap)
+{
+  join_args const& a = *ap;
+  int64_t const n      = a.build.nrows;
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint64_t const cap   = a.capacity;
+  uint64_t const* keys = SINGLE64 ? static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset : nullptr;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+    uint64_t h;
+    if constexpr (SINGLE64) {
+      h = hash64_single(gload(keys + i));
+    } else {
+      // null_equality::UNEQUAL: rows containing a NULL can never match and are not inserted
+      // (reference hash_join.cu:77-84, join_common_utils.cuh:36-47)
+      if (a.check_nulls && !a.nulls_equal && row_has_null(a.build, i)) continue;
+      h = join_row_hash(a.build, i, a.check_nulls);
+    }
+    uint64_t const entry = make_entry(h, i);
+    uint64_t slot        = home_slot(h, cap);
+    for (;;) {
+      unsigned long long const old =
+        atomicCAS(reinterpret_cast<unsigned long long*>(a.table + slot), EMPTY_SLOT, static_cast<unsigned long long>(entry));
+      if (old == EMPTY_SLOT) break;
+      slot = slot + 1 == cap ? 0 : slot + 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ probe (count / retrieve)
+// MODE 0: count pairs. MODE 1: write pairs. One probe row per lane; per probing round the lanes that found a
+// match get consecutive output slots from ONE wave-level atomic (64-lane ballot + mbcnt prefix).
+template <int MODE, bool SINGLE64>
+__global__ void __launch_bounds__(256) k_probe(join_args const* __restrict__ ap)
+{
+  join_args const& a = *ap;
+  int64_t const n      = a.probe.nrows;
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint64_t const cap   = a.capacity;
+  int const kind       = a.kind;
+  uint64_t const* pkeys = SINGLE64 ? static_cast<uint64_t const*>(a.probe.col[0].head) + a.probe.col[0].offset : nullptr;
+  uint64_t const* bkeys = SINGLE64 ? static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset : nullptr;
+  unsigned long long local_count = 0;
+  int64_t const first = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  // all lanes of a wave iterate together (the wave-level allocation needs every lane at the ballots)
+  int64_t const n_round = ((n + stride - 1) / stride) * stride;
+  for (int64_t j0 = first; j0 < n_round; j0 += stride) {
+    int64_t const j = j0;
+    bool active     = j < n;
+    uint64_t h = 0, pkey = 0;
+    if (active) {
+      if constexpr (SINGLE64) {
+        pkey = gload(pkeys + j);
+        h    = hash64_single(pkey);
+      } else {
+        if (a.check_nulls && !a.nulls_equal && row_has_null(a.probe, j)) {
+          active = false;  // matches nothing; still emitted once for left/full joins below
+        } else {
+          h = join_row_hash(a.probe, j, a.check_nulls);
+        }
+      }
+    }
+    bool const row_live = j < n;
+    uint64_t slot       = active ? home_slot(h, cap) : 0;
+    uint32_t const tag  = static_cast<uint32_t>(h >> 32);
+    bool found_any      = false;
+    bool walking        = active;
+    while (__any(walking)) {
+      bool match       = false;
+      size_type brow   = 0;
+      if (walking) {
+        uint64_t const e = gload(a.table + slot);
+        if (e == EMPTY_SLOT) {
+          walking = false;
+        } else {
+          if (static_cast<uint32_t>(e >> 32) == tag) {
+            brow = static_cast<size_type>(static_cast<uint32_t>(e));
+            if constexpr (SINGLE64) match = gload(bkeys + brow) == pkey;
+            else match = rows_equal(a.probe, j, a.build, brow, a.nulls_equal != 0);
+          }
+          slot = slot + 1 == cap ? 0 : slot + 1;
+        }
+      }
+      if (match) found_any = true;
+      if constexpr (MODE == 0) {
+        local_count += match ? 1 : 0;
+      } else {
+        unsigned long long const ballot = __ballot(match);
+        if (ballot != 0) {
+          int const lane     = threadIdx.x & 63;
+          int const rank     = __popcll(ballot & ((1ull << lane) - 1));
+          unsigned long long base = 0;
+          if (lane == __ffsll(static_cast<long long>(ballot)) - 1) base = atomicAdd(a.total, static_cast<unsigned long long>(__popcll(ballot)));
+          base = __shfl(base, __ffsll(static_cast<long long>(ballot)) - 1);
+          if (match) {
+            uint64_t const o = base + rank;
+            if (o < a.out_capacity) {
+              gstore(a.out_probe + o, static_cast<size_type>(j));
+              gstore(a.out_build + o, brow);
+            }
+            if (kind == 2) gstore(a.build_matched + brow, uint8_t{1});
+          }
+        }
+      }
+    }
+    // left / full join: probe rows without a match are emitted once with JoinNoMatch
+    if (kind != 0) {
+      bool const lonely = row_live && !found_any;
+      if constexpr (MODE == 0) {
+        local_count += lonely ? 1 : 0;
+      } else {
+        unsigned long long const ballot = __ballot(lonely);
+        if (ballot != 0) {
+          int const lane = threadIdx.x & 63;
+          int const rank = __popcll(ballot & ((1ull << lane) - 1));
+          int const lead = __ffsll(static_cast<long long>(ballot)) - 1;
+          unsigned long long base = 0;
+          if (lane == lead) base = atomicAdd(a.total, static_cast<unsigned long long>(__popcll(ballot)));
+          base = __shfl(base, lead);
+          if (lonely) {
+            uint64_t const o = base + rank;
+            if (o < a.out_capacity) {
+              gstore(a.out_probe + o, static_cast<size_type>(j));
+              gstore(a.out_build + o, JoinNoMatch);
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 0) {
+    for (int o = 32; o > 0; o >>= 1) local_count += __shfl_down(local_count, o);
+    if ((threadIdx.x & 63) == 0 && local_count) atomicAdd(a.total, local_count);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_complement(join_args const* __restrict__ ap)
+{
+  join_args const& a   = *ap;
+  int64_t const n      = a.build.nrows;
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  int64_t const first  = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  int64_t const n_round = ((n + stride - 1) / stride) * stride;
+  for (int64_t r = first; r < n_round; r += stride) {
+    bool const lonely = r < n && a.build_matched[r] == 0;
+    unsigned long long const ballot = __ballot(lonely);
+    if (ballot == 0) continue;
+    int const lane = threadIdx.x & 63;
+    int const rank = __popcll(ballot & ((1ull << lane) - 1));
+    int const lead = __ffsll(static_cast<long long>(ballot)) - 1;
+    unsigned long long base = 0;
+    if (lane == lead) base = atomicAdd(a.total, static_cast<unsigned long long>(__popcll(ballot)));
+    base = __shfl(base, lead);
+    if (lonely) {
+      uint64_t const o = base + rank;
+      if (o < a.out_capacity) {
+        gstore(a.out_probe + o, JoinNoMatch);
+        gstore(a.out_build + o, static_cast<size_type>(r));
+      }
+    }
+  }
+}
+
+unsigned grid_for(int64_t n)
+{
+  int64_t const blocks = (n + 255) / 256;
+  return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(blocks, 256 * 16)));
+}
+}  // namespace
+
+void launch_build(join_args const& a, join_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_build", stream};
+  if (a.single64) hipLaunchKernelGGL(k_build<true>, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args);
+  else hipLaunchKernelGGL(k_build<false>, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+void launch_count(join_args const& a, join_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_count", stream};
+  if (a.single64) hipLaunchKernelGGL((k_probe<0, true>), dim3(grid_for(a.probe.nrows)), dim3(256), 0, stream, d_args);
+  else hipLaunchKernelGGL((k_probe<0, false>), dim3(grid_for(a.probe.nrows)), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_retrieve", stream};
+  if (a.single64) hipLaunchKernelGGL((k_probe<1, true>), dim3(grid_for(a.probe.nrows)), dim3(256), 0, stream, d_args);
+  else hipLaunchKernelGGL((k_probe<1, false>), dim3(grid_for(a.probe.nrows)), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+void launch_complement(join_args const& a, join_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_complement", stream};
+  hipLaunchKernelGGL(k_complement, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+}  // namespace cudf::detail::join

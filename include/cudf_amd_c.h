@@ -94,6 +94,29 @@ cudf_amd_status cudf_amd_groupby_aggregate(const cudf_amd_column_view* keys, int
                                            void* stream, cudf_amd_table_t* out_keys, cudf_amd_table_t* out_results,
                                            int32_t* out_path);
 
+/* ---- cudf::inner_join / left_join / full_join(left_keys, right_keys, compare_nulls, stream, mr)
+ * (reference cpp/include/cudf/join/join.hpp:160-166 and the left/full overloads; src/join/join.cu:30-118).
+ * nulls_equal: 1 = null_equality::EQUAL, 0 = UNEQUAL. kind: 0 inner, 1 left, 2 full.
+ * out_indices: table of two INT32 columns {left_indices, right_indices}; unmatched side = JoinNoMatch (INT32_MIN).
+ * pylibcudf wraps the two device_uvectors into columns the same way (join.pyx:51-64). */
+cudf_amd_status cudf_amd_join(const cudf_amd_column_view* left_keys, int32_t num_left,
+                              const cudf_amd_column_view* right_keys, int32_t num_right, int32_t nulls_equal,
+                              int32_t kind, void* stream, cudf_amd_table_t* out_indices);
+
+/* ---- cudf::hash_join (reference cpp/include/cudf/join/hash_join.hpp:71): build once on `right`, probe many times.
+ * has_nulls: 1 = nullable_join::YES, 0 = NO, -1 = use the (right, compare_nulls) constructor. load_factor in (0, 1].
+ * The caller keeps `right`'s memory alive while the object lives (as the reference requires). */
+cudf_amd_status cudf_amd_hash_join_create(const cudf_amd_column_view* right_keys, int32_t num_right, int32_t has_nulls,
+                                          int32_t nulls_equal, double load_factor, void* stream,
+                                          cudf_amd_hash_join_t* out);
+void cudf_amd_hash_join_destroy(cudf_amd_hash_join_t h);
+/* output_size < 0: unknown (a count pass runs first). */
+cudf_amd_status cudf_amd_hash_join_probe(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys, int32_t num_left,
+                                         int32_t kind, int64_t output_size, void* stream, cudf_amd_table_t* out_indices);
+/* inner_join_size / left_join_size / full_join_size: std::size_t, may exceed INT32_MAX. */
+cudf_amd_status cudf_amd_hash_join_size(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys, int32_t num_left,
+                                        int32_t kind, void* stream, uint64_t* out_size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,150 @@
+"""GPU parity tests for cudf::inner_join / left_join / full_join and cudf::hash_join through the C ABI: the
+reference's own KATs (tests/golden/kat_join.json), then seeded random inputs against the CPU oracle, then
+size-independent properties at large sizes."""
+import numpy as np
+import pytest
+
+import kat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(gpu):
+    import gpu_backend
+    return gpu_backend
+
+
+@pytest.mark.parametrize("c", kat.load("kat_join.json")["table_cases"], ids=lambda c: c["name"])
+def test_join_table_kat(G, c):
+    kat.run_join_table_case(G, c)
+
+
+@pytest.mark.parametrize("c", kat.load("kat_join.json")["hash_join_cases"], ids=lambda c: c["name"])
+def test_hash_join_kat(G, c):
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    right = cudf_amd.Table([G.to_device(x) for x in kat.table_cols(c["right"])])
+    has_nulls = None if c["nullable"] is None else (c["nullable"] == "YES")
+    kw = {} if c["load_factor"] is None else {"load_factor": c["load_factor"]}
+    hj = HashJoin(right, NullEquality.EQUAL if c["nulls"] == "equal" else NullEquality.UNEQUAL, has_nulls=has_nulls, **kw)
+    for p in c["probes"]:
+        left = cudf_amd.Table([G.to_device(x) for x in kat.table_cols(p["left"])])
+        size = getattr(hj, p["kind"] + "_join_size")(left)
+        assert size == p["size"]
+        li, ri = getattr(hj, p["kind"] + "_join")(left, output_size=size)
+        assert kat.sorted_pairs(li.to_numpy()[0], ri.to_numpy()[0]) == kat.sorted_pairs(p["gold_left"], p["gold_right"])
+        li, ri = getattr(hj, p["kind"] + "_join")(left)  # without the size hint
+        assert kat.sorted_pairs(li.to_numpy()[0], ri.to_numpy()[0]) == kat.sorted_pairs(p["gold_left"], p["gold_right"])
+
+
+def test_join_generated_kats(G):
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    z = cudf_amd.Table([G.to_device(np.zeros(65567, np.int32))])  # join_tests.cpp:2379-2394
+    hj = HashJoin(z, NullEquality.UNEQUAL, has_nulls=False, load_factor=0.5)
+    assert hj.inner_join_size(z) == 65567 * 65567
+    a = np.array([1197], np.int32)
+    with pytest.raises(ValueError):  # join_tests.cpp:432-450 -> std::invalid_argument
+        G.join([a, a], [a, a, a])
+    with pytest.raises(ValueError):
+        G.join([], [a, a, a])
+    with pytest.raises(TypeError):  # hash_join.cu:56-58 -> cudf::data_type_error
+        G.join([a], [a.astype(np.int64)])
+    with pytest.raises(ValueError):  # join_tests.cpp:347-367: load factor outside (0, 1]
+        HashJoin(z, NullEquality.EQUAL, has_nulls=False, load_factor=0.0)
+    with pytest.raises(ValueError):
+        HashJoin(z, NullEquality.EQUAL, has_nulls=False, load_factor=1.5)
+    # left table has nulls but the table was built without null check (hash_join.cu:52-54)
+    hj2 = HashJoin(cudf_amd.Table([G.to_device(a)]), NullEquality.EQUAL, has_nulls=False)
+    with pytest.raises(ValueError):
+        hj2.inner_join(cudf_amd.Table([G.to_device((a, np.array([False])))]))
+
+
+def _check(G, O, left, right, nulls_equal, kind):
+    li, ri = G.join(left, right, nulls_equal=nulls_equal, kind=kind)
+    el, er = O.join(left, right, nulls_equal=nulls_equal, kind=kind)
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+
+
+@pytest.mark.parametrize("kind", ["inner", "left", "full"])
+@pytest.mark.parametrize("nulls_equal", [True, False])
+def test_random_int64_with_nulls(G, oracle, kind, nulls_equal):
+    """C3 shape at small size: int64 keys, 5% nulls on both sides, selectivity 0.3, duplicates on both sides."""
+    rng = np.random.default_rng(44)
+    nl, nr = 60_000, 7_000
+    rk = rng.integers(0, 5_000, nr, dtype=np.int64)
+    lk = np.where(rng.random(nl) < 0.3, rng.integers(0, 5_000, nl), rng.integers(5_000, 10_000, nl)).astype(np.int64)
+    lv, rv = rng.random(nl) > 0.05, rng.random(nr) > 0.05
+    _check(G, oracle, [(lk, lv)], [(rk, rv)], nulls_equal, kind)
+
+
+@pytest.mark.parametrize("kind", ["inner", "left", "full"])
+def test_random_no_nulls_fast_path(G, oracle, kind):
+    rng = np.random.default_rng(12345)
+    nl, nr = 200_000, 20_000
+    rk = rng.permutation(40_000)[:nr].astype(np.int64)  # unique build keys
+    lk = rng.integers(0, 80_000, nl, dtype=np.int64)
+    _check(G, oracle, [lk], [rk], True, kind)
+    _check(G, oracle, [rk], [lk], True, kind)  # right bigger than left: inner join builds on left and swaps
+
+
+@pytest.mark.parametrize("nulls_equal", [True, False])
+def test_random_multi_column_mixed_types(G, oracle, nulls_equal):
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(7)
+    nl, nr = 30_000, 9_000
+    l0, r0 = rng.integers(0, 50, nl, dtype=np.int32), rng.integers(0, 50, nr, dtype=np.int32)
+    l1 = rng.integers(0, 4, nl).astype(np.float64) * 0.5
+    r1 = rng.integers(0, 4, nr).astype(np.float64) * 0.5
+    l1[::97] = np.nan
+    r1[::89] = np.nan
+    l1[1::97] = -0.0
+    r1[1::89] = 0.0
+    l2, r2 = rng.integers(0, 2, nl).astype(np.uint8), rng.integers(0, 2, nr).astype(np.uint8)
+    lv, rv = rng.random(nl) > 0.1, rng.random(nr) > 0.1
+    left = [HostColumn(l0, lv, "int32"), HostColumn(l1, None, "float64"), HostColumn(l2, None, "bool")]
+    right = [HostColumn(r0, rv, "int32"), HostColumn(r1, None, "float64"), HostColumn(r2, None, "bool")]
+    for kind in ("inner", "left", "full"):
+        _check(G, oracle, left, right, nulls_equal, kind)
+
+
+def test_empty_sides(G, oracle):
+    e = np.zeros(0, np.int64)
+    k = np.array([1, 2, 3], np.int64)
+    for kind in ("inner", "left", "full"):
+        _check(G, oracle, [e], [k], True, kind)
+        _check(G, oracle, [k], [e], True, kind)
+        _check(G, oracle, [e], [e], True, kind)
+
+
+def test_sliced_key_columns(G, oracle):
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(5)
+    lk, rk = rng.integers(0, 100, 5000, dtype=np.int64), rng.integers(0, 100, 700, dtype=np.int64)
+    lv, rv = rng.random(5000) > 0.1, rng.random(700) > 0.1
+    _check(G, oracle, [HostColumn(lk, lv, "int64", offset=13)], [HostColumn(rk, rv, "int64", offset=5)], False, "inner")
+    _check(G, oracle, [HostColumn(lk, lv, "int64", offset=13)], [HostColumn(rk, rv, "int64", offset=5)], True, "full")
+
+
+def test_large_properties(G):
+    """50M x 5M inner join (unique build keys): pair count == number of probe keys present in the build side;
+    every pair joins equal keys; every probe row appears at most once."""
+    import torch
+    import cudf_amd
+    from cudf_amd import join as J
+    nl, nr = 50_000_000, 5_000_000
+    g = torch.Generator(device="cuda").manual_seed(12345)
+    rk = torch.randperm(2 * nr, generator=g, device="cuda")[:nr].to(torch.int64)
+    lk = torch.randint(0, 4 * nr, (nl,), generator=g, device="cuda", dtype=torch.int64)
+    li, ri = J.inner_join(cudf_amd.Table([cudf_amd.Column.from_torch(lk)]), cudf_amd.Table([cudf_amd.Column.from_torch(rk)]))
+    li_t = torch.from_numpy(li.to_numpy()[0]).cuda().long()
+    ri_t = torch.from_numpy(ri.to_numpy()[0]).cuda().long()
+    present = torch.zeros(4 * nr, dtype=torch.bool, device="cuda")
+    present[rk] = True
+    assert li_t.numel() == int(present[lk].sum())
+    assert bool((lk[li_t] == rk[ri_t]).all())
+    assert torch.unique(li_t).numel() == li_t.numel()
