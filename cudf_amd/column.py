@@ -152,6 +152,25 @@ class Column:
             out = out != 0
         return out, valid
 
+    # ---- zero-copy interop (torch.as_tensor / cupy / numba read this protocol)
+    @property
+    def __cuda_array_interface__(self):
+        npdt = self._dtype.numpy_dtype()
+        if npdt == np.bool_:
+            npdt = np.dtype(np.uint8)
+        return {"shape": (self._size,), "typestr": npdt.str, "version": 2,
+                "data": (self._data + self._offset * npdt.itemsize, False)}
+
+    def to_torch(self):
+        """Zero-copy torch tensor over the column's data (validity is not carried); keeps the column alive."""
+        import torch
+
+        if self._size == 0:
+            return torch.empty(0, dtype=torch.from_numpy(np.empty(0, self._dtype.numpy_dtype())).dtype, device="cuda")
+        t = torch.as_tensor(self, device="cuda")
+        t._cudf_amd_owner = self
+        return t
+
     def __repr__(self):
         return f"Column({self._dtype}, size={self._size}, nulls={self._null_count})"
 

@@ -5,7 +5,9 @@
 
 #include "common/profiler.hpp"
 
+#include <cudf/copying.hpp>
 #include <cudf/groupby.hpp>
+#include <cudf/partitioning.hpp>
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
 #include <cudf/table/table.hpp>
@@ -287,6 +289,49 @@ cudf_amd_status cudf_amd_hash_join_size(cudf_amd_hash_join_t h, const cudf_amd_c
     cudf::stream_ref const s{as_stream(stream)};
     CUDF_EXPECTS(kind >= 0 && kind <= 2, "join kind must be 0 (inner), 1 (left) or 2 (full)", std::invalid_argument);
     *out_size = kind == 0 ? h->hj->inner_join_size(l, s) : kind == 1 ? h->hj->left_join_size(l, s) : h->hj->full_join_size(l, s);
+  });
+}
+
+cudf_amd_status cudf_amd_hash_partition(const cudf_amd_column_view* input, int32_t num_columns,
+                                        const int32_t* columns_to_hash, int32_t num_hash_columns, int32_t num_partitions,
+                                        uint32_t seed, void* stream, cudf_amd_table_t* out_table, int32_t* out_offsets)
+{
+  return guarded([&] {
+    *out_table   = nullptr;
+    auto const t = to_table(input, num_columns);
+    std::vector<cudf::size_type> cols(columns_to_hash, columns_to_hash + num_hash_columns);
+    auto [tbl, offs] = cudf::hash_partition(t, cols, num_partitions, cudf::hash_id::HASH_MURMUR3, seed,
+                                            cudf::stream_ref{as_stream(stream)});
+    for (size_t i = 0; i < offs.size(); ++i) out_offsets[i] = offs[i];
+    auto h  = std::make_unique<cudf_amd_table_s>();
+    h->cols = tbl->release();
+    *out_table = h.release();
+  });
+}
+
+cudf_amd_status cudf_amd_murmurhash3_x86_32(const cudf_amd_column_view* input, int32_t num_columns, uint32_t seed,
+                                            void* stream, cudf_amd_table_t* out_column)
+{
+  return guarded([&] {
+    *out_column = nullptr;
+    auto h      = std::make_unique<cudf_amd_table_s>();
+    h->cols.push_back(cudf::hashing::murmurhash3_x86_32(to_table(input, num_columns), seed, cudf::stream_ref{as_stream(stream)}));
+    *out_column = h.release();
+  });
+}
+
+cudf_amd_status cudf_amd_gather(const cudf_amd_column_view* source, int32_t num_columns,
+                                const cudf_amd_column_view* gather_map, int32_t nullify, void* stream,
+                                cudf_amd_table_t* out_table)
+{
+  return guarded([&] {
+    *out_table = nullptr;
+    auto tbl   = cudf::gather(to_table(source, num_columns), to_view(*gather_map),
+                              nullify ? cudf::out_of_bounds_policy::NULLIFY : cudf::out_of_bounds_policy::DONT_CHECK,
+                              cudf::stream_ref{as_stream(stream)});
+    auto h     = std::make_unique<cudf_amd_table_s>();
+    h->cols    = tbl->release();
+    *out_table = h.release();
   });
 }
 }  // extern "C"

@@ -117,6 +117,23 @@ cudf_amd_status cudf_amd_hash_join_probe(cudf_amd_hash_join_t h, const cudf_amd_
 cudf_amd_status cudf_amd_hash_join_size(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys, int32_t num_left,
                                         int32_t kind, void* stream, uint64_t* out_size);
 
+/* ---- cudf::hash_partition(input, columns_to_hash, num_partitions, HASH_MURMUR3, seed, stream, mr)
+ * (reference cpp/include/cudf/partitioning.hpp; src/partitioning/partitioning.cu:925-947). out_offsets receives
+ * num_partitions start offsets (first is 0), as the reference's std::vector<size_type>. */
+cudf_amd_status cudf_amd_hash_partition(const cudf_amd_column_view* input, int32_t num_columns,
+                                        const int32_t* columns_to_hash, int32_t num_hash_columns, int32_t num_partitions,
+                                        uint32_t seed, void* stream, cudf_amd_table_t* out_table, int32_t* out_offsets);
+
+/* ---- cudf::hashing::murmurhash3_x86_32(input, seed) -> UINT32 column (reference cpp/include/cudf/hashing.hpp). */
+cudf_amd_status cudf_amd_murmurhash3_x86_32(const cudf_amd_column_view* input, int32_t num_columns, uint32_t seed,
+                                            void* stream, cudf_amd_table_t* out_column);
+
+/* ---- cudf::gather(source_table, gather_map, bounds_policy) (reference cpp/include/cudf/copying.hpp).
+ * nullify: 1 = out_of_bounds_policy::NULLIFY (JoinNoMatch and other out-of-range indices give NULL rows). */
+cudf_amd_status cudf_amd_gather(const cudf_amd_column_view* source, int32_t num_columns,
+                                const cudf_amd_column_view* gather_map, int32_t nullify, void* stream,
+                                cudf_amd_table_t* out_table);
+
 #ifdef __cplusplus
 }
 #endif

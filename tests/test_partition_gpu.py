@@ -1,0 +1,145 @@
+"""GPU parity tests for the pieces either side of the hot path: cudf::hashing::murmurhash3_x86_32 (bit-exact vs
+the oracle's reference-compatible row hash), cudf::hash_partition, cudf::gather, and the single-rank run of the
+distributed groupby over RCCL."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(gpu):
+    import gpu_backend
+    return gpu_backend
+
+
+def _cols(rng, n):
+    from oracle.oracle import HostColumn
+    return [
+        HostColumn(rng.integers(-50, 50, n, dtype=np.int64), rng.random(n) > 0.1, "int64"),
+        HostColumn(rng.integers(0, 7, n).astype(np.int32), None, "int32"),
+        HostColumn(np.where(rng.random(n) < 0.05, np.nan, rng.integers(-3, 3, n) * 0.5), None, "float64"),
+        HostColumn(rng.integers(0, 3, n).astype(np.uint8), None, "bool"),
+        HostColumn(rng.integers(-100, 100, n).astype(np.int16), rng.random(n) > 0.5, "int16"),
+        HostColumn((rng.integers(-2, 3, n) * 0.0).astype(np.float32), None, "float32"),  # +0.0 / -0.0
+    ]
+
+
+@pytest.mark.parametrize("seed", [0, 31])
+def test_murmur3_row_hash_bit_exact(G, oracle, seed):
+    import cudf_amd
+    from cudf_amd import partitioning
+    rng = np.random.default_rng(1)
+    cols = _cols(rng, 10_000)
+    for k in range(1, len(cols) + 1):
+        t = cudf_amd.Table([G.to_device(c) for c in cols[:k]])
+        got = partitioning.murmurhash3_x86_32(t, seed).to_numpy()[0]
+        assert np.array_equal(got, oracle.row_hash(cols[:k], seed)), f"{k} columns"
+
+
+@pytest.mark.parametrize("nparts", [1, 2, 3, 8, 64, 1000])
+@pytest.mark.parametrize("n", [0, 1, 5000, 300_000])
+def test_hash_partition(G, oracle, nparts, n):
+    import cudf_amd
+    from cudf_amd import partitioning
+    rng = np.random.default_rng(2)
+    cols = _cols(rng, n)
+    t = cudf_amd.Table([G.to_device(c) for c in cols])
+    out, offs = partitioning.hash_partition(t, [0, 1], nparts)
+    assert len(offs) == nparts
+    if n == 0:
+        assert out.num_rows() == 0 and all(o == 0 for o in offs)
+        return
+    part, eoffs, order = oracle.hash_partition(cols[:2], nparts)
+    assert list(offs) == [int(x) for x in eoffs]
+    got = [c.to_numpy() for c in out.columns()]
+    bounds = list(offs) + [n]
+    # membership: every output row of partition p is a source row of partition p (compare as sorted row tuples)
+    def rows(data_valid_list, idx):
+        out_rows = []
+        for i in idx:
+            out_rows.append(tuple(None if (v is not None and not v[i]) else (d[i].item() if not (isinstance(d[i].item(), float) and np.isnan(d[i])) else "nan")
+                                  for d, v in data_valid_list))
+        return sorted(out_rows, key=lambda r: tuple((x is None, str(x)) for x in r))
+    src = [(c.data if c.type_id != 11 else c.data != 0, c.valid) for c in cols]
+    for p in range(nparts):
+        if bounds[p + 1] - bounds[p] > 2000:
+            continue  # checked by the count; keep the python loop small
+        src_idx = np.nonzero(part == p)[0]
+        assert bounds[p + 1] - bounds[p] == len(src_idx)
+        assert rows(got, range(bounds[p], bounds[p + 1])) == rows(src, src_idx)
+    # null counts preserved
+    for c, o in zip(cols, out.columns()):
+        assert o.null_count() == c.null_count
+
+
+def test_gather_with_nullify(G):
+    import cudf_amd
+    from cudf_amd import partitioning
+    from cudf_amd.types import OutOfBoundsPolicy
+    rng = np.random.default_rng(3)
+    n = 1000
+    data = rng.integers(0, 1 << 40, n, dtype=np.int64)
+    valid = rng.random(n) > 0.2
+    t = cudf_amd.Table([G.to_device((data, valid)), G.to_device(rng.random(n).astype(np.float32))])
+    idx = rng.integers(0, n, 5000).astype(np.int32)
+    idx[::7] = -2**31  # JoinNoMatch
+    out = partitioning.gather(t, G.to_device(idx), OutOfBoundsPolicy.NULLIFY)
+    d0, v0 = out.columns()[0].to_numpy()
+    d1, v1 = out.columns()[1].to_numpy()
+    ok = idx >= 0
+    assert np.array_equal(v0, np.where(ok, valid[np.where(ok, idx, 0)], False))
+    assert np.array_equal(d0[v0], data[idx[v0]])
+    assert np.array_equal(v1, ok)
+    assert out.columns()[1].null_count() == int((~ok).sum())
+
+
+def test_join_then_gather_payload(G, oracle):
+    """C3 end to end at small size: inner join on int64 keys with 5% nulls, then gather 2 float64 payload columns
+    per side by the returned indices (the step every caller runs after inner_join)."""
+    import cudf_amd
+    from cudf_amd import join as J, partitioning
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(44)
+    nl, nr = 50_000, 5_000
+    rk = rng.permutation(2 * nr)[:nr].astype(np.int64)
+    lk = rng.integers(0, 4 * nr, nl, dtype=np.int64)
+    lv, rv = rng.random(nl) > 0.05, rng.random(nr) > 0.05
+    lp = [rng.random(nl), rng.random(nl)]
+    rp = [rng.random(nr), rng.random(nr)]
+    li, ri = J.inner_join(cudf_amd.Table([G.to_device((lk, lv))]), cudf_amd.Table([G.to_device((rk, rv))]), NullEquality.UNEQUAL)
+    gl = partitioning.gather(cudf_amd.Table([G.to_device(x) for x in lp]), li)
+    gr = partitioning.gather(cudf_amd.Table([G.to_device(x) for x in rp]), ri)
+    el, er = oracle.join([(lk, lv)], [(rk, rv)], nulls_equal=False)
+    got = sorted(zip(li.to_numpy()[0].tolist(), ri.to_numpy()[0].tolist(), gl.columns()[0].to_numpy()[0].tolist(),
+                     gl.columns()[1].to_numpy()[0].tolist(), gr.columns()[0].to_numpy()[0].tolist(), gr.columns()[1].to_numpy()[0].tolist()))
+    exp = sorted(zip(el.tolist(), er.tolist(), lp[0][el].tolist(), lp[1][el].tolist(), rp[0][er].tolist(), rp[1][er].tolist()))
+    assert got == exp
+
+
+@pytest.mark.parametrize("mode", ["shuffle", "preaggregate"])
+def test_distributed_single_rank_rccl(G, oracle, mode):
+    """world_size 1 over the nccl (RCCL) backend on the GPU: same code path the multi-GPU bench runs."""
+    import torch
+    import torch.distributed as dist
+    import kat
+    from cudf_amd import distributed as D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(5)
+        n = 400_000
+        k = rng.integers(0, 30_000, n, dtype=np.int64)
+        v = rng.random(n)
+        gk, gs, gc = D.distributed_groupby_sum_count(torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda(), mode=mode)
+        kc, rc = kat.sort_groups(*oracle.groupby([k], [(v, ["sum", "count_valid"])]))
+        o = torch.argsort(gk)
+        assert np.array_equal(gk[o].cpu().numpy(), kc[0][0])
+        assert np.array_equal(gc[o].cpu().numpy().astype(np.int64), rc[0][1][0].astype(np.int64))
+        assert np.allclose(gs[o].cpu().numpy(), rc[0][0][0], rtol=1e-12)
+    finally:
+        dist.destroy_process_group()
