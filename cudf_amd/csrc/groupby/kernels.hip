@@ -295,11 +295,10 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
   }
   __syncthreads();
 
-  for (int64_t tile = sr.begin; tile < sr.end; tile += T) {
-    uint64_t rec[RPT][UT];
-    uint32_t dig[RPT], rank[RPT];
-    bool keep[RPT];
-    // phase 1a: issue all loads of the tile
+  uint64_t rec[RPT][UT];
+  bool keep[RPT];
+  // loads one tile into registers (all loads issued back to back)
+  auto load_tile = [&](int64_t tile) {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       int64_t const r = tile + static_cast<int64_t>(k) * B + threadIdx.x;
@@ -318,14 +317,18 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
           }
         } else if constexpr (EXACT && UT == 2) {
           u64x2 const v = gload(reinterpret_cast<u64x2 const*>(in_records) + r);
-          rec[k][0]          = v.x;
-          rec[k][1]          = v.y;
+          rec[k][0]     = v.x;
+          rec[k][1]     = v.y;
         } else {
 #pragma unroll
           for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? gload(in_records + r * U + u) : 0;
         }
       }
     }
+  };
+  if (sr.begin < sr.end) load_tile(sr.begin);
+  for (int64_t tile = sr.begin; tile < sr.end; tile += T) {
+    uint32_t dig[RPT], rank[RPT];
     // phase 1b: hash and rank within (tile, partition)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -375,6 +378,9 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
         pid[pos] = static_cast<uint16_t>(dig[k]);
       }
     }
+    // the records are staged: the registers are free, so the NEXT tile's loads go out now and fly under the
+    // write-out phase (one workgroup per CU: nothing else would hide their latency)
+    if (tile + T < sr.end) load_tile(tile + T);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) {
@@ -477,14 +483,34 @@ __device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask
 // registers together with the key (0 = payload fetched lazily per accumulator: column input, wide records).
 // NACCT: compile-time bound of the accumulator loop (descriptors sit in registers, statically indexed).
 // EXACT: the input record has exactly KUT + PAYT units (a 16-byte record is one global_load_dwordx4).
-template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT>
+// SIG: compile-time accumulator signature (0 = read the descriptors at run time). For the hot shapes every
+// descriptor test folds away and the accumulate step is straight-line ds_* atomics: the generic form spends
+// ~200 scalar instructions per 64 rows on descriptor branches and is bound by the CU's single scalar ALU.
+// 12 bits per accumulator: op(4) | src(2) | pay+1 (3) | vbit+1 (3); accumulator count in bits 60..63.
+constexpr uint64_t sig_acc(int op, int src, int pay, int vbit)
+{
+  return static_cast<uint64_t>(op) | (static_cast<uint64_t>(src) << 4) | (static_cast<uint64_t>(pay + 1) << 6) |
+         (static_cast<uint64_t>(vbit + 1) << 9);
+}
+constexpr uint64_t make_sig(int n, uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, uint64_t a3 = 0)
+{
+  return (static_cast<uint64_t>(n) << 60) | a0 | (a1 << 12) | (a2 << 24) | (a3 << 36);
+}
+constexpr int sig_n(uint64_t s) { return static_cast<int>(s >> 60); }
+constexpr int sig_op(uint64_t s, int q) { return static_cast<int>((s >> (12 * q)) & 0xf); }
+constexpr int sig_src(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 4)) & 0x3); }
+constexpr int sig_pay(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 6)) & 0x7) - 1; }
+constexpr int sig_vbit(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 9)) & 0x7) - 1; }
+
+template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT, uint64_t SIG = 0>
 __global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggregate(agg_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   agg_args const& a = *ap;
   plan_dev const& p = a.plan;
   int const cap     = a.geom.cap;
-  int const KU = EXACT ? KUT : p.KU, NACC = p.NACC;
+  constexpr bool STATIC_SIG = SIG != 0;
+  int const KU = EXACT ? KUT : p.KU, NACC = STATIC_SIG ? sig_n(SIG) : p.NACC;
   uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);                 // [KU][cap]
   uint64_t* accs = keys + static_cast<size_t>(KU) * cap;                   // [NACC][cap]
   uint32_t* st   = reinterpret_cast<uint32_t*>(accs + static_cast<size_t>(NACC) * cap);  // [cap]
@@ -509,10 +535,10 @@ __global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggr
 #pragma unroll
   for (int j = 0; j < NACCT; ++j) {
     uint32_t const w = j < NACC ? reinterpret_cast<uint32_t const*>(p.acc)[j] : 0u;
-    acc_op[j]        = static_cast<int8_t>(w);
-    acc_src[j]       = static_cast<int8_t>(w >> 8);
-    acc_pay[j]       = static_cast<int8_t>(w >> 16);
-    acc_vbit[j]      = static_cast<int8_t>(w >> 24);
+    acc_op[j]        = STATIC_SIG ? sig_op(SIG, j) : static_cast<int8_t>(w);
+    acc_src[j]       = STATIC_SIG ? sig_src(SIG, j) : static_cast<int8_t>(w >> 8);
+    acc_pay[j]       = STATIC_SIG ? sig_pay(SIG, j) : static_cast<int8_t>(w >> 16);
+    acc_vbit[j]      = STATIC_SIG ? sig_vbit(SIG, j) : static_cast<int8_t>(w >> 24);
   }
   __syncthreads();
 
@@ -643,25 +669,39 @@ __global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggr
       // rows that miss walk the full claim/probe protocol.
       uint64_t h[R];
       int slot[R];
-      uint32_t s0[R];
-      uint64_t k0[R][KUT];
+      uint32_t s0[R], s1[R];
+      uint64_t k0[R][KUT], k1[R][KUT];
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         h[k]    = hash_of(key[k]);
         slot[k] = static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(h[k])) * static_cast<uint32_t>(cap)) >> 32);
+        int const nxt = slot[k] + 1 == cap ? 0 : slot[k] + 1;
         s0[k]   = __hip_atomic_load(&st[slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        s1[k]   = __hip_atomic_load(&st[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-        for (int u = 0; u < KUT; ++u) k0[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + slot[k])] : 0;
+        for (int u = 0; u < KUT; ++u) {
+          k0[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + slot[k])] : 0;
+          k1[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + nxt)] : 0;
+        }
       }
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         if (!keep[k]) continue;
-        bool hit = s0[k] == tag_of(h[k]);
+        uint32_t const tag = tag_of(h[k]);
+        bool hit0 = s0[k] == tag, hit1 = s1[k] == tag;
 #pragma unroll
-        for (int u = 0; u < KUT; ++u)
-          if (u < KU) hit = hit && (k0[k][u] == (key[k][u] & kmask[u]));
+        for (int u = 0; u < KUT; ++u) {
+          if (u < KU) {
+            hit0 = hit0 && (k0[k][u] == (key[k][u] & kmask[u]));
+            hit1 = hit1 && (k1[k][u] == (key[k][u] & kmask[u]));
+          }
+        }
         int sl = slot[k];
-        if (!hit) sl = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
+        if (!hit0) {
+          // the second slot only counts when the first is occupied by another key (else the key would sit there)
+          if (hit1 && s0[k] >= 2) sl = slot[k] + 1 == cap ? 0 : slot[k] + 1;
+          else sl = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
+        }
         if (sl >= 0) accumulate(base + k * B + threadIdx.x, sl, pay[k], valvalid[k]);
       }
     }
@@ -869,7 +909,12 @@ void launch_partition_scatter(part_args const& a, part_args const* d_args, hipSt
   int const U       = a.plan.KU + a.plan.NPAY;
   bool const simple = a.plan.simple && a.from_columns;
   switch (next_ut(U)) {
-    case 2: simple ? launch_scatter_t<2, 8, true, true>(a, d_args, stream) : launch_scatter_t<2, 8, false, true>(a, d_args, stream); break;
+    case 2:
+      if (a.geom.tile_rows == 4 * a.geom.block)  // half-size tile: 64 KiB of LDS, two workgroups per CU
+        simple ? launch_scatter_t<2, 4, true, true>(a, d_args, stream) : launch_scatter_t<2, 4, false, true>(a, d_args, stream);
+      else
+        simple ? launch_scatter_t<2, 8, true, true>(a, d_args, stream) : launch_scatter_t<2, 8, false, true>(a, d_args, stream);
+      break;
     case 3: simple ? launch_scatter_t<3, 4, true, true>(a, d_args, stream) : launch_scatter_t<3, 4, false, true>(a, d_args, stream); break;
     case 4: simple ? launch_scatter_t<4, 4, true, true>(a, d_args, stream) : launch_scatter_t<4, 4, false, true>(a, d_args, stream); break;
     case 6: launch_scatter_t<6, 2, false, false>(a, d_args, stream); break;
@@ -880,21 +925,44 @@ void launch_partition_scatter(part_args const& a, part_args const* d_args, hipSt
   }
 }
 
-template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT>
+template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT, uint64_t SIG = 0>
 static void launch_aggregate_n(agg_args const& a, agg_args* d_args, hipStream_t stream)
 {
   auto const lds = aggregate_lds_bytes(a.plan, a.geom);
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT, SIG>));
     attr_set = true;
   }
   hipLaunchKernelGGL(k_store_args<agg_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"aggregate", stream};
-  hipLaunchKernelGGL((k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT>), dim3(a.nitems), dim3(a.geom.block), lds, stream,
-                     d_args);
+  hipLaunchKernelGGL((k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT, SIG>), dim3(a.nitems), dim3(a.geom.block), lds,
+                     stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
+
+// Signature of a plan's accumulators (0 if it does not fit the static encoding).
+static uint64_t plan_sig(plan_dev const& p)
+{
+  if (p.NACC < 1 || p.NACC > 4) return 0;
+  uint64_t a[4] = {0, 0, 0, 0};
+  for (int q = 0; q < p.NACC; ++q) {
+    auto const& d = p.acc[q];
+    if (d.pay > 5 || d.valid_bit > 5) return 0;
+    a[q] = sig_acc(d.op, d.src, d.pay, d.valid_bit);
+  }
+  return make_sig(p.NACC, a[0], a[1], a[2], a[3]);
+}
+// hot signatures with their own instantiation
+constexpr uint64_t SIG_SUMF_CNT = make_sig(2, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1));
+constexpr uint64_t SIG_SUMI_CNT = make_sig(2, sig_acc(ADD_I64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1));
+constexpr uint64_t SIG_SUMF     = make_sig(1, sig_acc(ADD_F64, SRC_VALUE, 0, -1));
+constexpr uint64_t SIG_SUMI     = make_sig(1, sig_acc(ADD_I64, SRC_VALUE, 0, -1));
+constexpr uint64_t SIG_CNT      = make_sig(1, sig_acc(ADD_I64, SRC_ONE, -1, -1));
+// C4: MEAN + MIN + MAX of a nullable float64 column -> SUM, COUNT_VALID, MIN, MAX
+constexpr uint64_t SIG_MEAN_MIN_MAX_F_NULLS =
+  make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0), sig_acc(MIN_F64, SRC_VALUE, 0, 0),
+           sig_acc(MAX_F64, SRC_VALUE, 0, 0));
 
 template <int INPUT, int KUT, int PAYT, bool SIMPLE, bool EXACT>
 static void launch_aggregate_t(agg_args const& a, agg_args* d_args, hipStream_t stream)
@@ -909,6 +977,19 @@ static void launch_aggregate_records(agg_args const& a, agg_args* d_args, hipStr
 {
   int const KU   = a.plan.KU;
   int const npay = INPUT == IN_RAW_RECORDS ? a.plan.NPAY : a.plan.NACC;
+  // hot signatures: descriptors folded at compile time
+  if constexpr (INPUT == IN_RAW_RECORDS) {
+    uint64_t const sig = plan_sig(a.plan);
+    if (KU == 1 && npay == 1 && a.plan.flags_unit < 0) {
+      if (sig == SIG_SUMF_CNT) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMF_CNT>(a, d_args, stream);
+      if (sig == SIG_SUMI_CNT) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMI_CNT>(a, d_args, stream);
+      if (sig == SIG_SUMF) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMF>(a, d_args, stream);
+      if (sig == SIG_SUMI) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMI>(a, d_args, stream);
+      if (sig == SIG_CNT) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_CNT>(a, d_args, stream);
+    }
+    if (KU == 2 && npay == 1 && sig == SIG_MEAN_MIN_MAX_F_NULLS)
+      return launch_aggregate_n<INPUT, 2, 1, 4, false, true, SIG_MEAN_MIN_MAX_F_NULLS>(a, d_args, stream);
+  }
   // exact shapes get the payload prefetched with the key; everything else fetches it lazily
   if (KU == 1 && npay == 1) return launch_aggregate_t<INPUT, 1, 1, false, true>(a, d_args, stream);
   if (KU == 1 && npay == 2) return launch_aggregate_t<INPUT, 1, 2, false, true>(a, d_args, stream);
