@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Secondary configurations of BASELINE.json at full size on one MI355X (not the headline line; `bench.py` is):
+  C3  hash inner_join, 500M x 50M int64 keys, 5% nulls on both sides, selectivity 0.3 (UNEQUAL, as the reference's
+      benchmark default cpp/benchmarks/join/join_common.hpp:42) + gather of 2+2 float64 payload columns
+  C4  groupby keys (int64, int32), value float64, 10M groups, 10% nulls on k1 and on the value, MEAN+MIN+MAX
+Prints one JSON line per config with per-kernel times (HIP events on the launch stream) and property checks.
+Usage: python bench_configs.py [c3] [c4] [--scale 1.0]
+"""
+import json
+import sys
+import time
+
+import torch
+
+import cudf_amd
+from cudf_amd import _lib, aggregation as agg, groupby as gb, join as J, partitioning
+from cudf_amd.types import NullEquality, NullPolicy
+
+
+def bernoulli_mask(n, p_null, seed, dev):
+    """int32 bitmask words with P(bit = 0) = p_null, plus the null count."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    nwords = (n + 31) // 32
+    valid = torch.rand(nwords * 32, generator=g, device=dev) >= p_null
+    valid[n:] = False
+    w = (valid.view(nwords, 32).to(torch.int64) << torch.arange(32, device=dev, dtype=torch.int64)).sum(1)
+    words = (w & 0xFFFFFFFF).to(torch.int64)
+    words = torch.where(words >= 2**31, words - 2**32, words).to(torch.int32)
+    pad = torch.zeros(16, dtype=torch.int32, device=dev)
+    return torch.cat([words, pad]), int(n - valid[:n].sum().item()), valid[:n]
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    _lib.profile_enable(False)
+    prof = {k: v[1] / steps for k, v in sorted(_lib.profile_report().items())}
+    return out, dt, prof
+
+
+def c4(scale):
+    dev = torch.device("cuda", 0)
+    n = int(1_000_000_000 * scale)
+    g = torch.Generator(device=dev).manual_seed(46)
+    k0 = torch.randint(0, 10_000, (n,), generator=g, device=dev, dtype=torch.int64)
+    k1 = torch.randint(0, 1_000, (n,), generator=g, device=dev, dtype=torch.int32)
+    v = torch.rand(n, generator=g, device=dev, dtype=torch.float64)
+    k1m, k1nulls, k1valid = bernoulli_mask(n, 0.10, 47, dev)
+    vm, vnulls, vvalid = bernoulli_mask(n, 0.10, 48, dev)
+    keys = cudf_amd.Table([cudf_amd.Column.from_torch(k0), cudf_amd.Column.from_torch(k1, k1m, k1nulls)])
+    vals = cudf_amd.Column.from_torch(v, vm, vnulls)
+
+    def run():
+        grp = gb.GroupBy(keys, NullPolicy.EXCLUDE)
+        return grp, grp.aggregate([gb.GroupByRequest(vals, [agg.mean(), agg.min(), agg.max()])], stream=torch.cuda.current_stream())
+
+    (grp, (uk, res)), dt, prof = timed(run, 3, 1)
+    G = uk.num_rows()
+    mean, mn, mx = [c.to_torch() for c in res[0].columns()]
+    # properties: group count == distinct valid (k0,k1) pairs; min <= mean <= max where valid; global max matches
+    combo = (k0 * 1000 + k1.to(torch.int64))[k1valid]
+    distinct = int(torch.unique(combo).numel())
+    checks = {"groups": G, "distinct_pairs": distinct, "groups_ok": G == distinct}
+    mvalid = ~torch.isnan(mean) if res[0].columns()[0].null_count() == 0 else None
+    sel = k1valid & vvalid
+    checks["global_max_ok"] = bool(abs(float(mx.max()) - float(v[sel].max())) == 0.0)
+    checks["global_min_ok"] = bool(abs(float(mn.min()) - float(v[sel].min())) == 0.0)
+    algo_bytes = n * (8 + 4 + 8) + 2 * n / 8
+    print(json.dumps({"config": "C4", "rows": n, "groups": G, "ms": dt * 1e3, "rows_per_s": n / dt,
+                      "algorithmic_GBps": algo_bytes / dt / 1e9, "path": grp.last_path.name,
+                      "kernels_ms": prof, "checks": checks}), flush=True)
+
+
+def c3(scale):
+    dev = torch.device("cuda", 0)
+    nl, nr = int(500_000_000 * scale), int(50_000_000 * scale)
+    g = torch.Generator(device=dev).manual_seed(12345)
+    rk = torch.randperm(nr, generator=g, device=dev).to(torch.int64)  # unique build keys [0, nr)
+    sel = torch.rand(nl, generator=g, device=dev) < 0.3
+    lk = torch.where(sel, torch.randint(0, nr, (nl,), generator=g, device=dev, dtype=torch.int64),
+                     torch.randint(nr, 2 * nr, (nl,), generator=g, device=dev, dtype=torch.int64))
+    del sel
+    lm, lnulls, lvalid = bernoulli_mask(nl, 0.05, 44, dev)
+    rm, rnulls, rvalid = bernoulli_mask(nr, 0.05, 45, dev)
+    L = cudf_amd.Table([cudf_amd.Column.from_torch(lk, lm, lnulls)])
+    R = cudf_amd.Table([cudf_amd.Column.from_torch(rk, rm, rnulls)])
+
+    def run():
+        return J.inner_join(L, R, NullEquality.UNEQUAL, stream=torch.cuda.current_stream())
+
+    (li, ri), dt, prof = timed(run, 3, 1)
+    M = li.size()
+    li_t, ri_t = li.to_torch().long(), ri.to_torch().long()
+    present = torch.zeros(2 * nr, dtype=torch.bool, device=dev)
+    present[rk[rvalid]] = True
+    expect = int((present[lk] & lvalid).sum())
+    checks = {"pairs": M, "expected_pairs": expect, "count_ok": M == expect,
+              "keys_equal": bool((lk[li_t] == rk[ri_t]).all()), "no_null_rows": bool(lvalid[li_t].all() and rvalid[ri_t].all())}
+    algo_bytes = 8 * (nl + nr) + (nl + nr) / 8 + 8 * M
+    out = {"config": "C3", "left_rows": nl, "right_rows": nr, "pairs": M, "join_ms": dt * 1e3,
+           "rows_per_s": (nl + nr) / dt, "algorithmic_GBps": algo_bytes / dt / 1e9, "kernels_ms": prof, "checks": checks}
+    # gather 2 + 2 float64 payload columns by the returned indices
+    lp = cudf_amd.Table([cudf_amd.Column.from_torch(torch.rand(nl, device=dev, dtype=torch.float64)) for _ in range(2)])
+    rp = cudf_amd.Table([cudf_amd.Column.from_torch(torch.rand(nr, device=dev, dtype=torch.float64)) for _ in range(2)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gl = partitioning.gather(lp, li)
+    gr = partitioning.gather(rp, ri)
+    torch.cuda.synchronize()
+    out["gather_ms"] = (time.perf_counter() - t0) * 1e3
+    out["checks"]["gather_ok"] = bool((gl.columns()[0].to_torch() == lp.columns()[0].to_torch()[li_t]).all())
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    scale = 1.0
+    if "--scale" in sys.argv:
+        scale = float(sys.argv[sys.argv.index("--scale") + 1])
+    which = args or ["c4", "c3"]
+    if "c4" in which:
+        c4(scale)
+        torch.cuda.empty_cache()
+    if "c3" in which:
+        c3(scale)

@@ -76,8 +76,9 @@ __global__ void __launch_bounds__(1024) k_agg(const u64x2* __restrict__ rec, int
   if (threadIdx.x == 0) out[blockIdx.x] = sums[1] + (double)cnts[2];
 }
 
-int main() {
-  const int64_t n = 1000000000; const int P = 1024; const int64_t per = n / P; const int cap = 2633; const int gpp = 977;
+int main(int argc, char** argv) {
+  const int64_t n = 1000000000; const int P = argc > 1 ? atoi(argv[1]) : 1024; const int64_t per = n / P; const int cap = argc > 2 ? atoi(argv[2]) : 2633; const int gpp = 1000000 / P;
+  printf("P %d cap %d groups/partition %d\n", P, cap, gpp);
   u64x2* rec; double* out; CK(hipMalloc(&rec, n * 16)); CK(hipMalloc(&out, P * 8));
   hipLaunchKernelGGL(k_gen, dim3(4096), dim3(256), 0, 0, rec, n, per, gpp); CK(hipDeviceSynchronize());
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -90,7 +91,7 @@ int main() {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
     printf("%-34s block %4d: %7.3f ms  %6.1f Grows/s  %5.2f TB/s\n", name, block, ms, n / ms / 1e6, n * 16.0 / ms / 1e9);
   };
-  for (int block : {256, 512, 1024}) {
+  for (int block : {1024}) {
     run(k_agg<3, 4>, "stream only R=4", block);
     run(k_agg<3, 8>, "stream only R=8", block);
     run(k_agg<0, 4>, "direct slot + 2 atomics R=4", block);

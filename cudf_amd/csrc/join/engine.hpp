@@ -31,10 +31,18 @@ struct join_args {
   size_type* out_build;        // build-side row of each pair (JoinNoMatch for unmatched probe rows)
   uint64_t out_capacity;       // pairs that fit in out_probe/out_build
   uint8_t* build_matched;      // full join: build rows seen by some probe row
+  // probe rows are cut into `nblocks` contiguous chunks, one per workgroup, identical in the count and the
+  // retrieve pass: block_offsets[b] (exclusive scan of the per-block pair counts) makes the output position of
+  // every pair a block-local matter — no global atomic on the probe path
+  int32_t nblocks;
+  int64_t chunk;
+  unsigned long long* block_counts;   // [nblocks + 1]; after launch_scan: exclusive offsets, [nblocks] = total
 };
 
 void launch_build(join_args const& a, join_args* d_args, hipStream_t stream);
 void launch_count(join_args const& a, join_args* d_args, hipStream_t stream);
+// exclusive scan of block_counts in place (block_counts[nblocks] = total pairs)
+void launch_scan(join_args const& a, hipStream_t stream);
 void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream);
 // full join: appends (JoinNoMatch, r) for every build row with build_matched[r] == 0
 void launch_complement(join_args const& a, join_args* d_args, hipStream_t stream);

@@ -111,11 +111,16 @@ class hash_join_impl {
       return r.first->size();
     }
     join_args a = base_args(left, kind == join_kind::INNER_JOIN ? 0 : 1);
-    dev_scalar<unsigned long long> total{0, stream.value()};
-    a.total = total.ptr();
+    rmm::device_buffer counts{(static_cast<std::size_t>(a.nblocks) + 1) * sizeof(unsigned long long), stream.value(),
+                              cudf::get_current_device_resource_ref()};
+    a.block_counts = static_cast<unsigned long long*>(counts.data());
     rmm::device_buffer d_args{sizeof(join_args), stream.value(), cudf::get_current_device_resource_ref()};
     join::launch_count(a, static_cast<join_args*>(d_args.data()), stream.value());
-    return static_cast<std::size_t>(total.value());
+    join::launch_scan(a, stream.value());
+    unsigned long long total = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(&total, a.block_counts + a.nblocks, sizeof(total), hipMemcpyDeviceToHost, stream.value()));
+    CUDF_HIP_TRY(hipStreamSynchronize(stream.value()));
+    return static_cast<std::size_t>(total);
   }
 
   [[nodiscard]] join_index_pair probe(table_view const& left, join_kind kind, std::optional<std::size_t> output_size,
@@ -140,16 +145,23 @@ class hash_join_impl {
     hipStream_t const s = stream.value();
     rmm::device_buffer d_args{sizeof(join_args), s, cudf::get_current_device_resource_ref()};
     // ---- size: given, or counted with one probe pass (reference: compute_join_output_size, size_impl.cuh:26-61)
+    // The count pass always runs: its per-workgroup counts place every pair without global atomics (the pass
+    // costs ~6% of the retrieve it replaces); a caller-supplied output_size is checked against it.
     std::size_t pairs = 0;
-    if (output_size.has_value() && kind != join_kind::FULL_JOIN) {
-      pairs = *output_size;
-    } else {
-      join_args c = base_args(left, k == 0 ? 0 : 1);
-      dev_scalar<unsigned long long> total{0, s};
-      c.total = total.ptr();
-      join::launch_count(c, static_cast<join_args*>(d_args.data()), s);
-      pairs = static_cast<std::size_t>(total.value());
+    join_args c = base_args(left, k == 0 ? 0 : 1);
+    rmm::device_buffer counts{(static_cast<std::size_t>(c.nblocks) + 1) * sizeof(unsigned long long), s,
+                              cudf::get_current_device_resource_ref()};
+    c.block_counts = static_cast<unsigned long long*>(counts.data());
+    join::launch_count(c, static_cast<join_args*>(d_args.data()), s);
+    join::launch_scan(c, s);
+    {
+      unsigned long long total = 0;
+      CUDF_HIP_TRY(hipMemcpyAsync(&total, c.block_counts + c.nblocks, sizeof(total), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipStreamSynchronize(s));
+      pairs = static_cast<std::size_t>(total);
     }
+    if (output_size.has_value() && kind != join_kind::FULL_JOIN)
+      CUDF_EXPECTS(*output_size == pairs, "hash join: output_size does not match the number of matches", std::invalid_argument);
     std::size_t const complement_room = kind == join_kind::FULL_JOIN ? static_cast<std::size_t>(_right.num_rows()) : 0;
     std::size_t const room            = pairs + complement_room;
     CUDF_EXPECTS(room <= static_cast<std::size_t>(std::numeric_limits<size_type>::max()),
@@ -158,8 +170,9 @@ class hash_join_impl {
     auto out_l = std::make_unique<rmm::device_uvector<size_type>>(room, s, mr);
     auto out_r = std::make_unique<rmm::device_uvector<size_type>>(room, s, mr);
     join_args a = base_args(left, k);
-    dev_scalar<unsigned long long> cursor{0, s};
+    dev_scalar<unsigned long long> cursor{static_cast<unsigned long long>(pairs), s};  // complement appends after the pairs
     a.total        = cursor.ptr();
+    a.block_counts = c.block_counts;
     a.out_probe    = out_l->data();
     a.out_build    = out_r->data();
     a.out_capacity = room;
@@ -184,8 +197,7 @@ class hash_join_impl {
       }
       return {std::move(out_l), std::move(out_r)};
     }
-    std::size_t const written = static_cast<std::size_t>(cursor.value());  // also orders d_args' lifetime
-    CUDF_EXPECTS(written == pairs, "hash join: output_size does not match the number of matches", std::invalid_argument);
+    CUDF_HIP_TRY(hipStreamSynchronize(s));  // d_args / counts go out of scope
     return {std::move(out_l), std::move(out_r)};
   }
 
@@ -212,6 +224,11 @@ class hash_join_impl {
     a.check_nulls = _has_nulls && (cudf::has_nulls(_right) || cudf::has_nulls(probe));
     a.kind        = kind;
     a.single64    = !a.check_nulls && is_single64(_right) && is_single64(probe);
+    // one workgroup per contiguous chunk of probe rows (>= 2048 rows each, at most 16 workgroups per CU)
+    int64_t const n = probe.num_rows();
+    a.nblocks       = static_cast<int32_t>(std::clamp<int64_t>((n + 2047) / 2048, 1, 256 * 16));
+    a.chunk         = (n + a.nblocks - 1) / a.nblocks;
+    a.chunk         = (a.chunk + 255) / 256 * 256;
     return a;
   }
 
