@@ -155,6 +155,14 @@ struct part_args {
   int64_t* item_base;          // [nseg*slices][P] exclusive output offsets (records)
   int64_t* out_offsets;        // [nseg*P + 1] partition boundaries (records)
   uint64_t* out_records;
+  // Optimistic single-pass partition (no histogram pass): workgroup w appends partition d's records to its own
+  // fixed-capacity region [(d*slices + w) * region_cap, +region_cap); fill counts go to region_count[d*slices + w].
+  // If any region would overflow (skewed keys) the workgroup raises *overflow before writing and the host redoes
+  // the call with the exact histogram/scan/scatter pipeline.
+  int32_t optimistic;
+  int64_t region_cap;
+  int32_t* region_count;
+  int32_t* overflow;
 };
 
 // Launchers (kernels.hip). All asynchronous on `stream`. Kernel arguments live in DEVICE memory (`d_args`,

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -487,6 +488,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     est_groups = std::max(est_groups, 1.0);
   }
   int64_t const forced_p = env_i64("CUDF_AMD_GB_P", 0);
+  bool allow_optimistic    = env_i64("CUDF_AMD_GB_OPTIMISTIC", 1) != 0;
+  bool const forced_exact  = env_i64("CUDF_AMD_GB_EXACT", 0) != 0;
 
   uint64_t* partial  = nullptr;  // final partial records: item i at [i*cap, i*cap + count[i])
   int32_t* d_count   = nullptr;
@@ -575,12 +578,61 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       pa.from_columns = 1;
       pa.nrows        = n;
       size_t const items1 = static_cast<size_t>(pa.geom.slices);
+      part_args* d_pa     = sc.alloc<part_args>(1);
+      // single-level partitions of big inputs: try the optimistic single-pass partition first
+      // Region sizing: rows of a (slice, partition) cell = sum over the ~G/P keys of the partition of their rows in
+      // the slice; its relative spread has a key-count part 1/sqrt(G/P) (which keys hash there) and a row-sampling
+      // part 1/sqrt(mean). Six sigmas of slack; if that needs more than 2x the memory, use the exact pipeline.
+      double const cell_mean   = static_cast<double>(n) / static_cast<double>(items1) / static_cast<double>(P1);
+      double const keys_per_p  = std::max(1.0, est_groups / static_cast<double>(P1));
+      double const rel_sigma   = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, cell_mean));
+      bool const optimistic = allow_optimistic && P2 == 1 && !forced_exact && n >= (int64_t{1} << 22) && 6.0 * rel_sigma <= 1.0;
+      uint64_t* recA = nullptr;
+      if (optimistic) {
+        int64_t const capR  = (static_cast<int64_t>(cell_mean * (1.0 + 6.0 * rel_sigma) + 16.0) + 7) / 8 * 8;
+        pa.optimistic       = 1;
+        pa.region_cap       = capR;
+        pa.region_count     = sc.alloc<int32_t>(items1 * P1);
+        pa.overflow         = d_overflow;
+        recA                = sc.alloc<uint64_t>(items1 * static_cast<size_t>(P1) * static_cast<size_t>(capR) * RU);
+        pa.out_records      = recA;
+        store_args(pa, d_pa, s);
+        launch_partition_scatter(pa, d_pa, s);
+        if (env_i64("CUDF_AMD_DEBUG", 0)) { CUDF_HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[cudf_amd] optimistic scatter done capR=%ld P=%ld slices=%zu\n", (long)capR, (long)P1, items1); }
+        nitems         = static_cast<int32_t>(P1);
+        partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);
+        d_count        = sc.alloc<int32_t>(nitems);
+        aa.input       = IN_RAW_RECORDS;
+        aa.seg         = SEG_STRIDED;
+        aa.records     = recA;
+        aa.src_count   = pa.region_count;
+        aa.src_stride  = capR;
+        aa.fan         = pa.geom.slices;
+        aa.nsrc        = static_cast<int32_t>(items1 * P1);
+        aa.out_records = partial;
+        aa.out_count   = d_count;
+        aa.nitems      = nitems;
+        launch_aggregate(aa, sc.alloc<agg_args>(1), s);
+        if (env_i64("CUDF_AMD_DEBUG", 0)) { CUDF_HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[cudf_amd] optimistic aggregate done\n"); }
+
+        int32_t h_ov = 0;
+        CUDF_HIP_TRY(hipMemcpyAsync(&h_ov, d_overflow, 4, hipMemcpyDeviceToHost, s));
+        CUDF_HIP_TRY(hipStreamSynchronize(s));
+        if (env_i64("CUDF_AMD_DEBUG", 0)) fprintf(stderr, "[cudf_amd] optimistic overflow flag = %d\n", h_ov);
+        if (h_ov == 0) break;
+        // a region overflowed (skewed keys) or a table did: redo with exact offsets; a table overflow is then
+        // detected again below and handled by the usual escalation
+        allow_optimistic = false;
+        sc.bufs.clear();
+        d_overflow = sc.alloc<int32_t>(1);
+        --attempt;
+        continue;
+      }
       pa.counts       = sc.alloc<uint32_t>(items1 * P1);
       pa.item_base    = sc.alloc<int64_t>(items1 * P1);
       pa.out_offsets  = sc.alloc<int64_t>(P1 + 1);
-      uint64_t* recA  = sc.alloc<uint64_t>(static_cast<size_t>(n) * RU);
+      recA            = sc.alloc<uint64_t>(static_cast<size_t>(n) * RU);
       pa.out_records  = recA;
-      part_args* d_pa = sc.alloc<part_args>(1);
       store_args(pa, d_pa, s);
       launch_partition_hist(pa, d_pa, s);
       launch_partition_scan(pa, d_pa, s);

@@ -433,11 +433,20 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
   }
   // Thread t owns partitions d = t*MAXE + k: their running output cursor lives in registers.
   constexpr int MAXE = 2;  // P <= 2 * B
-  int64_t cursor[MAXE];
+  int64_t cursor[MAXE], region_end[MAXE];
+  int const optimistic = a.optimistic;
+  __shared__ int s_abort;
+  if (threadIdx.x == 0) s_abort = 0;
 #pragma unroll
   for (int k = 0; k < MAXE; ++k) {
     int const d = threadIdx.x * MAXE + k;
-    cursor[k]   = d < P ? a.item_base[static_cast<int64_t>(item) * P + d] : 0;
+    if (optimistic) {
+      cursor[k]     = (static_cast<int64_t>(d) * a.geom.slices + item) * a.region_cap;
+      region_end[k] = cursor[k] + a.region_cap;
+    } else {
+      cursor[k]     = d < P ? a.item_base[static_cast<int64_t>(item) * P + d] : 0;
+      region_end[k] = INT64_MAX;
+    }
     if (d < P) hist[d] = 0;
   }
   __syncthreads();
@@ -510,9 +519,14 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
         delta[d] = cursor[k] - static_cast<int64_t>(run);
         cursor[k] += hv[k];
         run += hv[k];
+        if (cursor[k] > region_end[k]) s_abort = 1;  // optimistic region too small: nothing of this tile is written
       }
     }
     __syncthreads();
+    if (s_abort) {
+      if (threadIdx.x == 0) *a.overflow = 1;
+      return;
+    }
     // phase 3: stage records in partition order
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -549,6 +563,13 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
       }
     }
     __syncthreads();
+  }
+  if (optimistic) {
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      int const d = threadIdx.x * MAXE + k;
+      if (d < P) a.region_count[static_cast<int64_t>(d) * a.geom.slices + item] = static_cast<int32_t>(cursor[k] - (region_end[k] - a.region_cap));
+    }
   }
 }
 
@@ -790,10 +811,18 @@ __global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggr
   if (a.seg == SEG_STRIDED) {
     src0 = item * a.fan;
     nsrc = min(a.fan, a.nsrc - src0);
+    // an upstream kernel (optimistic partition, previous merge round) gave up: its counts are not valid
+    if (*a.overflow != 0) nsrc = 0;
   }
   constexpr int R = (KUT + PAYT <= 2) ? 4 : 2;  // rows in flight per thread
   int64_t const B = blockDim.x;
-  for (int sidx = 0; sidx < nsrc; ++sidx) {
+  // Work is dealt to WAVES in batches of W = R*64 consecutive records. One big segment (a partition, a row chunk):
+  // the waves interleave batches. Many short segments (the per-slice regions of an optimistic partition, the
+  // partial tables of a merge round): each wave takes whole segments, so short segments still run batched.
+  constexpr int64_t W = R * 64;
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  bool const multi = a.seg == SEG_STRIDED;
+  for (int sidx = multi ? wave : 0; sidx < nsrc; sidx += multi ? nwaves : 1) {
     int64_t begin, end;
     if (a.seg == SEG_ROW_CHUNKS) {
       begin = static_cast<int64_t>(item) * a.chunk;
@@ -803,17 +832,18 @@ __global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggr
       end   = a.offsets[item + 1];
     } else {
       begin = static_cast<int64_t>(src0 + sidx) * a.src_stride;
-      end   = begin + a.src_count[src0 + sidx];
+      end   = begin + min<int64_t>(max(a.src_count[src0 + sidx], 0), a.src_stride);
     }
-    int64_t base = begin;
-    // main loop: R full rows per thread, all loads issued before the LDS work
-    for (; base + R * B <= end; base += R * B) {
+    int64_t const nbatches = (end - begin) / W;
+    // main loop: R full rows per lane, all loads issued before the LDS work
+    for (int64_t b = multi ? 0 : wave; b < nbatches; b += multi ? 1 : nwaves) {
+      int64_t const base = begin + b * W;
       uint64_t key[R][KUT];
       uint64_t pay[R][PAYT > 0 ? PAYT : 1];
       uint32_t valvalid[R];
       bool keep[R];
 #pragma unroll
-      for (int k = 0; k < R; ++k) keep[k] = load_row(base + k * B + threadIdx.x, key[k], pay[k], valvalid[k]);
+      for (int k = 0; k < R; ++k) keep[k] = load_row(base + k * 64 + lane, key[k], pay[k], valvalid[k]);
       // Batched first probe: the state word and the stored key words of the home slot of all R rows are read
       // with independent ds_reads (one LDS round trip for the common "group already present" case); only
       // rows that miss walk the full claim/probe protocol.
@@ -852,11 +882,12 @@ __global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggr
           if (hit1 && s0[k] >= 2) sl = slot[k] + 1 == cap ? 0 : slot[k] + 1;
           else sl = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
         }
-        if (sl >= 0) accumulate(base + k * B + threadIdx.x, sl, pay[k], valvalid[k]);
+        if (sl >= 0) accumulate(base + k * 64 + lane, sl, pay[k], valvalid[k]);
       }
     }
-    // tail
-    for (int64_t r = base + threadIdx.x; r < end; r += B) {
+    // tail: the < W records after the last full batch
+    int64_t const tail_begin = begin + nbatches * W;
+    for (int64_t r = tail_begin + (multi ? lane : static_cast<int>(threadIdx.x)); r < end; r += multi ? 64 : B) {
       uint64_t key[KUT];
       uint64_t pay[PAYT > 0 ? PAYT : 1];
       uint32_t valvalid;

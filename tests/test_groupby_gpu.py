@@ -162,6 +162,19 @@ def test_skewed_keys_retry(G, oracle):
     _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all"])])
 
 
+def test_optimistic_partition_and_its_fallback(G, oracle):
+    """n >= 4M rows takes the optimistic single-pass partition (no histogram pass). Uniform keys must stay on it;
+    a heavy-hitter key overflows its fixed-capacity region and must be repaired by the exact pipeline."""
+    rng = np.random.default_rng(17)
+    n = 5_000_000
+    k = rng.integers(0, 200_000, n, dtype=np.int64)
+    v = rng.random(n)
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all", "min"])], expect_path="PARTITIONED_LDS")
+    k2 = k.copy()
+    k2[rng.random(n) < 0.5] = 7  # half of all rows carry one key
+    _check_against_oracle(G, oracle, [k2], [(v, ["sum", "count_all", "max"])], expect_path="PARTITIONED_LDS")
+
+
 def test_two_level_partition_forced(G, oracle, monkeypatch):
     """Forces the two-level radix partition (C4's regime) at a size the oracle can check."""
     rng = np.random.default_rng(13)
