@@ -37,7 +37,13 @@ struct join_args {
   int32_t nblocks;
   int64_t chunk;
   unsigned long long* block_counts;   // [nblocks + 1]; after launch_scan: exclusive offsets, [nblocks] = total
+  // Per-probe-row result of the count pass: MATCH_NONE, or the build row of the first match with bit 31 set when
+  // there are further matches. The retrieve pass streams this array (coalesced) and only re-walks the table for
+  // rows with several matches, instead of repeating 500M random probes (C3: 29 ms -> ~2 ms).
+  uint32_t* match_cache;
 };
+constexpr uint32_t MATCH_NONE  = 0xffffffffu;
+constexpr uint32_t MATCH_MULTI = 0x80000000u;
 
 void launch_build(join_args const& a, join_args* d_args, hipStream_t stream);
 void launch_count(join_args const& a, join_args* d_args, hipStream_t stream);

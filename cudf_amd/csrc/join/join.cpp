@@ -45,7 +45,7 @@ bool same_types(table_view const& a, table_view const& b)
 
 bool is_single64(table_view const& t)
 {
-  if (t.num_columns() != 1 || t.column(0).has_nulls()) return false;
+  if (t.num_columns() != 1) return false;
   auto const id  = t.column(0).type().id();
   auto const cls = class_of(id);
   return size_of_id(id) == 8 && (cls == CLS_SINT || cls == CLS_UINT);
@@ -114,6 +114,9 @@ class hash_join_impl {
     rmm::device_buffer counts{(static_cast<std::size_t>(a.nblocks) + 1) * sizeof(unsigned long long), stream.value(),
                               cudf::get_current_device_resource_ref()};
     a.block_counts = static_cast<unsigned long long*>(counts.data());
+    rmm::device_buffer cache{static_cast<std::size_t>(left.num_rows()) * sizeof(uint32_t), stream.value(),
+                             cudf::get_current_device_resource_ref()};
+    a.match_cache = static_cast<uint32_t*>(cache.data());
     rmm::device_buffer d_args{sizeof(join_args), stream.value(), cudf::get_current_device_resource_ref()};
     join::launch_count(a, static_cast<join_args*>(d_args.data()), stream.value());
     join::launch_scan(a, stream.value());
@@ -152,6 +155,9 @@ class hash_join_impl {
     rmm::device_buffer counts{(static_cast<std::size_t>(c.nblocks) + 1) * sizeof(unsigned long long), s,
                               cudf::get_current_device_resource_ref()};
     c.block_counts = static_cast<unsigned long long*>(counts.data());
+    rmm::device_buffer cache{static_cast<std::size_t>(left.num_rows()) * sizeof(uint32_t), s,
+                             cudf::get_current_device_resource_ref()};
+    c.match_cache = static_cast<uint32_t*>(cache.data());
     join::launch_count(c, static_cast<join_args*>(d_args.data()), s);
     join::launch_scan(c, s);
     {
@@ -173,6 +179,7 @@ class hash_join_impl {
     dev_scalar<unsigned long long> cursor{static_cast<unsigned long long>(pairs), s};  // complement appends after the pairs
     a.total        = cursor.ptr();
     a.block_counts = c.block_counts;
+    a.match_cache  = c.match_cache;
     a.out_probe    = out_l->data();
     a.out_build    = out_r->data();
     a.out_capacity = room;
@@ -223,12 +230,14 @@ class hash_join_impl {
     a.nulls_equal = _nulls_equal == null_equality::EQUAL;
     a.check_nulls = _has_nulls && (cudf::has_nulls(_right) || cudf::has_nulls(probe));
     a.kind        = kind;
-    a.single64    = !a.check_nulls && is_single64(_right) && is_single64(probe);
+    // one 8-byte integer key per side; NULLs are fine as long as they can never match (UNEQUAL): then every key
+    // comparison is between valid values and needs no descriptor walk
+    a.single64    = is_single64(_right) && is_single64(probe) && (!a.check_nulls || !a.nulls_equal);
     // one workgroup per contiguous chunk of probe rows (>= 2048 rows each, at most 16 workgroups per CU)
     int64_t const n = probe.num_rows();
     a.nblocks       = static_cast<int32_t>(std::clamp<int64_t>((n + 2047) / 2048, 1, 256 * 16));
     a.chunk         = (n + a.nblocks - 1) / a.nblocks;
-    a.chunk         = (a.chunk + 255) / 256 * 256;
+    a.chunk         = (a.chunk + 1023) / 1024 * 1024;
     return a;
   }
 
