@@ -26,6 +26,13 @@ constexpr uint32_t ST_LOCKED = 1;
 
 __device__ __forceinline__ uint32_t tag_of(uint64_t h) { return (static_cast<uint32_t>(h >> 20) & ~3u) | 2u; }
 
+// Workgroup barrier that orders LDS traffic only. __syncthreads() makes hipcc emit `s_waitcnt vmcnt(0)` in front
+// of s_barrier, i.e. every wave drains ALL its outstanding global loads and stores at every barrier — in the
+// partition kernel that serialised the tile's HBM traffic with its LDS phases (nothing else hides it at one
+// workgroup per CU). Here global loads/stores stay in flight across the barrier; the compiler still waits on
+// vmcnt where a loaded register is first used.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <typename T>
 __global__ void k_store_args(T v, T* dst)
 {
@@ -263,7 +270,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     if (lane >= o) inc += t;
   }
   if (lane == 63) wave_sums[wave] = inc;
-  __syncthreads();
+  lds_barrier();
   if (wave == 0) {
     uint32_t s = lane < nwaves ? wave_sums[lane] : 0;
 #pragma unroll
@@ -273,10 +280,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
     }
     if (lane < nwaves) wave_sums[lane] = s;  // inclusive
   }
-  __syncthreads();
+  lds_barrier();
   uint32_t const wave_off = wave == 0 ? 0 : wave_sums[wave - 1];
   total                   = wave_sums[nwaves - 1];
-  __syncthreads();
+  lds_barrier();
   return wave_off + inc - v;
 }
 
@@ -449,7 +456,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
     }
     if (d < P) hist[d] = 0;
   }
-  __syncthreads();
+  lds_barrier();
 
   uint64_t rec[RPT][UT];
   bool keep[RPT];
@@ -500,7 +507,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
         rank[k] = atomicAdd(&hist[dig[k]], 1u);
       }
     }
-    __syncthreads();
+    lds_barrier();
     // phase 2: hist -> exclusive local offsets (in place); delta = global cursor - local offset
     uint32_t hv[MAXE], local = 0;
 #pragma unroll
@@ -522,7 +529,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
         if (cursor[k] > region_end[k]) s_abort = 1;  // optimistic region too small: nothing of this tile is written
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (s_abort) {
       if (threadIdx.x == 0) *a.overflow = 1;
       return;
@@ -545,7 +552,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
     // the records are staged: the registers are free, so the NEXT tile's loads go out now and fly under the
     // write-out phase (one workgroup per CU: nothing else would hide their latency)
     if (tile + T < sr.end) load_tile(tile + T);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) {
       int const d = threadIdx.x * MAXE + k;
@@ -562,7 +569,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
           if (u < U) gstore(out_records + dst * U + u, stage[static_cast<size_t>(j) * U + u]);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (optimistic) {
 #pragma unroll
