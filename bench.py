@@ -104,7 +104,12 @@ def main():
     vals = torch.rand(n, generator=gen, device=dev, dtype=torch.float64)
     stream = torch.cuda.current_stream()
 
-    if world == 1:
+    force_dist = os.environ.get("BENCH_FORCE_DISTRIBUTED") == "1"  # rehearse the N>1 code path on one GPU
+    if world == 1 and force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    if world == 1 and not force_dist:
         kcol, vcol = cudf_amd.Column.from_torch(keys), cudf_amd.Column.from_torch(vals)
 
         def step():
@@ -115,7 +120,7 @@ def main():
         from cudf_amd import distributed as D
 
         def step():
-            return D.distributed_groupby_sum_count(keys, vals, stream=stream)
+            return D.distributed_groupby_sum_count(keys, vals, stream=stream, mode=os.environ.get("BENCH_DIST_MODE", "shuffle"))
 
     def barrier():
         if world > 1:
@@ -141,6 +146,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # N > 1: also time the decomposable variant (local groupby -> all-to-all of the partials -> merge); reported next
+    # to the config-5 number, never instead of it.
+    pre = None
+    if world > 1 or force_dist:
+        from cudf_amd import distributed as D2
+
+        def pre_step():
+            return D2.distributed_groupby_sum_count(keys, vals, stream=stream, mode="preaggregate")
+
+        pre_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pre_step()
+        barrier()
+        tp = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        pre = float(tp.item())
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         total_rows = n * world
@@ -165,13 +190,18 @@ def main():
                                     if world == 1 else
                                     "C5: hash-range partition + RCCL all-to-all + per-GPU groupby SUM+COUNT_VALID"),
                        "rows_per_gpu": n, "groups": groups, "key": "int64 uniform [0, groups)", "value": "float64 uniform [0,1)",
-                       "path": (last[0].last_path.name if world == 1 else "PARTITION+ALLTOALL+GROUPBY")},
+                       "path": (last[0].last_path.name if (world == 1 and not force_dist) else "PARTITION+ALLTOALL+GROUPBY:" + os.environ.get("BENCH_DIST_MODE", "shuffle"))},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if pre is not None:
+            line["preaggregated_variant"] = {"value": total_rows * args.steps / pre, "unit": "rows/s",
+                                             "ms_per_step": pre / args.steps * 1e3,
+                                             "what": "local groupby -> hash-partition + RCCL all-to-all of the partial "
+                                                     "(key, sum, count) rows -> merge; same result, xGMI carries MBs"}
+        if world == 1 and not force_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(groups, args.cpu_sample_rows)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

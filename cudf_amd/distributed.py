@@ -49,9 +49,15 @@ class GpuBackend:
         return uk.columns()[0].to_torch(), sums, cnt
 
 
-def exchange(columns, offsets, group=None):
+# RCCL (2.26, ROCm 7.0) silently truncates all_to_all_single messages beyond 2^31 bytes per peer (measured: a
+# 2.4 GB self-exchange returned half of the rows as zeros), so big columns go in rounds of bounded messages.
+MAX_MESSAGE_BYTES = 1 << 30
+
+
+def exchange(columns, offsets, group=None, max_message_bytes=None):
     """All-to-all-v of partitioned columns. `offsets[p]` = first row of the slice destined for rank p.
-    -> list of received tensors (rows from rank 0, then rank 1, ...)."""
+    -> list of received tensors (rows from rank 0, then rank 1, ...). No message exceeds max_message_bytes."""
+    limit = max_message_bytes or MAX_MESSAGE_BYTES
     world = dist.get_world_size(group)
     n = columns[0].numel()
     bounds = list(offsets) + [n]
@@ -60,30 +66,58 @@ def exchange(columns, offsets, group=None):
     sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
     rc = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_to_all_single(rc, sc, group=group)
+    biggest = torch.max(torch.stack([sc.max(), rc.max()])).reshape(1)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)  # every rank runs the same number of rounds
     recv_counts = [int(x) for x in rc.tolist()]
+    biggest = int(biggest.item())
     total = sum(recv_counts)
+    soff = bounds[:-1]
+    roff = [0] * world
+    for p in range(1, world):
+        roff[p] = roff[p - 1] + recv_counts[p - 1]
+    list_ok = dist.get_backend(group) == "nccl"  # gloo has no list all_to_all
     out = []
     for c in columns:
         r = torch.empty(total, dtype=c.dtype, device=dev)
-        dist.all_to_all_single(r, c, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+        chunk = max(1, limit // c.element_size())
+        rounds = max(1, -(-biggest // chunk))
+        if rounds == 1:
+            dist.all_to_all_single(r, c, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+        else:
+            for k in range(rounds):
+                ins = [c[soff[p] + min(k * chunk, send_counts[p]): soff[p] + min((k + 1) * chunk, send_counts[p])]
+                       for p in range(world)]
+                outs = [r[roff[p] + min(k * chunk, recv_counts[p]): roff[p] + min((k + 1) * chunk, recv_counts[p])]
+                        for p in range(world)]
+                if list_ok:
+                    dist.all_to_all(outs, ins, group=group)  # views: no staging copies
+                else:
+                    packed = torch.empty(sum(o.numel() for o in outs), dtype=c.dtype, device=dev)
+                    dist.all_to_all_single(packed, torch.cat(ins), output_split_sizes=[o.numel() for o in outs],
+                                           input_split_sizes=[i.numel() for i in ins], group=group)
+                    pos = 0
+                    for o in outs:
+                        o.copy_(packed[pos:pos + o.numel()])
+                        pos += o.numel()
         out.append(r)
     return out
 
 
-def distributed_groupby_sum_count(keys, vals, stream=None, mode="shuffle", backend=None, group=None):
+def distributed_groupby_sum_count(keys, vals, stream=None, mode="shuffle", backend=None, group=None,
+                                  max_message_bytes=None):
     """Global SUM(vals) and COUNT per key over all ranks; every rank returns the groups it owns
     (keys, sums, counts). The union over ranks is the global result; ownership is by key hash."""
     backend = backend or GpuBackend(stream)
     world = dist.get_world_size(group)
     if mode == "shuffle":
         cols, offs = backend.partition([keys, vals], world)
-        rk, rv = exchange(cols, offs, group)
+        rk, rv = exchange(cols, offs, group, max_message_bytes)
         k, sums, cnt = backend.groupby_sum(rk, [rv], count=True)
         return k, sums[0], cnt
     if mode == "preaggregate":
         k, sums, cnt = backend.groupby_sum(keys, [vals], count=True)
         cols, offs = backend.partition([k, sums[0], cnt.to(torch.int64)], world)
-        rk, rs, rc = exchange(cols, offs, group)
+        rk, rs, rc = exchange(cols, offs, group, max_message_bytes)
         k2, sums2, _ = backend.groupby_sum(rk, [rs, rc], count=False)
         return k2, sums2[0], sums2[1]
     raise ValueError(f"unknown mode {mode!r}")

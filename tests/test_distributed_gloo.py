@@ -33,7 +33,7 @@ class HostBackend:
         return torch.from_numpy(kc[0][0].copy()), sums, cnt
 
 
-def _worker(rank, world, port, mode, out_dir):
+def _worker(rank, world, port, mode, out_dir, max_message_bytes=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -44,7 +44,8 @@ def _worker(rank, world, port, mode, out_dir):
         n = 20_000 + 1000 * rank  # ragged shards
         keys = torch.from_numpy(rng.integers(0, 3000, n, dtype=np.int64))
         vals = torch.from_numpy(rng.random(n))
-        k, s, c = D.distributed_groupby_sum_count(keys, vals, mode=mode, backend=HostBackend())
+        k, s, c = D.distributed_groupby_sum_count(keys, vals, mode=mode, backend=HostBackend(),
+                                                  max_message_bytes=max_message_bytes)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), k=k.numpy(), s=s.numpy(), c=c.numpy(), keys=keys.numpy(), vals=vals.numpy())
     finally:
         dist.destroy_process_group()
@@ -58,10 +59,11 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("mode", ["shuffle", "preaggregate"])
-def test_two_rank_groupby(tmp_path, mode):
+@pytest.mark.parametrize("mode,max_message_bytes", [("shuffle", None), ("preaggregate", None), ("shuffle", 16 * 1024)])
+def test_two_rank_groupby(tmp_path, mode, max_message_bytes):
+    """max_message_bytes=16 KiB forces the multi-round exchange (RCCL truncates messages > 2^31 bytes)."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), max_message_bytes), nprocs=world, join=True)
     parts = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     # ownership is disjoint
     assert len(np.intersect1d(parts[0]["k"], parts[1]["k"])) == 0
