@@ -176,8 +176,16 @@ def main():
             name, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
             avg_ms = total_ms / launches
             achieved = BYTES_PER_ROW * n / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            try:  # PMC traffic of this kernel at this workload, collected with rocprofv3 (see the file's "how")
+                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                    pmc = json.load(f)["kernels"]
+                if name in pmc and n == 1_000_000_000 and groups == 1_000_000:
+                    traffic = pmc[name]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": BYTES_PER_ROW * n,
                     "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items())},
                     "whole_call_frac": BYTES_PER_ROW * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
