@@ -78,14 +78,18 @@ enum out_kind : int8_t {
   OUT_KEY = 0,    // key column `a0` (index into plan cols)
   OUT_ACC,        // accumulator a0 cast to the target type
   OUT_MEAN,       // double(acc a0) / acc a1   (a0 class in `cls`)
-  OUT_COUNT       // accumulator a0 as INT32
+  OUT_COUNT,      // accumulator a0 as INT32
+  OUT_M2,         // double(a0 = sum of squares) - double(a1 = sum)^2 / (a2 = count); 0 for an empty group
+  OUT_VAR,        // M2 / (count - ddof); null when count - ddof <= 0
+  OUT_STD         // sqrt(VAR)
 };
 struct out_desc {
   void* data;
   bitmask_type* mask;   // nullptr: not nullable
   int32_t* null_count;  // device counter (nullable columns only)
   int8_t kind;
-  int8_t a0, a1;
+  int8_t a0, a1, a2;
+  int8_t ddof;
   int8_t valid_acc;     // accumulator whose value > 0 means valid (-1: always valid)
   int8_t cls;           // accumulator class of a0: elem_class (SINT/UINT/F64)
   int8_t width;         // output element width

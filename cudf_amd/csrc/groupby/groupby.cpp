@@ -178,7 +178,10 @@ bool is_engine_kind(aggregation::Kind k)
     case aggregation::COUNT_VALID:
     case aggregation::COUNT_ALL:
     case aggregation::MEAN:
-    case aggregation::SUM_OF_SQUARES: return true;
+    case aggregation::SUM_OF_SQUARES:
+    case aggregation::M2:
+    case aggregation::VARIANCE:
+    case aggregation::STD: return true;
     default: return false;
   }
 }
@@ -187,7 +190,8 @@ struct result_spec {  // one per (request, aggregation)
   aggregation::Kind kind;
   data_type target;
   int value_idx;  // distinct value column
-  int a0{-1}, a1{-1}, valid_acc{-1};
+  int a0{-1}, a1{-1}, a2{-1}, valid_acc{-1};
+  int ddof{1};
   bool nullable{false};
   int acc_cls{0};
 };
@@ -361,6 +365,18 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
           rs.a0 = sum_acc(SRC_VALUE);
           rs.a1 = count_valid_acc();
           break;
+        case aggregation::M2:
+        case aggregation::VARIANCE:
+        case aggregation::STD: {
+          // reference extract_single_pass_aggs.cpp:26-177: {SUM_OF_SQUARES, SUM, COUNT_VALID}
+          rs.a0       = sum_acc(SRC_SQUARE);
+          rs.a1       = sum_acc(SRC_VALUE);
+          rs.a2       = count_valid_acc();
+          rs.nullable = agg->kind != aggregation::M2;  // M2 is never null; VAR/STD get a mask from the counts
+          if (auto const* dd = dynamic_cast<cudf::detail::ddof_aggregation const*>(agg.get())) rs.ddof = dd->_ddof;
+          hp.results.push_back(rs);
+          continue;
+        }
         default: CUDF_FAIL("Unsupported aggregation on the hash path.");
       }
       if (rs.nullable) rs.valid_acc = count_valid_acc();
@@ -570,7 +586,10 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       part_args pa{};
       pa.plan         = p;
       pa.geom.nseg    = 1;
-      pa.geom.slices  = static_cast<int32_t>(env_i64("CUDF_AMD_GB_SLICES", 512));
+      // optimistic: one persistent workgroup per CU (longer regions for the aggregate); exact: 2 per CU (the
+      // histogram pass wants the parallelism: 1.6 ms at 512 slices vs 2.7 ms at 256)
+      bool const will_try_optimistic = allow_optimistic && P2 == 1 && !forced_exact && n >= (int64_t{1} << 22);
+      pa.geom.slices  = static_cast<int32_t>(env_i64("CUDF_AMD_GB_SLICES", will_try_optimistic ? 256 : 512));
       pa.geom.P       = static_cast<int32_t>(P1);
       pa.geom.shift   = 64 - log2P1;
       pa.geom.block   = 1024;
@@ -747,9 +766,14 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     d.null_count = d_nulls + fin.nout;
     d.kind       = (rs.kind == aggregation::COUNT_VALID || rs.kind == aggregation::COUNT_ALL) ? OUT_COUNT
                    : rs.kind == aggregation::MEAN                                              ? OUT_MEAN
+                   : rs.kind == aggregation::M2                                                ? OUT_M2
+                   : rs.kind == aggregation::VARIANCE                                          ? OUT_VAR
+                   : rs.kind == aggregation::STD                                               ? OUT_STD
                                                                                                : OUT_ACC;
     d.a0         = static_cast<int8_t>(rs.a0);
     d.a1         = static_cast<int8_t>(rs.a1);
+    d.a2         = static_cast<int8_t>(rs.a2);
+    d.ddof       = static_cast<int8_t>(rs.ddof);
     d.valid_acc  = static_cast<int8_t>(rs.valid_acc);
     d.cls        = static_cast<int8_t>(rs.acc_cls);
     d.width      = static_cast<int8_t>(size_of(rs.target));

@@ -967,6 +967,26 @@ __global__ void __launch_bounds__(256) k_finalize(finalize_args const* __restric
         if (d.valid_acc >= 0) valid = static_cast<int64_t>(rec[p.KU + d.valid_acc]) > 0;
         if (d.kind == OUT_COUNT) {
           bits = a0;
+        } else if (d.kind == OUT_M2 || d.kind == OUT_VAR || d.kind == OUT_STD) {
+          // reference groupby/common/m2_var_std.cu:48-60,152-187
+          auto as_double = [&](uint64_t v) {
+            return d.cls == cudf::detail::CLS_F64 ? __longlong_as_double(static_cast<long long>(v))
+                                                  : static_cast<double>(static_cast<int64_t>(v));
+          };
+          int64_t const cnt = static_cast<int64_t>(rec[p.KU + d.a2]);
+          double const ssq  = as_double(a0);
+          double const sm   = as_double(rec[p.KU + d.a1]);
+          double const m2   = cnt > 0 ? ssq - sm * sm / static_cast<double>(cnt) : 0.0;
+          double out        = m2;
+          if (d.kind != OUT_M2) {
+            int64_t const df = cnt - d.ddof;
+            valid            = cnt > 0 && df > 0;
+            out              = valid ? m2 / static_cast<double>(df) : 0.0;
+            if (d.kind == OUT_STD) out = sqrt(out);
+          } else {
+            valid = true;
+          }
+          bits = static_cast<uint64_t>(__double_as_longlong(out));
         } else if (d.kind == OUT_MEAN) {
           // MEAN = double(SUM) / COUNT_VALID as FLOAT64 (reference hash_compound_agg_finalizer.cu:92-133)
           double const s = d.cls == cudf::detail::CLS_F64 ? __longlong_as_double(static_cast<long long>(a0))

@@ -390,18 +390,20 @@ int orc_groupby(const orc_column* keys, int32_t nkeys, int32_t include_null_keys
             if (acc[g].arg < 0 || better) { acc[g].arg = i; acc[g].f = x; acc[g].i = xi; acc[g].u = xu; }
             break;
           }
-          case K_M2: case K_VARIANCE: case K_STD: {
-            double d = x - acc[g].mean_;
-            acc[g].mean_ += d / (double)acc[g].nvalid;
-            acc[g].m2_ += d * (x - acc[g].mean_);
+          case K_M2: case K_VARIANCE: case K_STD:
+            /* hash path: M2/VARIANCE/STD are built from SUM_OF_SQUARES, SUM and COUNT_VALID in their target
+             * types (extract_single_pass_aggs.cpp:26-177): int64 wrapping for integral sources, fp otherwise */
+            acc[g].f += x; acc[g].i = (int64_t)((uint64_t)acc[g].i + (uint64_t)xi);
+            acc[g].m2_ += x * x; acc[g].u = acc[g].u + (uint64_t)xi * (uint64_t)xi;
             break;
-          }
           default: break;
         }
       }
       /* Rule 5: result nullable iff kind is not COUNT and values.has_nulls() (output_utils.cu:67-86). */
       int is_count = (kind == K_COUNT_VALID || kind == K_COUNT_ALL);
       int nullable = !is_count && v->null_count > 0;
+      if (kind == K_M2) nullable = 0;                      /* make_numeric_column without a mask */
+      if (kind == K_VARIANCE || kind == K_STD) nullable = 1; /* mask rebuilt from the group counts */
       orc_out_column* o = &res->results[oc];
       out_col_alloc(o, tgt, G, nullable);
       int tcls = type_class(tgt);
@@ -429,11 +431,17 @@ int orc_groupby(const orc_column* keys, int32_t nkeys, int32_t include_null_keys
             store_float(o, g, valid ? s / (double)acc[g].nvalid : 0.0);
             break;
           }
-          case K_M2: valid = acc[g].nvalid > 0; store_float(o, g, acc[g].m2_); break;
-          case K_VARIANCE: case K_STD: {
-            /* ddof = 1 (aggregation.hpp make_variance/std default); null when count <= ddof */
+          case K_M2: case K_VARIANCE: case K_STD: {
+            /* m2 = sum_sqr - sum*sum/count, 0 for an empty group (groupby/common/m2_var_std.cu:48-60);
+             * variance = m2 / (count - ddof), std = sqrt(variance), null when count == 0 or count - ddof <= 0
+             * (:152-187); ddof = 1 (aggregation.hpp default). M2 itself is never null. */
+            int is_f = (cls == C_F32 || cls == C_F64);
+            double ssq = is_f ? acc[g].m2_ : (double)(int64_t)acc[g].u;
+            double sm  = is_f ? acc[g].f : (double)acc[g].i;
+            double m2  = acc[g].nvalid > 0 ? ssq - sm * sm / (double)acc[g].nvalid : 0.0;
+            if (kind == K_M2) { valid = 1; store_float(o, g, m2); break; }
             valid = acc[g].nvalid > 1;
-            double var = valid ? acc[g].m2_ / (double)(acc[g].nvalid - 1) : 0.0;
+            double var = valid ? m2 / (double)(acc[g].nvalid - 1) : 0.0;
             store_float(o, g, kind == K_STD ? sqrt(var) : var);
             break;
           }

@@ -130,6 +130,30 @@ def test_key_types(G, oracle, kt):
         _check_against_oracle(G, oracle, [HostColumn(k, kv, kt)], [(v, ["sum", "count_all"])], include=include)
 
 
+@pytest.mark.parametrize("vt", ["int32", "int64", "float64", "float32"])
+def test_variance_std_m2(G, oracle, vt):
+    """M2 / VARIANCE / STD on the hash path = SUM_OF_SQUARES, SUM, COUNT_VALID combined as the reference does
+    (groupby/common/m2_var_std.cu:48-60,152-187); groups of one row give null VARIANCE/STD (ddof = 1)."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(21)
+    n = 60_000
+    k = rng.integers(0, 400, n, dtype=np.int64)
+    k[:50] = np.arange(1000, 1050)  # singleton groups
+    npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
+    v = (rng.random(n) * 20 - 10).astype(npt) if np.dtype(npt).kind == "f" else rng.integers(-50, 50, n).astype(npt)
+    vv = rng.random(n) > 0.1
+    got = kat.sort_groups(*G.groupby([k], [(HostColumn(v, vv, vt), ["m2", "variance", "std", "sum_of_squares"])]))
+    exp = kat.sort_groups(*oracle.groupby([k], [(HostColumn(v, vv, vt), ["m2", "variance", "std", "sum_of_squares"])]))
+    kat.compare_columns(got[0][0], exp[0][0], "keys")
+    m = 400  # rows per group upper bound (n / 400 groups ~ 150, generous)
+    # sumsq - sum^2/n cancels: both sides carry rounding of order eps * m * max(v)^2 (float32 inputs: our float64
+    # accumulation vs the float32 of the reference differs by float32 rounding of each square)
+    tol = kat.sum_atol(m, 100.0) * (1e7 if vt == "float32" else 1.0)
+    for name, a, e in zip(["m2", "variance", "std", "sum_of_squares"], got[1][0], exp[1][0]):
+        kat.compare_columns(a, e, name, atol=tol)
+    assert got[1][0][1][1] is not None and not got[1][0][1][1].all()  # singleton groups -> null variance
+
+
 def test_sliced_columns_offset(G, oracle):
     """Arrow offset: element i at data[offset+i], validity at bit offset+i."""
     from oracle.oracle import HostColumn
