@@ -70,6 +70,7 @@ struct plan_dev {
   // Fast path: every record unit is an 8-byte column without nulls that needs no conversion or normalisation
   // (int64/uint64/float64 values, 8-byte integer keys): unit u of row r is simple_base[u][r].
   int32_t simple;
+  int32_t simple_vec16;  // every simple_base pointer is 16-byte aligned: rows can be loaded two at a time (dwordx4)
   uint64_t const* simple_base[MAX_UNITS];
 };
 
@@ -167,6 +168,8 @@ struct part_args {
   int64_t region_cap;
   int32_t* region_count;
   int32_t* overflow;
+  // diagnostics (CUDF_AMD_GB_STAMPS=1): per-workgroup cycle totals of the tile phases, 8 x u64 per workgroup
+  unsigned long long* stamps;
 };
 
 // Launchers (kernels.hip). All asynchronous on `stream`. Kernel arguments live in DEVICE memory (`d_args`,

@@ -396,6 +396,12 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
     p.simple_base[w] = static_cast<uint64_t const*>(c.head) + c.offset;
   }
   if (env_i64("CUDF_AMD_GB_NO_SIMPLE", 0)) p.simple = 0;
+  p.simple_vec16 = p.simple;
+  for (int w = 0; p.simple && w < p.KU + p.NPAY; ++w)
+    if (reinterpret_cast<uintptr_t>(p.simple_base[w]) % 16 != 0) p.simple_vec16 = 0;
+  // measured slower than 8-byte loads in both the histogram (1.85 vs 1.6 ms) and the scatter (25.5M vs 22.2M
+  // cycles per workgroup): opt-in only
+  if (!env_i64("CUDF_AMD_GB_VEC16", 0)) p.simple_vec16 = 0;
   return hp;
 }
 
@@ -615,8 +621,19 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         pa.overflow         = d_overflow;
         recA                = sc.alloc<uint64_t>(items1 * static_cast<size_t>(P1) * static_cast<size_t>(capR) * RU);
         pa.out_records      = recA;
+        if (env_i64("CUDF_AMD_GB_STAMPS", 0)) pa.stamps = sc.alloc<unsigned long long>(items1 * 8);
         store_args(pa, d_pa, s);
         launch_partition_scatter(pa, d_pa, s);
+        if (pa.stamps != nullptr) {
+          std::vector<unsigned long long> h(items1 * 8);
+          CUDF_HIP_TRY(hipMemcpyAsync(h.data(), pa.stamps, h.size() * 8, hipMemcpyDeviceToHost, s));
+          CUDF_HIP_TRY(hipStreamSynchronize(s));
+          double tot[8] = {0};
+          for (size_t w = 0; w < items1; ++w) for (int i = 0; i < 8; ++i) tot[i] += static_cast<double>(h[w * 8 + i]);
+          double all = 0; for (double t : tot) all += t;
+          fprintf(stderr, "[cudf_amd] scatter phase shares (wave 0 of each WG, s_memtime): rank %.1f%% | barrier %.1f%% | scan %.1f%% | stage %.1f%% | prefetch-issue %.1f%% | barrier %.1f%% | write-out %.1f%% | barrier %.1f%%  (avg cycles/WG %.0f)\n",
+                  100 * tot[0] / all, 100 * tot[1] / all, 100 * tot[2] / all, 100 * tot[3] / all, 100 * tot[4] / all, 100 * tot[5] / all, 100 * tot[6] / all, 100 * tot[7] / all, all / items1);
+        }
         if (env_i64("CUDF_AMD_DEBUG", 0)) { CUDF_HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[cudf_amd] optimistic scatter done capR=%ld P=%ld slices=%zu\n", (long)capR, (long)P1, items1); }
         nitems         = static_cast<int32_t>(P1);
         partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);

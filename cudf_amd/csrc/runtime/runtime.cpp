@@ -383,6 +383,24 @@ void pool_memory_resource::do_deallocate(void* p, std::size_t, hipStream_t strea
   (void)hipEventRecord(b.freed, stream);
   _impl->free_lists[b.size].push_back(b);
   _impl->cached += b.size;
+  // Bound what the cache may hold (every distinct rounded size keeps its own list): beyond the limit
+  // (CUDF_AMD_POOL_MAX_CACHED_GB, default 128 of the 288 GB) everything cached goes back to the driver.
+  static std::size_t const limit = [] {
+    char const* e = std::getenv("CUDF_AMD_POOL_MAX_CACHED_GB");
+    std::size_t const gb = (e != nullptr && *e != 0) ? std::strtoull(e, nullptr, 10) : 128;
+    return gb << 30;
+  }();
+  if (_impl->cached > limit) {
+    for (auto& [sz, v] : _impl->free_lists) {
+      for (auto& blk : v) {
+        (void)hipEventSynchronize(blk.freed);
+        (void)hipEventDestroy(blk.freed);
+        (void)hipFree(blk.ptr);
+      }
+    }
+    _impl->free_lists.clear();
+    _impl->cached = 0;
+  }
 }
 
 namespace {
