@@ -1,0 +1,588 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 aggregation kernels of the hash-groupby engine: LDS hash-table aggregate, finalize, cardinality estimate.
+#include "device_common.hpp"
+
+namespace cudf::groupby::detail {
+namespace {
+// ------------------------------------------------------------------ K_aggregate
+__device__ __forceinline__ uint64_t acc_identity(int op)
+{
+  switch (op) {
+    case MIN_I64: return static_cast<uint64_t>(INT64_MAX);
+    case MIN_U64: return UINT64_MAX;
+    case MIN_F64: return 0x7ff0000000000000ull;  // +inf
+    case MAX_I64: return static_cast<uint64_t>(INT64_MIN);
+    case MAX_U64: return 0;
+    case MAX_F64: return 0xfff0000000000000ull;  // -inf
+    default: return 0;                            // ADD_I64 / ADD_F64
+  }
+}
+
+__device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
+{
+  switch (op) {
+    case ADD_I64: atomicAdd(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case ADD_F64: atomicAdd(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v))); break;
+    case MIN_I64: atomicMin(reinterpret_cast<long long*>(slot), static_cast<long long>(v)); break;
+    case MIN_U64: atomicMin(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case MAX_I64: atomicMax(reinterpret_cast<long long*>(slot), static_cast<long long>(v)); break;
+    case MAX_U64: atomicMax(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case MIN_F64:
+      __hip_atomic_fetch_min(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    case MAX_F64:
+      __hip_atomic_fetch_max(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+  }
+}
+
+// Finds or claims the slot of `key` in the LDS table. Returns -1 if the table is saturated.
+template <int KUT>
+__device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask)[KUT], uint32_t* st, uint64_t* keys,
+                                                  int cap, uint64_t const (&key)[KUT], uint64_t h, uint32_t* nfilled,
+                                                  int fill_limit, int32_t* overflow_flag)
+{
+  uint32_t const tag = tag_of(h);
+  int slot = static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(h)) * static_cast<uint32_t>(cap)) >> 32);
+  for (int probes = 0; probes < cap; ++probes) {
+    uint32_t s = __hip_atomic_load(&st[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (s == ST_EMPTY) {
+      uint32_t const old = atomicCAS(&st[slot], ST_EMPTY, ST_LOCKED);
+      if (old == ST_EMPTY) {
+#pragma unroll
+        for (int u = 0; u < KUT; ++u)
+          if (u < KU) keys[static_cast<uint32_t>(u * cap + slot)] = key[u] & kmask[u];
+        // publish: key words first, then the tag (LDS executes a wave's accesses in order; the release fence
+        // keeps the compiler from reordering and waits for the key stores)
+        __hip_atomic_store(&st[slot], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t const n = atomicAdd(nfilled, 1u);
+        if (static_cast<int>(n) >= fill_limit) *overflow_flag = 1;
+        return slot;
+      }
+      s = old;
+    }
+    if (s == ST_LOCKED) {
+      --probes;  // owner is publishing: re-read the same slot
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    if (s == tag) {
+      bool eq = true;
+#pragma unroll
+      for (int u = 0; u < KUT; ++u)
+        if (u < KU) eq = eq && (keys[static_cast<uint32_t>(u * cap + slot)] == (key[u] & kmask[u]));
+      if (eq) return slot;
+    }
+    slot = slot + 1 == cap ? 0 : slot + 1;
+  }
+  *overflow_flag = 1;
+  return -1;
+}
+
+// INPUT: agg_input. KUT: key units held in registers. PAYT: payload units of a RECORD prefetched into
+// registers together with the key (0 = payload fetched lazily per accumulator: column input, wide records).
+// NACCT: compile-time bound of the accumulator loop (descriptors sit in registers, statically indexed).
+// EXACT: the input record has exactly KUT + PAYT units (a 16-byte record is one global_load_dwordx4).
+// SIG: compile-time accumulator signature (0 = read the descriptors at run time). For the hot shapes every
+// descriptor test folds away and the accumulate step is straight-line ds_* atomics: the generic form spends
+// ~200 scalar instructions per 64 rows on descriptor branches and is bound by the CU's single scalar ALU.
+// 12 bits per accumulator: op(4) | src(2) | pay+1 (3) | vbit+1 (3); accumulator count in bits 60..63.
+constexpr uint64_t sig_acc(int op, int src, int pay, int vbit)
+{
+  return static_cast<uint64_t>(op) | (static_cast<uint64_t>(src) << 4) | (static_cast<uint64_t>(pay + 1) << 6) |
+         (static_cast<uint64_t>(vbit + 1) << 9);
+}
+constexpr uint64_t make_sig(int n, uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, uint64_t a3 = 0)
+{
+  return (static_cast<uint64_t>(n) << 60) | a0 | (a1 << 12) | (a2 << 24) | (a3 << 36);
+}
+constexpr int sig_n(uint64_t s) { return static_cast<int>(s >> 60); }
+constexpr int sig_op(uint64_t s, int q) { return static_cast<int>((s >> (12 * q)) & 0xf); }
+constexpr int sig_src(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 4)) & 0x3); }
+constexpr int sig_pay(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 6)) & 0x7) - 1; }
+constexpr int sig_vbit(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 9)) & 0x7) - 1; }
+
+template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT, uint64_t SIG = 0>
+__global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggregate(agg_args const* __restrict__ ap)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  agg_args const& a = *ap;
+  plan_dev const& p = a.plan;
+  int const cap     = a.geom.cap;
+  constexpr bool STATIC_SIG = SIG != 0;
+  int const KU = EXACT ? KUT : p.KU, NACC = STATIC_SIG ? sig_n(SIG) : p.NACC;
+  uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);                 // [KU][cap]
+  uint64_t* accs = keys + static_cast<size_t>(KU) * cap;                   // [NACC][cap]
+  uint32_t* st   = reinterpret_cast<uint32_t*>(accs + static_cast<size_t>(NACC) * cap);  // [cap]
+  __shared__ uint32_t s_nfilled, s_dump;
+  __shared__ int32_t s_overflow;
+
+  if (threadIdx.x == 0) {
+    s_nfilled  = 0;
+    s_dump     = 0;
+    s_overflow = 0;
+  }
+  for (int s = threadIdx.x; s < cap; s += blockDim.x) st[s] = ST_EMPTY;
+  for (int q = 0; q < NACC; ++q) {
+    uint64_t const id = acc_identity(p.acc[q].op);
+    for (int s = threadIdx.x; s < cap; s += blockDim.x) accs[static_cast<size_t>(q) * cap + s] = id;
+  }
+  uint64_t kmask[KUT];
+#pragma unroll
+  for (int u = 0; u < KUT; ++u) kmask[u] = u < KU ? p.key_mask[u] : 0;
+  // accumulator descriptors live in (scalar) registers for the whole kernel: no memory access per row
+  int acc_op[NACCT], acc_src[NACCT], acc_pay[NACCT], acc_vbit[NACCT];
+#pragma unroll
+  for (int j = 0; j < NACCT; ++j) {
+    uint32_t const w = j < NACC ? reinterpret_cast<uint32_t const*>(p.acc)[j] : 0u;
+    acc_op[j]        = STATIC_SIG ? sig_op(SIG, j) : static_cast<int8_t>(w);
+    acc_src[j]       = STATIC_SIG ? sig_src(SIG, j) : static_cast<int8_t>(w >> 8);
+    acc_pay[j]       = STATIC_SIG ? sig_pay(SIG, j) : static_cast<int8_t>(w >> 16);
+    acc_vbit[j]      = STATIC_SIG ? sig_vbit(SIG, j) : static_cast<int8_t>(w >> 24);
+  }
+  __syncthreads();
+
+  int const item  = blockIdx.x;
+  int const RU    = KU + p.NPAY;  // raw record units
+  int const PU    = KU + NACC;    // partial record units
+  int const U     = EXACT ? (KUT + PAYT) : (INPUT == IN_RAW_RECORDS ? RU : PU);
+  int const fill_limit = a.geom.fill_limit;
+  int const flags_unit = p.flags_unit, flags_hi = p.flags_hi;
+  uint64_t const* records = a.records;
+
+  // accumulators of one row whose LDS slot is known
+  auto accumulate = [&](int64_t r, int slot, uint64_t const (&pay)[PAYT > 0 ? PAYT : 1], uint32_t valvalid) {
+    int last_pay   = -1;
+    uint64_t value = 0;
+#pragma unroll
+    for (int q = 0; q < NACCT; ++q) {
+      if (q >= NACC) break;
+      uint64_t* tgt = accs + (static_cast<uint32_t>(q) * static_cast<uint32_t>(cap) + static_cast<uint32_t>(slot));
+      if constexpr (INPUT == IN_PARTIAL_RECORDS) {
+        uint64_t v;
+        if constexpr (PAYT > 0) v = q < PAYT ? pay[q < PAYT ? q : 0] : 0;
+        else v = gload(records + r * U + KU + q);
+        lds_merge(tgt, acc_op[q], v);
+      } else {
+        if (acc_src[q] == SRC_ONE) {
+          lds_merge(tgt, ADD_I64, 1);
+          continue;
+        }
+        bool const valid = acc_vbit[q] < 0 || ((valvalid >> acc_vbit[q]) & 1u);
+        if (!valid) continue;
+        if (acc_src[q] == SRC_ONE_IF_VALID) {
+          lds_merge(tgt, ADD_I64, 1);
+          continue;
+        }
+        if (acc_pay[q] != last_pay) {
+          if constexpr (INPUT == IN_COLUMNS) {
+            if constexpr (SIMPLE) value = gload(p.simple_base[KU + acc_pay[q]] + r);
+            else value = col_load_acc_bits(p.cols[p.nkeycols + acc_pay[q]], r);
+          } else if constexpr (PAYT > 0) {
+#pragma unroll
+            for (int w = 0; w < PAYT; ++w)
+              if (acc_pay[q] == w) value = pay[w];
+          } else {
+            value = gload(records + r * U + KU + acc_pay[q]);
+          }
+          last_pay = acc_pay[q];
+        }
+        uint64_t v = value;
+        if (acc_src[q] == SRC_SQUARE) {
+          if (acc_op[q] == ADD_F64) {
+            double const x = __longlong_as_double(static_cast<long long>(v));
+            v              = static_cast<uint64_t>(__double_as_longlong(x * x));
+          } else {
+            v = v * v;
+          }
+        }
+        lds_merge(tgt, acc_op[q], v);
+      }
+    }
+  };
+  auto hash_of = [&](uint64_t const (&key)[KUT]) {
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int u = 0; u < KUT; ++u)
+      if (u < KU) h = mix64(h ^ (key[u] & kmask[u]));
+    return h;
+  };
+  // one row, unbatched (tail rows)
+  auto process = [&](int64_t r, uint64_t const (&key)[KUT], uint64_t const (&pay)[PAYT > 0 ? PAYT : 1], uint32_t valvalid) {
+    uint64_t const h = hash_of(key);
+    int const slot   = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key, h, &s_nfilled, fill_limit, &s_overflow);
+    if (slot >= 0) accumulate(r, slot, pay, valvalid);
+  };
+  // loads one row; false if the row is dropped
+  auto load_row = [&](int64_t r, uint64_t (&key)[KUT], uint64_t (&pay)[PAYT > 0 ? PAYT : 1], uint32_t& valvalid) -> bool {
+    valvalid = 0xffffffffu;
+    if constexpr (INPUT == IN_COLUMNS) {
+      return build_key_units<KUT, SIMPLE>(p, r, key, valvalid);
+    } else if constexpr (EXACT && KUT == 1 && PAYT == 1) {
+      u64x2 const v = gload(reinterpret_cast<u64x2 const*>(records) + r);
+      key[0]        = v.x;
+      pay[0]        = v.y;
+      return true;
+    } else {
+#pragma unroll
+      for (int u = 0; u < KUT; ++u) key[u] = (u < KU) ? gload(records + r * U + u) : 0;
+      if constexpr (PAYT > 0) {
+#pragma unroll
+        for (int v = 0; v < PAYT; ++v) pay[v] = gload(records + r * U + KU + v);
+      }
+      if (INPUT == IN_RAW_RECORDS && flags_unit >= 0)
+        valvalid = gload(reinterpret_cast<uint32_t const*>(records + r * U + flags_unit) + flags_hi);
+      return true;
+    }
+  };
+
+  int nsrc = 1, src0 = item;
+  if (a.seg == SEG_STRIDED) {
+    src0 = item * a.fan;
+    nsrc = min(a.fan, a.nsrc - src0);
+    // an upstream kernel (optimistic partition, previous merge round) gave up: its counts are not valid
+    if (*a.overflow != 0) nsrc = 0;
+  }
+  constexpr int R = (KUT + PAYT <= 2) ? 4 : 2;  // rows in flight per thread
+  int64_t const B = blockDim.x;
+  // Work is dealt to WAVES in batches of W = R*64 consecutive records. One big segment (a partition, a row chunk):
+  // the waves interleave batches. Many short segments (the per-slice regions of an optimistic partition, the
+  // partial tables of a merge round): each wave takes whole segments, so short segments still run batched.
+  constexpr int64_t W = R * 64;
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  bool const multi = a.seg == SEG_STRIDED;
+  for (int sidx = multi ? wave : 0; sidx < nsrc; sidx += multi ? nwaves : 1) {
+    int64_t begin, end;
+    if (a.seg == SEG_ROW_CHUNKS) {
+      begin = static_cast<int64_t>(item) * a.chunk;
+      end   = min(a.nrows, begin + a.chunk);
+    } else if (a.seg == SEG_OFFSETS) {
+      begin = a.offsets[item];
+      end   = a.offsets[item + 1];
+    } else {
+      begin = static_cast<int64_t>(src0 + sidx) * a.src_stride;
+      end   = begin + min<int64_t>(max(a.src_count[src0 + sidx], 0), a.src_stride);
+    }
+    int64_t const nbatches = (end - begin) / W;
+    // main loop: R full rows per lane, all loads issued before the LDS work
+    for (int64_t b = multi ? 0 : wave; b < nbatches; b += multi ? 1 : nwaves) {
+      int64_t const base = begin + b * W;
+      uint64_t key[R][KUT];
+      uint64_t pay[R][PAYT > 0 ? PAYT : 1];
+      uint32_t valvalid[R];
+      bool keep[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) keep[k] = load_row(base + k * 64 + lane, key[k], pay[k], valvalid[k]);
+      // Batched first probe: the state word and the stored key words of the home slot of all R rows are read
+      // with independent ds_reads (one LDS round trip for the common "group already present" case); only
+      // rows that miss walk the full claim/probe protocol.
+      uint64_t h[R];
+      int slot[R];
+      uint32_t s0[R], s1[R];
+      uint64_t k0[R][KUT], k1[R][KUT];
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        h[k]    = hash_of(key[k]);
+        slot[k] = static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(h[k])) * static_cast<uint32_t>(cap)) >> 32);
+        int const nxt = slot[k] + 1 == cap ? 0 : slot[k] + 1;
+        s0[k]   = __hip_atomic_load(&st[slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        s1[k]   = __hip_atomic_load(&st[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int u = 0; u < KUT; ++u) {
+          k0[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + slot[k])] : 0;
+          k1[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + nxt)] : 0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (!keep[k]) continue;
+        uint32_t const tag = tag_of(h[k]);
+        bool hit0 = s0[k] == tag, hit1 = s1[k] == tag;
+#pragma unroll
+        for (int u = 0; u < KUT; ++u) {
+          if (u < KU) {
+            hit0 = hit0 && (k0[k][u] == (key[k][u] & kmask[u]));
+            hit1 = hit1 && (k1[k][u] == (key[k][u] & kmask[u]));
+          }
+        }
+        int sl = slot[k];
+        if (!hit0) {
+          // the second slot only counts when the first is occupied by another key (else the key would sit there)
+          if (hit1 && s0[k] >= 2) sl = slot[k] + 1 == cap ? 0 : slot[k] + 1;
+          else sl = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
+        }
+        if (sl >= 0) accumulate(base + k * 64 + lane, sl, pay[k], valvalid[k]);
+      }
+    }
+    // tail: the < W records after the last full batch
+    int64_t const tail_begin = begin + nbatches * W;
+    for (int64_t r = tail_begin + (multi ? lane : static_cast<int>(threadIdx.x)); r < end; r += multi ? 64 : B) {
+      uint64_t key[KUT];
+      uint64_t pay[PAYT > 0 ? PAYT : 1];
+      uint32_t valvalid;
+      if (load_row(r, key, pay, valvalid)) process(r, key, pay, valvalid);
+    }
+  }
+  __syncthreads();
+  // dump the table as compact partial records
+  uint64_t* out = a.out_records + static_cast<int64_t>(item) * cap * PU;
+  for (int s = threadIdx.x; s < cap; s += blockDim.x) {
+    if (st[s] >= 2) {
+      uint32_t const pos = atomicAdd(&s_dump, 1u);
+      uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
+      for (int u = 0; u < KU; ++u) gstore(o + u, keys[static_cast<size_t>(u) * cap + s]);
+      for (int q = 0; q < NACC; ++q) gstore(o + KU + q, accs[static_cast<size_t>(q) * cap + s]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a.out_count[item] = static_cast<int32_t>(s_dump);
+    if (s_overflow) *a.overflow = 1;
+  }
+}
+
+// ------------------------------------------------------------------ K_finalize
+__device__ __forceinline__ void store_elem(void* base, int64_t i, int width, uint64_t bits)
+{
+  switch (width) {
+    case 1: static_cast<uint8_t*>(base)[i] = static_cast<uint8_t>(bits); break;
+    case 2: static_cast<uint16_t*>(base)[i] = static_cast<uint16_t>(bits); break;
+    case 4: static_cast<uint32_t*>(base)[i] = static_cast<uint32_t>(bits); break;
+    default: static_cast<uint64_t*>(base)[i] = bits;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_finalize(finalize_args const* __restrict__ fa, uint64_t const* records,
+                                                  int64_t cap, int64_t const* prefix, int32_t nitems, int64_t total)
+{
+  plan_dev const& p     = fa->plan;
+  finalize_dev const& f = fa->fin;
+  int64_t const o = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  bool const live = o < total;
+  int const PU    = p.KU + p.NACC;
+  uint64_t const* rec = nullptr;
+  if (live) {
+    // largest item with prefix[item] <= o
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) {
+      int const mid = (lo + hi + 1) >> 1;
+      if (prefix[mid] <= o) lo = mid; else hi = mid - 1;
+    }
+    rec = records + (static_cast<int64_t>(lo) * cap + (o - prefix[lo])) * PU;
+  }
+  int const lane = threadIdx.x & 63;
+  for (int c = 0; c < f.nout; ++c) {
+    out_desc const d = f.out[c];
+    bool valid       = live;
+    uint64_t bits    = 0;
+    if (live) {
+      if (d.kind == OUT_KEY) {
+        uint64_t const unit = rec[d.key_unit];
+        bits                = d.key_full ? unit : (d.key_hi ? (unit >> 32) : (unit & 0xffffffffull));
+        if (d.key_null_bit >= 0) {
+          uint64_t const kn = rec[d.keynulls_unit];
+          uint32_t const w  = d.keynulls_hi ? static_cast<uint32_t>(kn >> 32) : static_cast<uint32_t>(kn);
+          valid             = !((w >> d.key_null_bit) & 1u);
+        }
+      } else {
+        uint64_t const a0 = rec[p.KU + d.a0];
+        if (d.valid_acc >= 0) valid = static_cast<int64_t>(rec[p.KU + d.valid_acc]) > 0;
+        if (d.kind == OUT_COUNT) {
+          bits = a0;
+        } else if (d.kind == OUT_M2 || d.kind == OUT_VAR || d.kind == OUT_STD) {
+          // reference groupby/common/m2_var_std.cu:48-60,152-187
+          auto as_double = [&](uint64_t v) {
+            return d.cls == cudf::detail::CLS_F64 ? __longlong_as_double(static_cast<long long>(v))
+                                                  : static_cast<double>(static_cast<int64_t>(v));
+          };
+          int64_t const cnt = static_cast<int64_t>(rec[p.KU + d.a2]);
+          double const ssq  = as_double(a0);
+          double const sm   = as_double(rec[p.KU + d.a1]);
+          double const m2   = cnt > 0 ? ssq - sm * sm / static_cast<double>(cnt) : 0.0;
+          double out        = m2;
+          if (d.kind != OUT_M2) {
+            int64_t const df = cnt - d.ddof;
+            valid            = cnt > 0 && df > 0;
+            out              = valid ? m2 / static_cast<double>(df) : 0.0;
+            if (d.kind == OUT_STD) out = sqrt(out);
+          } else {
+            valid = true;
+          }
+          bits = static_cast<uint64_t>(__double_as_longlong(out));
+        } else if (d.kind == OUT_MEAN) {
+          // MEAN = double(SUM) / COUNT_VALID as FLOAT64 (reference hash_compound_agg_finalizer.cu:92-133)
+          double const s = d.cls == cudf::detail::CLS_F64 ? __longlong_as_double(static_cast<long long>(a0))
+                           : d.cls == cudf::detail::CLS_UINT ? static_cast<double>(a0)
+                                                             : static_cast<double>(static_cast<int64_t>(a0));
+          double const n = static_cast<double>(static_cast<int64_t>(rec[p.KU + d.a1]));
+          bits           = static_cast<uint64_t>(__double_as_longlong(valid ? s / n : 0.0));
+        } else {  // OUT_ACC: accumulator class -> output type
+          if (d.cls == cudf::detail::CLS_F64 && d.out_cls == cudf::detail::CLS_F32) {
+            bits = __float_as_uint(static_cast<float>(__longlong_as_double(static_cast<long long>(a0))));
+          } else {
+            bits = a0;  // integers truncate to the output width; FLOAT64 passes through
+          }
+          if (!valid) bits = 0;
+        }
+      }
+      store_elem(d.data, o, d.width, bits);
+    }
+    if (d.mask != nullptr) {
+      unsigned long long const ballot      = __ballot(valid);  // valid implies live
+      unsigned long long const live_ballot = __ballot(live);
+      if (live && (lane & 31) == 0) d.mask[o >> 5] = static_cast<uint32_t>(ballot >> (lane & 32));
+      int const nulls = __popcll(live_ballot & ~ballot);
+      if (lane == 0 && nulls) atomicAdd(d.null_count, nulls);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K_estimate (linear counting on a sample)
+__global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
+                                                  uint32_t* bitmap, int32_t bits_log2)
+{
+  plan_dev const& p = *pp;
+  int64_t const i   = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i >= sample) return;
+  int64_t const row = sample >= nrows ? i : static_cast<int64_t>((static_cast<__int128>(i) * nrows) / sample);
+  uint64_t key[MAX_KU];
+  uint32_t vv;
+  if (!build_key_units<MAX_KU, false>(p, row, key, vv)) return;
+  uint64_t const h   = hash_key_units<MAX_KU>(p, key);
+  uint32_t const bit = static_cast<uint32_t>(h >> (64 - bits_log2));
+  atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+}
+__global__ void __launch_bounds__(256) k_popcount(uint32_t const* bitmap, int64_t nwords, uint32_t* out)
+{
+  int64_t i     = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  uint32_t acc  = 0;
+  for (; i < nwords; i += static_cast<int64_t>(gridDim.x) * blockDim.x) acc += __popc(bitmap[i]);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+}  // namespace
+
+std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g)
+{
+  return static_cast<std::size_t>(g.cap) * (8u * (plan.KU + plan.NACC) + 4u);
+}
+
+template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT, uint64_t SIG = 0>
+static void launch_aggregate_n(agg_args const& a, agg_args* d_args, hipStream_t stream)
+{
+  auto const lds = aggregate_lds_bytes(a.plan, a.geom);
+  static bool attr_set = false;
+  if (!attr_set) {
+    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT, SIG>));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_store_args<agg_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"aggregate", stream};
+  hipLaunchKernelGGL((k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT, SIG>), dim3(a.nitems), dim3(a.geom.block), lds,
+                     stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+// Signature of a plan's accumulators (0 if it does not fit the static encoding).
+static uint64_t plan_sig(plan_dev const& p)
+{
+  if (p.NACC < 1 || p.NACC > 4) return 0;
+  uint64_t a[4] = {0, 0, 0, 0};
+  for (int q = 0; q < p.NACC; ++q) {
+    auto const& d = p.acc[q];
+    if (d.pay > 5 || d.valid_bit > 5) return 0;
+    a[q] = sig_acc(d.op, d.src, d.pay, d.valid_bit);
+  }
+  return make_sig(p.NACC, a[0], a[1], a[2], a[3]);
+}
+// hot signatures with their own instantiation
+constexpr uint64_t SIG_SUMF_CNT = make_sig(2, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1));
+constexpr uint64_t SIG_SUMI_CNT = make_sig(2, sig_acc(ADD_I64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1));
+constexpr uint64_t SIG_SUMF     = make_sig(1, sig_acc(ADD_F64, SRC_VALUE, 0, -1));
+constexpr uint64_t SIG_SUMI     = make_sig(1, sig_acc(ADD_I64, SRC_VALUE, 0, -1));
+constexpr uint64_t SIG_CNT      = make_sig(1, sig_acc(ADD_I64, SRC_ONE, -1, -1));
+// C4: MEAN + MIN + MAX of a nullable float64 column -> SUM, COUNT_VALID, MIN, MAX
+constexpr uint64_t SIG_MEAN_MIN_MAX_F_NULLS =
+  make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0), sig_acc(MIN_F64, SRC_VALUE, 0, 0),
+           sig_acc(MAX_F64, SRC_VALUE, 0, 0));
+
+template <int INPUT, int KUT, int PAYT, bool SIMPLE, bool EXACT>
+static void launch_aggregate_t(agg_args const& a, agg_args* d_args, hipStream_t stream)
+{
+  if (a.plan.NACC <= 2) return launch_aggregate_n<INPUT, KUT, PAYT, 2, SIMPLE, EXACT>(a, d_args, stream);
+  if (a.plan.NACC <= 4) return launch_aggregate_n<INPUT, KUT, PAYT, 4, SIMPLE, EXACT>(a, d_args, stream);
+  return launch_aggregate_n<INPUT, KUT, PAYT, MAX_ACC, SIMPLE, EXACT>(a, d_args, stream);
+}
+
+template <int INPUT>
+static void launch_aggregate_records(agg_args const& a, agg_args* d_args, hipStream_t stream)
+{
+  int const KU   = a.plan.KU;
+  int const npay = INPUT == IN_RAW_RECORDS ? a.plan.NPAY : a.plan.NACC;
+  // hot signatures: descriptors folded at compile time
+  if constexpr (INPUT == IN_RAW_RECORDS) {
+    uint64_t const sig = plan_sig(a.plan);
+    if (KU == 1 && npay == 1 && a.plan.flags_unit < 0) {
+      if (sig == SIG_SUMF_CNT) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMF_CNT>(a, d_args, stream);
+      if (sig == SIG_SUMI_CNT) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMI_CNT>(a, d_args, stream);
+      if (sig == SIG_SUMF) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMF>(a, d_args, stream);
+      if (sig == SIG_SUMI) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMI>(a, d_args, stream);
+      if (sig == SIG_CNT) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_CNT>(a, d_args, stream);
+    }
+    if (KU == 2 && npay == 1 && sig == SIG_MEAN_MIN_MAX_F_NULLS)
+      return launch_aggregate_n<INPUT, 2, 1, 4, false, true, SIG_MEAN_MIN_MAX_F_NULLS>(a, d_args, stream);
+  }
+  // exact shapes get the payload prefetched with the key; everything else fetches it lazily
+  if (KU == 1 && npay == 1) return launch_aggregate_t<INPUT, 1, 1, false, true>(a, d_args, stream);
+  if (KU == 1 && npay == 2) return launch_aggregate_t<INPUT, 1, 2, false, true>(a, d_args, stream);
+  if (KU == 2 && npay == 1) return launch_aggregate_t<INPUT, 2, 1, false, true>(a, d_args, stream);
+  if (KU == 2 && npay == 4) return launch_aggregate_t<INPUT, 2, 4, false, true>(a, d_args, stream);
+  if (KU <= 1) return launch_aggregate_t<INPUT, 1, 0, false, false>(a, d_args, stream);
+  if (KU <= 2) return launch_aggregate_t<INPUT, 2, 0, false, false>(a, d_args, stream);
+  return launch_aggregate_t<INPUT, 4, 0, false, false>(a, d_args, stream);
+}
+
+void launch_aggregate(agg_args const& a, agg_args* d_args, hipStream_t stream)
+{
+  if (a.nitems == 0) return;
+  int const KU = a.plan.KU;
+  if (a.input == IN_RAW_RECORDS) return launch_aggregate_records<IN_RAW_RECORDS>(a, d_args, stream);
+  if (a.input == IN_PARTIAL_RECORDS) return launch_aggregate_records<IN_PARTIAL_RECORDS>(a, d_args, stream);
+  bool const simple = a.plan.simple;
+  if (KU <= 1) simple ? launch_aggregate_t<IN_COLUMNS, 1, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 1, 0, false, false>(a, d_args, stream);
+  else if (KU <= 2) simple ? launch_aggregate_t<IN_COLUMNS, 2, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 2, 0, false, false>(a, d_args, stream);
+  else simple ? launch_aggregate_t<IN_COLUMNS, 4, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 4, 0, false, false>(a, d_args, stream);
+}
+
+void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t const* records, int64_t cap,
+                     int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream)
+{
+  if (total == 0) return;
+  int const block = 256;
+  int64_t const grid = (total + block - 1) / block;
+  hipLaunchKernelGGL(k_store_args<finalize_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"finalize", stream};
+  hipLaunchKernelGGL(k_finalize, dim3(static_cast<unsigned>(grid)), dim3(block), 0, stream, d_args, records, cap, prefix,
+                     nitems, total);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
+                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, hipStream_t stream)
+{
+  int64_t const nwords = (int64_t{1} << bitmap_bits_log2) / 32;
+  CUDF_HIP_TRY(hipMemsetAsync(bitmap, 0, nwords * 4, stream));
+  CUDF_HIP_TRY(hipMemsetAsync(d_bits_set, 0, 4, stream));
+  int const block = 256;
+  hipLaunchKernelGGL(k_store_args<plan_dev>, dim3(1), dim3(1), 0, stream, plan, d_plan);
+  cudf::detail::prof::scope prof_{"estimate", stream};
+  hipLaunchKernelGGL(k_estimate, dim3(static_cast<unsigned>((sample + block - 1) / block)), dim3(block), 0, stream, d_plan,
+                     nrows, sample, bitmap, bitmap_bits_log2);
+  hipLaunchKernelGGL(k_popcount, dim3(256), dim3(block), 0, stream, bitmap, nwords, d_bits_set);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cudf::groupby::detail

@@ -1,0 +1,325 @@
+// SPDX-License-Identifier: Apache-2.0
+// Device helpers shared by the partition and aggregate translation units of the hash-groupby engine
+// (record building from columns, key hashing, block scan, LDS-only barrier, launch helpers).
+#pragma once
+#include "engine.hpp"
+#include "../common/profiler.hpp"
+
+#include <cudf/utilities/error.hpp>
+
+namespace cudf::groupby::detail {
+
+using cudf::detail::col_is_valid;
+using cudf::detail::col_load_acc_bits;
+using cudf::detail::col_load_bits;
+using cudf::detail::gload;
+using cudf::detail::gstore;
+using cudf::detail::mix64;
+using cudf::detail::normalize_key_bits;
+using cudf::detail::u64x2;
+
+namespace {
+
+constexpr uint32_t ST_EMPTY  = 0;
+constexpr uint32_t ST_LOCKED = 1;
+
+__device__ __forceinline__ uint32_t tag_of(uint64_t h) { return (static_cast<uint32_t>(h >> 20) & ~3u) | 2u; }
+
+// Workgroup barrier that orders LDS traffic only. __syncthreads() makes hipcc emit `s_waitcnt vmcnt(0)` in front
+// of s_barrier, i.e. every wave drains ALL its outstanding global loads and stores at every barrier — in the
+// partition kernel that serialised the tile's HBM traffic with its LDS phases (nothing else hides it at one
+// workgroup per CU). Here global loads/stores stay in flight across the barrier; the compiler still waits on
+// vmcnt where a loaded register is first used.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T>
+__global__ void k_store_args(T v, T* dst)
+{
+  *dst = v;
+}
+
+// ------------------------------------------------------------------ record building from columns
+// Validity words of one row: keynulls bit c = key column c NULL; valvalid bit v = value column v valid.
+__device__ __forceinline__ void row_validity(plan_dev const& p, int64_t row, uint32_t& keynulls, uint32_t& valvalid)
+{
+  keynulls = 0;
+  valvalid = 0;
+  for (int c = 0; c < p.ncols; ++c) {
+    if (p.cols[c].mask == nullptr) {
+      if (c >= p.nkeycols) valvalid |= 1u << (c - p.nkeycols);
+      continue;
+    }
+    bool const v = col_is_valid(p.cols[c], row);
+    if (c < p.nkeycols) {
+      if (!v) keynulls |= 1u << c;
+    } else if (v) {
+      valvalid |= 1u << (c - p.nkeycols);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t half_bits(plan_dev const& p, int8_t src, int64_t row, uint32_t keynulls,
+                                              uint32_t valvalid)
+{
+  if (src == H_NONE) return 0;
+  if (src == H_KEYNULLS) return keynulls;
+  if (src == H_VALVALID) return valvalid;
+  if ((keynulls >> src) & 1u) return 0;  // NULL key element: data zeroed so equal NULLs compare equal
+  return static_cast<uint32_t>(normalize_key_bits(col_load_bits(p.cols[src], row), p.cols[src].cls));
+}
+
+__device__ __forceinline__ uint64_t unit_bits(plan_dev const& p, int u, int64_t row, uint32_t keynulls,
+                                              uint32_t valvalid)
+{
+  // one aligned 32-bit scalar load instead of four byte loads
+  uint32_t const w = reinterpret_cast<uint32_t const*>(p.unit)[u];
+  unit_desc d;
+  d.full   = static_cast<int8_t>(w);
+  d.lo     = static_cast<int8_t>(w >> 8);
+  d.hi     = static_cast<int8_t>(w >> 16);
+  d.is_key = static_cast<int8_t>(w >> 24);
+  if (d.full) {
+    if (d.is_key) {
+      if ((keynulls >> d.lo) & 1u) return 0;
+      return normalize_key_bits(col_load_bits(p.cols[d.lo], row), p.cols[d.lo].cls);
+    }
+    return col_load_acc_bits(p.cols[d.lo], row);
+  }
+  return static_cast<uint64_t>(half_bits(p, d.lo, row, keynulls, valvalid)) |
+         (static_cast<uint64_t>(half_bits(p, d.hi, row, keynulls, valvalid)) << 32);
+}
+
+// Key units of one row from the columns; false if the row is dropped (null_policy::EXCLUDE).
+template <int KUT, bool SIMPLE>
+__device__ __forceinline__ bool build_key_units(plan_dev const& p, int64_t row, uint64_t (&key)[KUT], uint32_t& valvalid)
+{
+  if constexpr (SIMPLE) {
+    valvalid = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < KUT; ++u) key[u] = (u < p.KU) ? gload(p.simple_base[u] + row) : 0;
+    return true;
+  } else {
+    uint32_t keynulls;
+    row_validity(p, row, keynulls, valvalid);
+    if (p.drop_null_keys && keynulls != 0) return false;
+#pragma unroll
+    for (int u = 0; u < KUT; ++u) key[u] = (u < p.KU) ? unit_bits(p, u, row, keynulls, valvalid) : 0;
+    return true;
+  }
+}
+
+template <int KUT>
+__device__ __forceinline__ uint64_t hash_key_units(plan_dev const& p, uint64_t const (&key)[KUT])
+{
+  uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+  for (int u = 0; u < KUT; ++u)
+    if (u < p.KU) h = mix64(h ^ (key[u] & p.key_mask[u]));
+  return h;
+}
+
+// Column-at-a-time record building for a batch of NR rows per thread: every column / unit descriptor is decoded
+// ONCE per batch (scalar work) and the inner loops over the rows are straight typed loads. The row-at-a-time form
+// above re-decodes the descriptors for every row and is bound by the CU's scalar ALU (C4: 12.5 ms histogram).
+template <int NR>
+__device__ __forceinline__ void batch_validity(plan_dev const& p, int64_t const (&row)[NR], bool (&live)[NR],
+                                               uint32_t (&keynulls)[NR], uint32_t (&valvalid)[NR])
+{
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    keynulls[k] = 0;
+    valvalid[k] = 0;
+  }
+  for (int c = 0; c < p.ncols; ++c) {
+    bitmask_type const* mask = p.cols[c].mask;
+    int const off            = p.cols[c].offset;
+    bool const is_key        = c < p.nkeycols;
+    uint32_t const bit       = is_key ? (1u << c) : (1u << (c - p.nkeycols));
+    if (mask == nullptr) {
+      if (!is_key) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) valvalid[k] |= bit;
+      }
+      continue;
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      if (!live[k]) continue;
+      int64_t const b = static_cast<int64_t>(off) + row[k];
+      bool const v    = (gload(mask + (b >> 5)) >> (b & 31)) & 1u;
+      if (is_key) keynulls[k] |= v ? 0u : bit;
+      else valvalid[k] |= v ? bit : 0u;
+    }
+  }
+  if (p.drop_null_keys) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) live[k] = live[k] && keynulls[k] == 0;
+  }
+}
+
+// raw element bits of column c for NR rows (zero-extended)
+template <int NR>
+__device__ __forceinline__ void batch_load_bits(device_column const& col, int64_t const (&row)[NR], bool const (&live)[NR],
+                                                uint64_t (&out)[NR])
+{
+  int64_t const off = col.offset;
+  switch (col.width) {
+    case 1:
+#pragma unroll
+      for (int k = 0; k < NR; ++k) out[k] = live[k] ? gload(static_cast<uint8_t const*>(col.head) + off + row[k]) : 0;
+      break;
+    case 2:
+#pragma unroll
+      for (int k = 0; k < NR; ++k) out[k] = live[k] ? gload(static_cast<uint16_t const*>(col.head) + off + row[k]) : 0;
+      break;
+    case 4:
+#pragma unroll
+      for (int k = 0; k < NR; ++k) out[k] = live[k] ? gload(static_cast<uint32_t const*>(col.head) + off + row[k]) : 0;
+      break;
+    default:
+#pragma unroll
+      for (int k = 0; k < NR; ++k) out[k] = live[k] ? gload(static_cast<uint64_t const*>(col.head) + off + row[k]) : 0;
+  }
+}
+
+__device__ __forceinline__ uint64_t to_acc_bits(uint64_t raw, int cls, int width)
+{
+  switch (cls) {
+    case cudf::detail::CLS_SINT:
+      switch (width) {
+        case 1: return static_cast<uint64_t>(static_cast<int64_t>(static_cast<int8_t>(raw)));
+        case 2: return static_cast<uint64_t>(static_cast<int64_t>(static_cast<int16_t>(raw)));
+        case 4: return static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(raw)));
+        default: return raw;
+      }
+    case cudf::detail::CLS_BOOL: return raw != 0;
+    case cudf::detail::CLS_F32: return __double_as_longlong(static_cast<double>(__uint_as_float(static_cast<uint32_t>(raw))));
+    default: return raw;
+  }
+}
+
+// One 32-bit half of a unit for NR rows.
+template <int NR>
+__device__ __forceinline__ void batch_half(plan_dev const& p, int8_t src, int64_t const (&row)[NR], bool const (&live)[NR],
+                                           uint32_t const (&keynulls)[NR], uint32_t const (&valvalid)[NR], uint32_t (&out)[NR])
+{
+  if (src == H_NONE) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) out[k] = 0;
+  } else if (src == H_KEYNULLS) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) out[k] = keynulls[k];
+  } else if (src == H_VALVALID) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) out[k] = valvalid[k];
+  } else {
+    device_column const col = p.cols[src];
+    uint64_t raw[NR];
+    batch_load_bits<NR>(col, row, live, raw);
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+      out[k] = ((keynulls[k] >> src) & 1u) ? 0u : static_cast<uint32_t>(normalize_key_bits(raw[k], col.cls));
+  }
+}
+
+// Units [0, nunits) of NR rows; rows with live[k] == false are left untouched. UT bounds the static unroll.
+template <int NR, int UT>
+__device__ __forceinline__ void batch_units(plan_dev const& p, int nunits, int64_t const (&row)[NR], bool (&live)[NR],
+                                            uint64_t (&rec)[NR][UT], uint32_t (&valvalid)[NR])
+{
+  uint32_t keynulls[NR];
+  batch_validity<NR>(p, row, live, keynulls, valvalid);
+#pragma unroll
+  for (int u = 0; u < UT; ++u) {
+    if (u >= nunits) break;
+    uint32_t const w = reinterpret_cast<uint32_t const*>(p.unit)[u];
+    int8_t const full = static_cast<int8_t>(w), lo = static_cast<int8_t>(w >> 8), hi = static_cast<int8_t>(w >> 16),
+                 is_key = static_cast<int8_t>(w >> 24);
+    if (full) {
+      device_column const col = p.cols[lo];
+      uint64_t raw[NR];
+      batch_load_bits<NR>(col, row, live, raw);
+      if (is_key) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) rec[k][u] = ((keynulls[k] >> lo) & 1u) ? 0 : normalize_key_bits(raw[k], col.cls);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) rec[k][u] = to_acc_bits(raw[k], col.cls, col.width);
+      }
+    } else {
+      uint32_t l[NR], h[NR];
+      batch_half<NR>(p, lo, row, live, keynulls, valvalid, l);
+      batch_half<NR>(p, hi, row, live, keynulls, valvalid, h);
+#pragma unroll
+      for (int k = 0; k < NR; ++k) rec[k][u] = static_cast<uint64_t>(l[k]) | (static_cast<uint64_t>(h[k]) << 32);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ block scan helper
+// Exclusive scan of one uint32 per thread across the block; `total` receives the block sum.
+// `wave_sums` must hold blockDim.x / 64 entries.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_sums, uint32_t& total)
+{
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t const t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_sums[wave] = inc;
+  lds_barrier();
+  if (wave == 0) {
+    uint32_t s = lane < nwaves ? wave_sums[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t const t = __shfl_up(s, o);
+      if (lane >= o) s += t;
+    }
+    if (lane < nwaves) wave_sums[lane] = s;  // inclusive
+  }
+  lds_barrier();
+  uint32_t const wave_off = wave == 0 ? 0 : wave_sums[wave - 1];
+  total                   = wave_sums[nwaves - 1];
+  lds_barrier();
+  return wave_off + inc - v;
+}
+
+// ------------------------------------------------------------------ partition: slice bounds
+struct slice_range {
+  int64_t begin, end;
+  int64_t seg_begin;
+};
+__device__ __forceinline__ slice_range slice_of(part_args const& a, int item)
+{
+  int const g = item / a.geom.slices, s = item % a.geom.slices;
+  int64_t const b = a.from_columns ? 0 : a.seg_offsets[g];
+  int64_t const e = a.from_columns ? a.nrows : a.seg_offsets[g + 1];
+  int64_t per = (e - b + a.geom.slices - 1) / a.geom.slices;
+  per         = (per + 1) & ~int64_t{1};  // even slice starts: rows are loaded in 16-byte pairs on the simple path
+  slice_range r;
+  r.seg_begin = b;
+  r.begin     = min(e, b + per * s);
+  r.end       = min(e, r.begin + per);
+  return r;
+}
+
+inline int next_ut(int u)
+{
+  for (int c : {2, 3, 4, 6, 8, 12, 16})
+    if (u <= c) return c;
+  return -1;
+}
+
+// Opts a kernel into the full 160 KiB of LDS (static + dynamic) once per process.
+void allow_full_lds(void const* fn)
+{
+  hipFuncAttributes attr{};
+  CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
+  int const dyn = 160 * 1024 - static_cast<int>(attr.sharedSizeBytes);
+  CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+}
+
+}  // namespace
+}  // namespace cudf::groupby::detail

@@ -1,0 +1,426 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 partition kernels of the hash-groupby engine: histogram, scan, LDS-staged multi-split scatter (engine.hpp).
+#include "device_common.hpp"
+
+namespace cudf::groupby::detail {
+namespace {
+// ------------------------------------------------------------------ K_hist
+template <bool SIMPLE>
+__global__ void __launch_bounds__(1024) k_partition_hist(part_args const* __restrict__ ap)
+{
+  extern __shared__ uint32_t lds_hist[];
+  part_args const& a = *ap;
+  plan_dev const& p  = a.plan;
+  int const P = a.geom.P, shift = a.geom.shift;
+  for (int d = threadIdx.x; d < P; d += blockDim.x) lds_hist[d] = 0;
+  __syncthreads();
+  slice_range const sr = slice_of(a, blockIdx.x);
+  int const U          = p.KU + p.NPAY;
+  int const from_cols  = a.from_columns;
+  constexpr int R      = 4;
+  int64_t const B      = blockDim.x;
+  for (int64_t base = sr.begin; base < sr.end; base += R * B) {
+    uint64_t key[R][MAX_KU];
+    bool keep[R];
+    int64_t row[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      row[k]  = base + k * B + threadIdx.x;
+      keep[k] = row[k] < sr.end;
+    }
+    if (SIMPLE && from_cols && p.simple_vec16 && ((sr.begin & 1) == 0)) {
+      // two rows per 16-byte load (rows 2m, 2m+1); which lane counts which row does not matter for a histogram
+#pragma unroll
+      for (int m = 0; m < R / 2; ++m) {
+        int64_t const r = base + (static_cast<int64_t>(m) * B + threadIdx.x) * 2;
+        keep[2 * m]     = r < sr.end;
+        keep[2 * m + 1] = r + 1 < sr.end;
+#pragma unroll
+        for (int u = 0; u < MAX_KU; ++u) {
+          key[2 * m][u] = key[2 * m + 1][u] = 0;
+          if (u < p.KU) {
+            if (keep[2 * m + 1]) {
+              u64x2 const v     = gload(reinterpret_cast<u64x2 const*>(p.simple_base[u] + r));
+              key[2 * m][u]     = v.x;
+              key[2 * m + 1][u] = v.y;
+            } else if (keep[2 * m]) {
+              key[2 * m][u] = gload(p.simple_base[u] + r);
+            }
+          }
+        }
+      }
+    } else if (from_cols && !SIMPLE) {
+      uint32_t vv[R];
+      batch_units<R, MAX_KU>(p, p.KU, row, keep, key, vv);
+    } else {
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (keep[k]) {
+          if (from_cols) {
+            uint32_t vv;
+            keep[k] = build_key_units<MAX_KU, SIMPLE>(p, row[k], key[k], vv);
+          } else {
+#pragma unroll
+            for (int u = 0; u < MAX_KU; ++u) key[k][u] = (u < p.KU) ? gload(a.in_records + row[k] * U + u) : 0;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (keep[k]) {
+        uint64_t const h = hash_key_units<MAX_KU>(p, key[k]);
+        atomicAdd(&lds_hist[static_cast<uint32_t>(h >> shift) & static_cast<uint32_t>(P - 1)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < P; d += blockDim.x) gstore(a.counts + static_cast<int64_t>(blockIdx.x) * P + d, lds_hist[d]);
+}
+
+// ------------------------------------------------------------------ K_scan: one block per segment
+__global__ void __launch_bounds__(1024) k_partition_scan(part_args const* __restrict__ ap)
+{
+  __shared__ uint32_t wave_sums[16];
+  extern __shared__ uint32_t lds_tot[];  // P totals, then P exclusive offsets
+  part_args const& a = *ap;
+  int const P = a.geom.P, S = a.geom.slices, g = blockIdx.x;
+  int64_t const seg_begin = a.from_columns ? 0 : a.seg_offsets[g];
+  uint32_t* tot  = lds_tot;
+  uint32_t* excl = lds_tot + P;
+  for (int d = threadIdx.x; d < P; d += blockDim.x) {
+    uint32_t t = 0;
+    for (int s = 0; s < S; ++s) t += a.counts[(static_cast<int64_t>(g) * S + s) * P + d];
+    tot[d] = t;
+  }
+  __syncthreads();
+  // exclusive scan of tot over d: each thread owns a contiguous run of E entries
+  int const E = (P + blockDim.x - 1) / blockDim.x;
+  uint32_t local = 0;
+  for (int k = 0; k < E; ++k) {
+    int const d = threadIdx.x * E + k;
+    if (d < P) local += tot[d];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(local, wave_sums, total);
+  for (int k = 0; k < E; ++k) {
+    int const d = threadIdx.x * E + k;
+    if (d < P) {
+      excl[d] = run;
+      run += tot[d];
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < P; d += blockDim.x) {
+    int64_t running = seg_begin + excl[d];
+    a.out_offsets[static_cast<int64_t>(g) * P + d] = running;
+    for (int s = 0; s < S; ++s) {
+      int64_t const idx = (static_cast<int64_t>(g) * S + s) * P + d;
+      a.item_base[idx]  = running;
+      running += a.counts[idx];
+    }
+  }
+  if (g == a.geom.nseg - 1 && threadIdx.x == 0) a.out_offsets[static_cast<int64_t>(a.geom.nseg) * P] = seg_begin + total;
+}
+
+// ------------------------------------------------------------------ K_scatter
+// One workgroup per (segment, slice). Per tile of T = blockDim * RPT rows: rank rows inside their partition
+// with an LDS histogram, exclusive-scan the histogram, stage the records in LDS in partition order and write
+// them out so that consecutive lanes write consecutive records of one partition (runs of T/P records).
+// LDS layout: stage[T*U] u64 | delta[P] i64 | hist[P] u32 | pid[T] u16 | wave_sums[16] u32
+// EXACT: the record has exactly UT units (all `u < U` predicates fold away; 16-byte records move as one
+// ds_write_b128 / global_store_dwordx4).
+template <int UT, int RPT, bool SIMPLE, bool EXACT>
+__global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __restrict__ ap)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  part_args const& a = *ap;
+  plan_dev const& p  = a.plan;
+  int const P = a.geom.P, shift = a.geom.shift, B = blockDim.x, T = B * RPT;
+  int const U  = EXACT ? UT : (p.KU + p.NPAY);  // <= UT
+  int const KU = p.KU;
+  uint64_t* stage     = reinterpret_cast<uint64_t*>(lds_raw);
+  int64_t* delta      = reinterpret_cast<int64_t*>(stage + static_cast<size_t>(T) * U);
+  uint32_t* hist      = reinterpret_cast<uint32_t*>(delta + P);
+  uint16_t* pid       = reinterpret_cast<uint16_t*>(hist + P);
+  uint32_t* wave_sums = reinterpret_cast<uint32_t*>(pid + T + (T & 1));
+
+  int const item       = blockIdx.x;
+  slice_range const sr = slice_of(a, item);
+  int const from_cols  = a.from_columns;
+  uint64_t const* in_records = a.in_records;
+  uint64_t* out_records      = a.out_records;
+  uint64_t kmask[UT < MAX_KU ? UT : MAX_KU];
+#pragma unroll
+  for (int u = 0; u < (UT < MAX_KU ? UT : MAX_KU); ++u) kmask[u] = u < KU ? p.key_mask[u] : 0;
+  uint64_t const* sbase[UT];
+  if constexpr (SIMPLE) {
+#pragma unroll
+    for (int u = 0; u < UT; ++u) sbase[u] = u < U ? p.simple_base[u] : nullptr;
+  }
+  // Thread t owns partitions d = t*MAXE + k: their running output cursor lives in registers.
+  constexpr int MAXE = 2;  // P <= 2 * B
+  int64_t cursor[MAXE], region_end[MAXE];
+  int const optimistic = a.optimistic;
+  __shared__ int s_abort;
+  if (threadIdx.x == 0) s_abort = 0;
+#pragma unroll
+  for (int k = 0; k < MAXE; ++k) {
+    int const d = threadIdx.x * MAXE + k;
+    if (optimistic) {
+      cursor[k]     = (static_cast<int64_t>(d) * a.geom.slices + item) * a.region_cap;
+      region_end[k] = cursor[k] + a.region_cap;
+    } else {
+      cursor[k]     = d < P ? a.item_base[static_cast<int64_t>(item) * P + d] : 0;
+      region_end[k] = INT64_MAX;
+    }
+    if (d < P) hist[d] = 0;
+  }
+  lds_barrier();
+
+  uint64_t rec[RPT][UT];
+  bool keep[RPT];
+  // loads one tile into registers (all loads issued back to back)
+  bool const vec16 = SIMPLE && (RPT % 2 == 0) && p.simple_vec16 && ((sr.begin & 1) == 0);
+  auto load_tile = [&](int64_t tile) {
+    if constexpr (SIMPLE && (RPT % 2 == 0)) {
+      if (vec16) {
+        // 8-byte-per-lane loads run at 0.54-0.70x the 16-byte rate (the load issue was 51 % of the tile time):
+        // each lane takes rows (2m, 2m+1) of every column with one global_load_dwordx4
+#pragma unroll
+        for (int m = 0; m < RPT / 2; ++m) {
+          int64_t const r = tile + (static_cast<int64_t>(m) * B + threadIdx.x) * 2;
+          keep[2 * m]     = r < sr.end;
+          keep[2 * m + 1] = r + 1 < sr.end;
+          if (keep[2 * m + 1]) {
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+              if (u < U) {
+                u64x2 const v     = gload(reinterpret_cast<u64x2 const*>(sbase[u] + r));
+                rec[2 * m][u]     = v.x;
+                rec[2 * m + 1][u] = v.y;
+              }
+            }
+          } else if (keep[2 * m]) {
+#pragma unroll
+            for (int u = 0; u < UT; ++u) rec[2 * m][u] = (u < U) ? gload(sbase[u] + r) : 0;
+          }
+        }
+        return;
+      }
+    }
+    if (!SIMPLE && from_cols) {
+      int64_t row[RPT];
+      uint32_t vv[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        row[k]  = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+        keep[k] = row[k] < sr.end;
+      }
+      batch_units<RPT, UT>(p, U, row, keep, rec, vv);
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      int64_t const r = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+      keep[k]         = r < sr.end;
+      if (keep[k]) {
+        if constexpr (SIMPLE) {
+          if (vec16) continue;  // loaded two rows at a time below
+#pragma unroll
+          for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? gload(sbase[u] + r) : 0;
+        } else if constexpr (EXACT && UT == 2) {
+          u64x2 const v = gload(reinterpret_cast<u64x2 const*>(in_records) + r);
+          rec[k][0]     = v.x;
+          rec[k][1]     = v.y;
+        } else {
+#pragma unroll
+          for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? gload(in_records + r * U + u) : 0;
+        }
+      }
+    }
+  };
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool const stamp = a.stamps != nullptr && threadIdx.x == 0;
+  unsigned long long t_prev = stamp ? __builtin_amdgcn_s_memtime() : 0;
+  auto mark = [&](int i) {
+    if (stamp) {
+      unsigned long long const t = __builtin_amdgcn_s_memtime();
+      ph[i] += t - t_prev;
+      t_prev = t;
+    }
+  };
+  if (sr.begin < sr.end) load_tile(sr.begin);
+  for (int64_t tile = sr.begin; tile < sr.end; tile += T) {
+    uint32_t dig[RPT], rank[RPT];
+    // phase 1b: hash and rank within (tile, partition)
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      if (keep[k]) {
+        uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+        for (int u = 0; u < (UT < MAX_KU ? UT : MAX_KU); ++u)
+          if (u < KU) h = mix64(h ^ (rec[k][u] & kmask[u]));
+        dig[k]  = static_cast<uint32_t>(h >> shift) & static_cast<uint32_t>(P - 1);
+        rank[k] = atomicAdd(&hist[dig[k]], 1u);
+      }
+    }
+    mark(0);
+    lds_barrier();
+    mark(1);
+    // phase 2: hist -> exclusive local offsets (in place); delta = global cursor - local offset
+    uint32_t hv[MAXE], local = 0;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      int const d = threadIdx.x * MAXE + k;
+      hv[k]       = d < P ? hist[d] : 0;
+      local += hv[k];
+    }
+    uint32_t tile_count;
+    uint32_t run = block_exclusive_scan(local, wave_sums, tile_count);
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      int const d = threadIdx.x * MAXE + k;
+      if (d < P) {
+        hist[d]  = run;
+        delta[d] = cursor[k] - static_cast<int64_t>(run);
+        cursor[k] += hv[k];
+        run += hv[k];
+        if (cursor[k] > region_end[k]) s_abort = 1;  // optimistic region too small: nothing of this tile is written
+      }
+    }
+    lds_barrier();
+    mark(2);
+    if (s_abort) {
+      if (threadIdx.x == 0) *a.overflow = 1;
+      return;
+    }
+    // phase 3: stage records in partition order
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      if (keep[k]) {
+        uint32_t const pos = hist[dig[k]] + rank[k];
+        if constexpr (EXACT && UT == 2) {
+          reinterpret_cast<u64x2*>(stage)[pos] = u64x2{rec[k][0], rec[k][1]};
+        } else {
+#pragma unroll
+          for (int u = 0; u < UT; ++u)
+            if (u < U) stage[static_cast<size_t>(pos) * U + u] = rec[k][u];
+        }
+        pid[pos] = static_cast<uint16_t>(dig[k]);
+      }
+    }
+    // the records are staged: the registers are free, so the NEXT tile's loads go out now and fly under the
+    // write-out phase (one workgroup per CU: nothing else would hide their latency)
+    mark(3);
+    if (tile + T < sr.end) load_tile(tile + T);
+    mark(4);
+    lds_barrier();
+    mark(5);
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      int const d = threadIdx.x * MAXE + k;
+      if (d < P) hist[d] = 0;
+    }
+    // phase 4: coalesced write-out; consecutive staged records of one partition go to consecutive slots
+    for (uint32_t j = threadIdx.x; j < tile_count; j += B) {
+      int64_t const dst = delta[pid[j]] + static_cast<int64_t>(j);
+      if constexpr (EXACT && UT == 2) {
+        gstore(reinterpret_cast<u64x2*>(out_records) + dst, reinterpret_cast<u64x2 const*>(stage)[j]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < UT; ++u)
+          if (u < U) gstore(out_records + dst * U + u, stage[static_cast<size_t>(j) * U + u]);
+      }
+    }
+    mark(6);
+    lds_barrier();
+    mark(7);
+  }
+  if (stamp) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.stamps[static_cast<int64_t>(blockIdx.x) * 8 + i] = ph[i];
+  }
+  if (optimistic) {
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      int const d = threadIdx.x * MAXE + k;
+      if (d < P) a.region_count[static_cast<int64_t>(d) * a.geom.slices + item] = static_cast<int32_t>(cursor[k] - (region_end[k] - a.region_cap));
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g)
+{
+  int const U = plan.KU + plan.NPAY;
+  std::size_t const T = g.tile_rows;
+  return T * U * 8 + static_cast<std::size_t>(g.P) * (8 + 4) + (T + (T & 1)) * 2 + 16 * 4;
+}
+
+void store_args(part_args const& a, part_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<part_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_partition_hist(part_args const& a, part_args const* d_args, hipStream_t stream)
+{
+  int const items = a.geom.nseg * a.geom.slices;
+  cudf::detail::prof::scope prof_{"partition_hist", stream};
+  if (a.plan.simple && a.from_columns)
+    hipLaunchKernelGGL(k_partition_hist<true>, dim3(items), dim3(a.geom.block), a.geom.P * sizeof(uint32_t), stream, d_args);
+  else
+    hipLaunchKernelGGL(k_partition_hist<false>, dim3(items), dim3(a.geom.block), a.geom.P * sizeof(uint32_t), stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_partition_scan(part_args const& a, part_args const* d_args, hipStream_t stream)
+{
+  cudf::detail::prof::scope prof_{"partition_scan", stream};
+  hipLaunchKernelGGL(k_partition_scan, dim3(a.geom.nseg), dim3(1024), 2 * a.geom.P * sizeof(uint32_t), stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+template <int UT, int RPT, bool SIMPLE, bool EXACT>
+static void launch_scatter_t(part_args const& a, part_args const* d_args, hipStream_t stream)
+{
+  part_geom g  = a.geom;
+  g.tile_rows  = g.block * RPT;
+  auto const lds = partition_lds_bytes(a.plan, g);
+  CUDF_EXPECTS(lds <= 160 * 1024, "partition kernel: LDS budget exceeded (fan-out too large for this record width)");
+  static bool attr_set = false;
+  if (!attr_set) {
+    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter<UT, RPT, SIMPLE, EXACT>));
+    attr_set = true;
+  }
+  int const items = g.nseg * g.slices;
+  cudf::detail::prof::scope prof_{"partition_scatter", stream};
+  hipLaunchKernelGGL((k_partition_scatter<UT, RPT, SIMPLE, EXACT>), dim3(items), dim3(g.block), lds, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.geom.P <= 2 * a.geom.block, "partition fan-out exceeds 2x the block size");
+  int const U       = a.plan.KU + a.plan.NPAY;
+  bool const simple = a.plan.simple && a.from_columns;
+  switch (next_ut(U)) {
+    case 2:
+      if (a.geom.tile_rows == 4 * a.geom.block)  // half-size tile: 64 KiB of LDS, two workgroups per CU
+        simple ? launch_scatter_t<2, 4, true, true>(a, d_args, stream) : launch_scatter_t<2, 4, false, true>(a, d_args, stream);
+      else
+        simple ? launch_scatter_t<2, 8, true, true>(a, d_args, stream) : launch_scatter_t<2, 8, false, true>(a, d_args, stream);
+      break;
+    case 3: simple ? launch_scatter_t<3, 4, true, true>(a, d_args, stream) : launch_scatter_t<3, 4, false, true>(a, d_args, stream); break;
+    case 4: simple ? launch_scatter_t<4, 4, true, true>(a, d_args, stream) : launch_scatter_t<4, 4, false, true>(a, d_args, stream); break;
+    case 6: launch_scatter_t<6, 2, false, false>(a, d_args, stream); break;
+    case 8: launch_scatter_t<8, 2, false, false>(a, d_args, stream); break;
+    case 12: launch_scatter_t<12, 1, false, false>(a, d_args, stream); break;
+    case 16: launch_scatter_t<16, 1, false, false>(a, d_args, stream); break;
+    default: CUDF_FAIL("record too wide for the partition kernel");
+  }
+}
+}  // namespace cudf::groupby::detail
