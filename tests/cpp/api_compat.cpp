@@ -1,0 +1,131 @@
+// Source-compatibility check of the C++ boundary: this file is written the way a libcudf C++ user (or a Cython
+// .pxd) uses the reference API — cudf::groupby::groupby / aggregation_request / make_*_aggregation
+// (cpp/include/cudf/groupby.hpp:54-184), cudf::inner_join (join/join.hpp:160-166), cudf::hash_join
+// (join/hash_join.hpp:71), cudf::gather — and only swaps the stream type to hipStream_t.
+// Data and expectations are the reference's own KATs (sum_tests.cpp:68-80, mean_tests.cpp:37-55,
+// join_tests.cpp:2091-2118, :2396-2417).
+#include <cudf/aggregation.hpp>
+#include <cudf/copying.hpp>
+#include <cudf/groupby.hpp>
+#include <cudf/join/hash_join.hpp>
+#include <cudf/join/join.hpp>
+#include <cudf/table/table.hpp>
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <vector>
+
+#define CHECK(cond)                                                                  \
+  do {                                                                               \
+    if (!(cond)) {                                                                   \
+      std::fprintf(stderr, "FAILED %s at %s:%d\n", #cond, __FILE__, __LINE__);       \
+      return 1;                                                                      \
+    }                                                                                \
+  } while (0)
+
+template <typename T>
+struct dev_vec {
+  T* p{};
+  size_t n;
+  explicit dev_vec(std::vector<T> const& h) : n{h.size()}
+  {
+    (void)hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+    (void)hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice);
+  }
+  ~dev_vec() { (void)hipFree(p); }
+};
+template <typename T>
+std::vector<T> to_host(cudf::column_view const& c)
+{
+  std::vector<T> h(c.size());
+  (void)hipMemcpy(h.data(), c.data<T>(), h.size() * sizeof(T), hipMemcpyDeviceToHost);
+  return h;
+}
+
+int main()
+{
+  // ---- groupby: keys {1,2,3,1,2,2,1,3,3,2}, vals 0..9 -> SUM {9,19,17}, MEAN {3, 19/4, 17/3}, COUNT {3,4,3}
+  dev_vec<int32_t> keys{{1, 2, 3, 1, 2, 2, 1, 3, 3, 2}};
+  dev_vec<int32_t> vals{{0, 1, 2, 3, 4, 5, 6, 7, 8, 9}};
+  cudf::column_view kcol{cudf::data_type{cudf::type_id::INT32}, 10, keys.p, nullptr, 0};
+  cudf::column_view vcol{cudf::data_type{cudf::type_id::INT32}, 10, vals.p, nullptr, 0};
+  cudf::groupby::groupby gb_obj(cudf::table_view({kcol}));
+  std::vector<cudf::groupby::aggregation_request> requests;
+  requests.emplace_back();
+  requests[0].values = vcol;
+  requests[0].aggregations.push_back(cudf::make_sum_aggregation<cudf::groupby_aggregation>());
+  requests[0].aggregations.push_back(cudf::make_mean_aggregation<cudf::groupby_aggregation>());
+  requests[0].aggregations.push_back(cudf::make_count_aggregation<cudf::groupby_aggregation>());
+  auto result = gb_obj.aggregate(requests);
+  CHECK(result.first->num_rows() == 3);
+  CHECK(result.second.size() == 1 && result.second[0].results.size() == 3);
+  CHECK(result.second[0].results[0]->type().id() == cudf::type_id::INT64);
+  CHECK(result.second[0].results[1]->type().id() == cudf::type_id::FLOAT64);
+  CHECK(result.second[0].results[2]->type().id() == cudf::type_id::INT32);
+  auto k = to_host<int32_t>(result.first->view().column(0));
+  auto s = to_host<int64_t>(result.second[0].results[0]->view());
+  auto m = to_host<double>(result.second[0].results[1]->view());
+  auto c = to_host<int32_t>(result.second[0].results[2]->view());
+  std::map<int32_t, int> at;
+  for (int i = 0; i < 3; ++i) at[k[i]] = i;
+  CHECK(at.size() == 3);
+  CHECK(s[at[1]] == 9 && s[at[2]] == 19 && s[at[3]] == 17);
+  CHECK(c[at[1]] == 3 && c[at[2]] == 4 && c[at[3]] == 3);
+  CHECK(std::abs(m[at[1]] - 3.0) < 1e-12 && std::abs(m[at[2]] - 19.0 / 4) < 1e-12 && std::abs(m[at[3]] - 17.0 / 3) < 1e-12);
+
+  // size mismatch -> cudf::logic_error (groupby.cu:225-229)
+  {
+    dev_vec<int32_t> bad{{1, 2, 3}};
+    std::vector<cudf::groupby::aggregation_request> r2;
+    r2.emplace_back();
+    r2[0].values = cudf::column_view{cudf::data_type{cudf::type_id::INT32}, 3, bad.p, nullptr, 0};
+    r2[0].aggregations.push_back(cudf::make_sum_aggregation<cudf::groupby_aggregation>());
+    bool threw = false;
+    try {
+      gb_obj.aggregate(r2);
+    } catch (cudf::logic_error const&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+
+  // ---- inner_join corner case: {4,1,3,2,2,2,2} x {2} -> 4 pairs (join_tests.cpp:2091-2118)
+  dev_vec<int64_t> l{{4, 1, 3, 2, 2, 2, 2}};
+  dev_vec<int64_t> r{{2}};
+  cudf::table_view lt({cudf::column_view{cudf::data_type{cudf::type_id::INT64}, 7, l.p, nullptr, 0}});
+  cudf::table_view rt({cudf::column_view{cudf::data_type{cudf::type_id::INT64}, 1, r.p, nullptr, 0}});
+  auto [li, ri] = cudf::inner_join(lt, rt, cudf::null_equality::EQUAL);
+  CHECK(li->size() == 4 && ri->size() == 4);
+  std::vector<cudf::size_type> hl(4), hr(4);
+  (void)hipMemcpy(hl.data(), li->data(), 16, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hr.data(), ri->data(), 16, hipMemcpyDeviceToHost);
+  std::sort(hl.begin(), hl.end());
+  CHECK((hl == std::vector<cudf::size_type>{3, 4, 5, 6}));
+  CHECK(std::all_of(hr.begin(), hr.end(), [](auto x) { return x == 0; }));
+
+  // ---- hash_join object + gather of the joined rows (join_tests.cpp:2396-2417)
+  dev_vec<int32_t> t0{{3, 1, 2, 0, 2}};
+  dev_vec<int32_t> t1{{2, 2, 0, 4, 3}};
+  cudf::table_view t0v({cudf::column_view{cudf::data_type{cudf::type_id::INT32}, 5, t0.p, nullptr, 0}});
+  cudf::table_view t1v({cudf::column_view{cudf::data_type{cudf::type_id::INT32}, 5, t1.p, nullptr, 0}});
+  cudf::hash_join hj(t1v, cudf::null_equality::EQUAL);
+  CHECK(hj.inner_join_size(t0v) == 6);
+  auto [pl, pr] = hj.inner_join(t0v);
+  CHECK(pl->size() == 6);
+  // pylibcudf moves the index vector into a column (join.pyx:51-64); then gather
+  cudf::column lcol{std::move(*pl), rmm::device_buffer{}, 0};
+  cudf::column rcol{std::move(*pr), rmm::device_buffer{}, 0};
+  auto gl = cudf::gather(t0v, lcol.view());
+  auto gr = cudf::gather(t1v, rcol.view());
+  auto a  = to_host<int32_t>(gl->view().column(0));
+  auto b  = to_host<int32_t>(gr->view().column(0));
+  CHECK(a == b);  // joined keys agree row by row
+  std::sort(a.begin(), a.end());
+  CHECK((a == std::vector<int32_t>{0, 2, 2, 2, 2, 3}));
+  std::puts("api_compat OK");
+  return 0;
+}
