@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcudf_amd.so")
+LIB_PATH = os.environ.get("CUDF_AMD_LIB", os.path.join(_HERE, "lib", "libcudf_amd.so"))  # override: A/B builds
 
 
 class ColumnView(C.Structure):

@@ -71,6 +71,7 @@ device_table make_device_table(table_view const& t);
 #define CUDF_AMD_GLOBAL_AS __attribute__((address_space(1)))
 // one 16-byte record: moves as global_load/store_dwordx4 and ds_read/write_b128
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ __forceinline__ T gload(T const* p)
 {
@@ -80,6 +81,19 @@ template <typename T>
 __device__ __forceinline__ void gstore(T* p, T v)
 {
   *(CUDF_AMD_GLOBAL_AS T*)(p) = v;
+}
+
+// streaming (read-once / write-once) variants: the `nt` cache policy keeps such lines from displacing the
+// partially written lines the partition scatter needs the L2 to merge
+template <typename T>
+__device__ __forceinline__ T gload_stream(T const* p)
+{
+  return __builtin_nontemporal_load((CUDF_AMD_GLOBAL_AS T const*)(p));
+}
+template <typename T>
+__device__ __forceinline__ void gstore_stream(T* p, T v)
+{
+  __builtin_nontemporal_store(v, (CUDF_AMD_GLOBAL_AS T*)(p));
 }
 
 __device__ __forceinline__ bool col_is_valid(device_column const& c, int64_t i)

@@ -38,14 +38,26 @@ __device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
   }
 }
 
-// Finds or claims the slot of `key` in the LDS table. Returns -1 if the table is saturated.
+// The LDS table is an open-addressing table probed in aligned BUCKETS of four slots: the four state words of a
+// bucket are one ds_read_b128, a tag match names the one slot whose key words are worth reading, and slots of a
+// bucket are claimed in order (occupied slots form a prefix; a key moves on to the next bucket only when its bucket
+// is full). Two dependent LDS round trips resolve a row at any load factor the planner uses; slot-at-a-time linear
+// probing needed as many dependent round trips as the longest displacement among the wave's rows.
+__device__ __forceinline__ int home_bucket(uint64_t h, int cap)
+{
+  return static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(h)) * static_cast<uint32_t>(cap >> 2)) >> 32);
+}
+
+// Finds or claims the slot of `key`, one slot at a time (tail rows, tag collisions): walking the slots in order from
+// the home bucket's first slot visits the same buckets and claims the same first empty slot as the bucketed probe.
+// Returns -1 if the table is saturated.
 template <int KUT>
 __device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask)[KUT], uint32_t* st, uint64_t* keys,
                                                   int cap, uint64_t const (&key)[KUT], uint64_t h, uint32_t* nfilled,
                                                   int fill_limit, int32_t* overflow_flag)
 {
   uint32_t const tag = tag_of(h);
-  int slot = static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(h)) * static_cast<uint32_t>(cap)) >> 32);
+  int slot           = 4 * home_bucket(h, cap);
   for (int probes = 0; probes < cap; ++probes) {
     uint32_t s = __hip_atomic_load(&st[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (s == ST_EMPTY) {
@@ -105,7 +117,7 @@ constexpr int sig_pay(uint64_t s, int q) { return static_cast<int>((s >> (12 * q
 constexpr int sig_vbit(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 9)) & 0x7) - 1; }
 
 template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT, uint64_t SIG = 0>
-__global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggregate(agg_args const* __restrict__ ap)
+__global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   agg_args const& a = *ap;
@@ -246,10 +258,10 @@ __global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggr
     if (*a.overflow != 0) nsrc = 0;
   }
   constexpr int R = (KUT + PAYT <= 2) ? 4 : 2;  // rows in flight per thread
-  int64_t const B = blockDim.x;
   // Work is dealt to WAVES in batches of W = R*64 consecutive records. One big segment (a partition, a row chunk):
   // the waves interleave batches. Many short segments (the per-slice regions of an optimistic partition, the
   // partial tables of a merge round): each wave takes whole segments, so short segments still run batched.
+  int64_t const B     = blockDim.x;
   constexpr int64_t W = R * 64;
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   bool const multi = a.seg == SEG_STRIDED;
@@ -267,56 +279,123 @@ __global__ void __launch_bounds__(1024, (NACCT <= 4 && KUT <= 2) ? 8 : 4) k_aggr
     }
     int64_t const nbatches = (end - begin) / W;
     // main loop: R full rows per lane, all loads issued before the LDS work
-    for (int64_t b = multi ? 0 : wave; b < nbatches; b += multi ? 1 : nwaves) {
+    // (narrow records: the NEXT batch's loads are issued before the LDS work of this one - a wave walks its
+    // batches one after the other and 4 waves per SIMD do not hide a full HBM round trip per batch)
+    constexpr bool PREFETCH = (KUT + PAYT <= 2) && INPUT != IN_COLUMNS;
+    int64_t const bstep     = multi ? 1 : nwaves;
+    uint64_t nkey[R][KUT];
+    uint64_t npay[R][PAYT > 0 ? PAYT : 1];
+    uint32_t nvalvalid[R];
+    bool nkeep[R];
+    if constexpr (PREFETCH) {
+      int64_t const b0 = multi ? 0 : wave;
+      if (b0 < nbatches) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) nkeep[k] = load_row(begin + b0 * W + k * 64 + lane, nkey[k], npay[k], nvalvalid[k]);
+      }
+    }
+    for (int64_t b = multi ? 0 : wave; b < nbatches; b += bstep) {
       int64_t const base = begin + b * W;
       uint64_t key[R][KUT];
       uint64_t pay[R][PAYT > 0 ? PAYT : 1];
       uint32_t valvalid[R];
       bool keep[R];
+      if constexpr (PREFETCH) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) keep[k] = load_row(base + k * 64 + lane, key[k], pay[k], valvalid[k]);
-      // Batched first probe: the state word and the stored key words of the home slot of all R rows are read
-      // with independent ds_reads (one LDS round trip for the common "group already present" case); only
-      // rows that miss walk the full claim/probe protocol.
-      uint64_t h[R];
-      int slot[R];
-      uint32_t s0[R], s1[R];
-      uint64_t k0[R][KUT], k1[R][KUT];
+        for (int k = 0; k < R; ++k) {
 #pragma unroll
-      for (int k = 0; k < R; ++k) {
-        h[k]    = hash_of(key[k]);
-        slot[k] = static_cast<int>((static_cast<uint64_t>(static_cast<uint32_t>(h[k])) * static_cast<uint32_t>(cap)) >> 32);
-        int const nxt = slot[k] + 1 == cap ? 0 : slot[k] + 1;
-        s0[k]   = __hip_atomic_load(&st[slot[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        s1[k]   = __hip_atomic_load(&st[nxt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int u = 0; u < KUT; ++u) key[k][u] = nkey[k][u];
 #pragma unroll
-        for (int u = 0; u < KUT; ++u) {
-          k0[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + slot[k])] : 0;
-          k1[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + nxt)] : 0;
+          for (int u = 0; u < (PAYT > 0 ? PAYT : 1); ++u) pay[k][u] = npay[k][u];
+          valvalid[k] = nvalvalid[k];
+          keep[k]     = nkeep[k];
         }
+        if (b + bstep < nbatches) {
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            nkeep[k] = load_row(begin + (b + bstep) * W + k * 64 + lane, nkey[k], npay[k], nvalvalid[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) keep[k] = load_row(base + k * 64 + lane, key[k], pay[k], valvalid[k]);
       }
+      // Bucketed probe of all R rows together: per round, the four state words of each pending row's bucket (one
+      // ds_read_b128 each, issued back to back), then the key words of the slot whose tag matches, then the verdict.
+      uint64_t h[R];
+      int bkt[R], sl[R];
+      uint32_t pend   = 0;
+      int const nbkt  = cap >> 2;
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        if (!keep[k]) continue;
-        uint32_t const tag = tag_of(h[k]);
-        bool hit0 = s0[k] == tag, hit1 = s1[k] == tag;
+        h[k]   = hash_of(key[k]);
+        bkt[k] = home_bucket(h[k], cap);
+        sl[k]  = -1;
+        if (keep[k]) pend |= 1u << k;
+      }
+      int guard = 0;
+      while (pend != 0) {
+        asm volatile("" ::: "memory");  // the state words change under us: read them again every round
+        u32x4 sw[R];
+        int cand[R];
+        uint64_t kc[R][KUT];
 #pragma unroll
-        for (int u = 0; u < KUT; ++u) {
-          if (u < KU) {
-            hit0 = hit0 && (k0[k][u] == (key[k][u] & kmask[u]));
-            hit1 = hit1 && (k1[k][u] == (key[k][u] & kmask[u]));
+        for (int k = 0; k < R; ++k)
+          if ((pend >> k) & 1u) sw[k] = *reinterpret_cast<u32x4 const*>(st + 4 * bkt[k]);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          if (!((pend >> k) & 1u)) continue;
+          uint32_t const tag = tag_of(h[k]);
+          cand[k] = sw[k].x == tag ? 0 : (sw[k].y == tag ? 1 : (sw[k].z == tag ? 2 : (sw[k].w == tag ? 3 : -1)));
+          if (cand[k] >= 0) {
+#pragma unroll
+            for (int u = 0; u < KUT; ++u) kc[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + 4 * bkt[k] + cand[k])] : 0;
           }
         }
-        int sl = slot[k];
-        if (!hit0) {
-          // the second slot only counts when the first is occupied by another key (else the key would sit there)
-          if (hit1 && s0[k] >= 2) sl = slot[k] + 1 == cap ? 0 : slot[k] + 1;
-          else sl = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          if (!((pend >> k) & 1u)) continue;
+          uint32_t const tag = tag_of(h[k]);
+          if (cand[k] >= 0) {
+            bool eq = true;
+#pragma unroll
+            for (int u = 0; u < KUT; ++u)
+              if (u < KU) eq = eq && (kc[k][u] == (key[k][u] & kmask[u]));
+            // a different key with the same tag (2^-30 per occupied slot): resolve this row slot by slot
+            sl[k] = eq ? 4 * bkt[k] + cand[k]
+                       : lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
+            pend &= ~(1u << k);
+            continue;
+          }
+          bool const locked = sw[k].x == ST_LOCKED || sw[k].y == ST_LOCKED || sw[k].z == ST_LOCKED || sw[k].w == ST_LOCKED;
+          if (locked) continue;  // a slot of this bucket is being published (it may be this key): read again
+          int const e = sw[k].x == ST_EMPTY ? 0 : (sw[k].y == ST_EMPTY ? 1 : (sw[k].z == ST_EMPTY ? 2 : (sw[k].w == ST_EMPTY ? 3 : -1)));
+          if (e < 0) {  // full of other keys
+            bkt[k] = bkt[k] + 1 == nbkt ? 0 : bkt[k] + 1;
+            continue;
+          }
+          int const c = 4 * bkt[k] + e;
+          if (atomicCAS(&st[c], ST_EMPTY, ST_LOCKED) == ST_EMPTY) {
+#pragma unroll
+            for (int u = 0; u < KUT; ++u)
+              if (u < KU) keys[static_cast<uint32_t>(u * cap + c)] = key[k][u] & kmask[u];
+            __hip_atomic_store(&st[c], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t const nf = atomicAdd(&s_nfilled, 1u);
+            if (static_cast<int>(nf) >= fill_limit) s_overflow = 1;
+            sl[k] = c;
+            pend &= ~(1u << k);
+          }
+          // lost the race (possibly to an earlier row of this lane): read the bucket again
         }
-        if (sl >= 0) accumulate(base + k * 64 + lane, sl, pay[k], valvalid[k]);
+        if (++guard > cap + 64) {  // saturated table
+          s_overflow = 1;
+          pend       = 0;
+        }
       }
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        if (keep[k] && sl[k] >= 0) accumulate(base + k * 64 + lane, sl[k], pay[k], valvalid[k]);
     }
-    // tail: the < W records after the last full batch
+    // tail: the < W records after the last full batch (a masked partial batch instead measured 25-30 % slower)
     int64_t const tail_begin = begin + nbatches * W;
     for (int64_t r = tail_begin + (multi ? lane : static_cast<int>(threadIdx.x)); r < end; r += multi ? 64 : B) {
       uint64_t key[KUT];

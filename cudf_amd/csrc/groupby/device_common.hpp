@@ -13,10 +13,13 @@ using cudf::detail::col_is_valid;
 using cudf::detail::col_load_acc_bits;
 using cudf::detail::col_load_bits;
 using cudf::detail::gload;
+using cudf::detail::gload_stream;
+using cudf::detail::gstore_stream;
 using cudf::detail::gstore;
 using cudf::detail::mix64;
 using cudf::detail::normalize_key_bits;
 using cudf::detail::u64x2;
+using cudf::detail::u32x4;
 
 namespace {
 

@@ -168,6 +168,9 @@ struct part_args {
   int64_t region_cap;
   int32_t* region_count;
   int32_t* overflow;
+  // Write-combining scatter (optimistic, 16-byte records): records per output granule (4 = 64 B, 8 = 128 B); every
+  // global store of the tile loop is a whole, aligned granule; 0 = classic run-per-tile scatter.
+  int32_t wc_granule;
   // diagnostics (CUDF_AMD_GB_STAMPS=1): per-workgroup cycle totals of the tile phases, 8 x u64 per workgroup
   unsigned long long* stamps;
 };

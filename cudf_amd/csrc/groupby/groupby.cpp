@@ -474,7 +474,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   agg_geom ag{};
   int64_t const lds_budget = env_i64("CUDF_AMD_GB_LDS_KB", 150) * 1024;
   int const slot_bytes     = 8 * PU + 4;
-  ag.cap                   = static_cast<int32_t>(std::min<int64_t>(lds_budget / slot_bytes, 16384));
+  // a multiple of 4: the table is probed in aligned buckets of four slots (one ds_read_b128 of state words)
+  ag.cap                   = static_cast<int32_t>(std::min<int64_t>(lds_budget / slot_bytes, 16384)) & ~3;
   ag.block                 = static_cast<int32_t>(env_i64("CUDF_AMD_GB_AGG_BLOCK", 1024));
   ag.fill_limit            = static_cast<int32_t>(ag.cap * 0.6);
   CUDF_EXPECTS(ag.cap >= 64, "Aggregation state per group too large for an LDS table.");
@@ -621,6 +622,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         pa.overflow         = d_overflow;
         recA                = sc.alloc<uint64_t>(items1 * static_cast<size_t>(P1) * static_cast<size_t>(capR) * RU);
         pa.out_records      = recA;
+        // 16-byte records: write-combining scatter (whole aligned granules only); 64-byte granules at P = 1024
+        // (the carry area of 128-byte granules would not leave room for a tile), 128-byte granules at P <= 512
+        if (RU == 2 && p.KU == 1 && env_i64("CUDF_AMD_GB_WC", 1)) pa.wc_granule = static_cast<int32_t>(env_i64("CUDF_AMD_GB_WC_G", P1 > 512 ? 4 : 8));
         if (env_i64("CUDF_AMD_GB_STAMPS", 0)) pa.stamps = sc.alloc<unsigned long long>(items1 * 8);
         store_args(pa, d_pa, s);
         launch_partition_scatter(pa, d_pa, s);
