@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Summarises the rocprofv3 output of collect_profiles.sh: kernel_stats.txt (top kernels by time) and
+pmc_traffic.json (HBM bytes per launch of the groupby kernels, gfx950 corrections applied)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(sub, pat):
+    fs = glob.glob(os.path.join(out, sub, "**", pat), recursive=True)
+    return fs[0] if fs else None
+
+
+def short(name):
+    for key, label in (("k_partition_scatter", "partition_scatter"), ("k_partition_hist", "partition_hist"),
+                       ("k_aggregate", "aggregate"), ("k_finalize", "finalize"), ("k_estimate", "estimate")):
+        if key in name:
+            return label
+    return None
+
+
+# ---- kernel stats
+f = find("stats", "*kernel_stats.csv")
+lines = []
+if f:
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: -float(r.get("TotalDurationNs", r.get("Total_Duration", 0)) or 0))
+    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   ({os.path.basename(f)})")
+    lines.append(f"{'calls':>6} {'avg_ms':>10} {'total_ms':>10} {'pct':>6}  kernel")
+    for r in rows[:14]:
+        tot = float(r.get("TotalDurationNs", 0)) / 1e6
+        avg = float(r.get("AverageNs", 0)) / 1e6
+        lines.append(f"{r.get('Calls', '?'):>6} {avg:10.3f} {tot:10.3f} {float(r.get('Percentage', 0)):6.2f}  {r.get('Name', '')[:150]}")
+open(os.path.join(out, "kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:8]))
+
+# ---- PMC traffic
+res = {}
+for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        continue
+    acc = defaultdict(lambda: [0.0, set()])
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") != counter:
+            continue
+        k = short(r.get("Kernel_Name", ""))
+        if k is None:
+            continue
+        acc[k][0] += float(r["Counter_Value"])
+        acc[k][1].add(r.get("Dispatch_Id"))
+    for k, (tot, ids) in acc.items():
+        res.setdefault(k, {})[counter + "_KB"] = tot / max(1, len(ids))
+for k, d in res.items():
+    rd = 2 * d.get("FETCH_SIZE_KB", 0) * 1024  # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+    wr = d.get("WRITE_SIZE_KB", 0) * 1024
+    d.update(read_bytes_corrected=rd, write_bytes=wr, hbm_bytes_per_launch=rd + wr)
+doc = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py "
+              "--steps 3 --warmup 1 --no-cpu-baseline` (C2, 1B rows), bench_micro/collect_profiles.sh; per-launch averages. "
+              "Units: counter KB (x1024 B). gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests "
+              "at 64 B, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is taken as is.",
+       "kernels": res}
+json.dump(doc, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e9, 2) for k, v in res.items()}))

@@ -472,7 +472,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
 
   // ---- geometry
   agg_geom ag{};
-  int64_t const lds_budget = env_i64("CUDF_AMD_GB_LDS_KB", 150) * 1024;
+  int64_t const lds_budget = env_i64("CUDF_AMD_GB_LDS_KB", 159) * 1024;  // 160 KiB minus the kernels' static words
   int const slot_bytes     = 8 * PU + 4;
   // a multiple of 4: the table is probed in aligned buckets of four slots (one ds_read_b128 of state words)
   ag.cap                   = static_cast<int32_t>(std::min<int64_t>(lds_budget / slot_bytes, 16384)) & ~3;
@@ -523,8 +523,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     CUDF_EXPECTS(attempt < 4, "hash groupby: could not fit the groups into LDS tables (pathological key distribution).");
     CUDF_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, s));
     // tables needed; the group count can never exceed the row count
-    // plan for a lightly loaded table (first-probe hits): measured 5.4 ms at load 0.18 vs 8.4 ms at 0.36 on C2
-    double const plan_fill = std::max(1.0, ag.cap * 0.01 * static_cast<double>(env_i64("CUDF_AMD_GB_PLAN_LOAD_PCT", 25)));
+    // Planned table load. Bucketed probing resolves a row in two LDS round trips up to ~0.4; a lighter table means
+    // more partitions. 16-byte records (write-combining scatter): halving the fan-out saves more in the scatter
+    // (C2: 8.3 -> 7.1 ms) than the fuller tables cost the aggregate (3.1 -> 3.7 ms), so plan for 0.45/safety = 0.35.
+    bool const wc_eligible = RU == 2 && p.KU == 1 && env_i64("CUDF_AMD_GB_WC", 1) != 0;
+    double const plan_fill = std::max(1.0, ag.cap * 0.01 * static_cast<double>(env_i64("CUDF_AMD_GB_PLAN_LOAD_PCT", wc_eligible ? 45 : 25)));
     double const need = std::min(est_groups * safety, static_cast<double>(n)) / plan_fill;
     agg_args aa{};
     aa.plan     = p;
