@@ -1,6 +1,7 @@
 // SPDX-License-Identifier: Apache-2.0
 // gfx950 partition kernels of the hash-groupby engine: histogram, scan, LDS-staged multi-split scatter (engine.hpp).
 #include "device_common.hpp"
+#include "../common/wc_scatter.hpp"
 
 namespace cudf::groupby::detail {
 namespace {
@@ -362,64 +363,27 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
 
 
 // ------------------------------------------------------------------ K_scatter, write-combining form
-// Optimistic regions, 16-byte records. The classic kernel writes, per tile and partition, one run of ~T/P records
-// at an arbitrary 16-byte offset: almost every 128-byte line is written in two pieces and relies on the L2 to merge
-// them (with the merge disabled - nontemporal stores - the kernel takes 15.9 instead of 11.6 ms; isolated unaligned
-// 128-byte runs write at 1.2-1.4 TB/s against 5.8 TB/s aligned, profiles/r1_scatter_align_microbench.txt).
-// Here a partition's records leave the workgroup only as whole, aligned GRANULES of G records (64 or 128 bytes):
-// the 0..G-1 records that do not fill a granule stay in an LDS carry area and lead the partition's sequence in
-// the next tile. Per tile: rank (LDS histogram pre-loaded with the carry counts) -> one packed scan (new records |
-// granules) -> stage the new records -> issue the next tile's loads -> write the granules (G lanes per granule,
-// source = carry then stage) -> move the unwritten remainder from the stage to the carry area.
-// LDS: stage[T] rec | carry[P*(G-1)] rec | meta[P] u64 | delta[P] i64 | hist[P] u32 | gmap[(T+(G-1)P)/G] u16 | sums
+// Optimistic regions, 16-byte records (one key unit + one payload unit): common/wc_scatter.hpp does the work; this
+// kernel supplies the row loader (plain columns, generic columns, or records) and the partition digit.
 template <int RPT, int G, bool SIMPLE>
 __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   part_args const& a = *ap;
   plan_dev const& p  = a.plan;
-  int const P = a.geom.P, shift = a.geom.shift, B = blockDim.x, T = B * RPT;
-  constexpr int UT = 2, CW = G - 1;
-  int const KU = p.KU;  // 1
-  u64x2* stage        = reinterpret_cast<u64x2*>(lds_raw);
-  u64x2* carry        = stage + T;
-  uint64_t* meta      = reinterpret_cast<uint64_t*>(carry + static_cast<size_t>(P) * CW);
-  int64_t* delta      = reinterpret_cast<int64_t*>(meta + P);
-  uint32_t* hist      = reinterpret_cast<uint32_t*>(delta + P);
-  int const gmap_len  = (T + CW * P) / G + 1;
-  uint16_t* gmap      = reinterpret_cast<uint16_t*>(hist + P);
-  uint64_t* wave_sums = reinterpret_cast<uint64_t*>(gmap + ((gmap_len + 3) & ~3));
-
-  int const item       = blockIdx.x;
-  slice_range const sr = slice_of(a, item);
+  int const shift = a.geom.shift, B = blockDim.x;
+  constexpr int UT = 2;
+  slice_range const sr = slice_of(a, blockIdx.x);
   int const from_cols  = a.from_columns;
   uint64_t const* in_records = a.in_records;
-  u64x2* out = reinterpret_cast<u64x2*>(a.out_records);
   uint64_t const kmask0 = p.key_mask[0];
+  uint32_t const pmask  = static_cast<uint32_t>(a.geom.P - 1);
   uint64_t const* sbase[UT];
   if constexpr (SIMPLE) {
     sbase[0] = p.simple_base[0];
     sbase[1] = p.simple_base[1];
   }
-  // thread t owns partitions d = t + k*B: output cursor and carry count live in its registers
-  constexpr int MAXE = 2;  // P <= 2 * B
-  int64_t cursor[MAXE], region_end[MAXE];
-  uint32_t ccnt[MAXE];
-  __shared__ int s_abort;
-  if (threadIdx.x == 0) s_abort = 0;
-#pragma unroll
-  for (int k = 0; k < MAXE; ++k) {
-    int const d   = threadIdx.x + k * B;
-    cursor[k]     = (static_cast<int64_t>(d) * a.geom.slices + item) * a.region_cap;
-    region_end[k] = cursor[k] + a.region_cap;
-    ccnt[k]       = 0;
-    if (d < P) hist[d] = 0;
-  }
-  lds_barrier();
-
-  uint64_t rec[RPT][UT];
-  bool keep[RPT];
-  auto load_tile = [&](int64_t tile) {
+  auto load_tile = [&](int64_t tile, uint64_t (&rec)[RPT][UT], bool (&keep)[RPT]) {
     if (!SIMPLE && from_cols) {
       int64_t row[RPT];
       uint32_t vv[RPT];
@@ -447,123 +411,21 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
       }
     }
   };
-  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
-  if (sr.begin < sr.end) load_tile(sr.begin);
-  for (int64_t tile = sr.begin; tile < sr.end; tile += T) {
-    uint32_t dig[RPT], rank[RPT];
-    // rank within the partition's sequence: the histogram starts at the carry count
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      if (keep[k]) {
-        uint64_t const h = mix64(0x9e3779b97f4a7c15ull ^ (rec[k][0] & kmask0));
-        dig[k]  = static_cast<uint32_t>(h >> shift) & static_cast<uint32_t>(P - 1);
-        rank[k] = atomicAdd(&hist[dig[k]], 1u);
-      }
-    }
-    lds_barrier();
-    // owners: new-record count and granule count per partition; one packed scan gives stage and granule offsets
-    uint32_t tot[MAXE], wr[MAXE];
-    uint64_t local = 0;
-#pragma unroll
-    for (int k = 0; k < MAXE; ++k) {
-      int const d = threadIdx.x + k * B;
-      tot[k]      = d < P ? hist[d] : 0;
-      wr[k]       = tot[k] & ~static_cast<uint32_t>(G - 1);
-      local += static_cast<uint64_t>(tot[k] - ccnt[k]) | (static_cast<uint64_t>(wr[k] / G) << 32);
-    }
-    unsigned long long inc = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      unsigned long long const t = __shfl_up(inc, o);
-      if (lane >= o) inc += t;
-    }
-    if (lane == 63) wave_sums[wave] = inc;
-    lds_barrier();
-    if (wave == 0) {
-      unsigned long long s = lane < nwaves ? wave_sums[lane] : 0;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        unsigned long long const t = __shfl_up(s, o);
-        if (lane >= o) s += t;
-      }
-      if (lane < nwaves) wave_sums[16 + lane] = s;  // inclusive
-    }
-    lds_barrier();
-    uint64_t run             = (wave == 0 ? 0 : wave_sums[16 + wave - 1]) + inc - local;
-    uint32_t const total_gr  = static_cast<uint32_t>(wave_sums[16 + nwaves - 1] >> 32);
-    uint32_t sofs[MAXE];
-#pragma unroll
-    for (int k = 0; k < MAXE; ++k) {
-      int const d = threadIdx.x + k * B;
-      if (d < P) {
-        uint32_t const s = static_cast<uint32_t>(run), L = static_cast<uint32_t>(run >> 32);
-        sofs[k]  = s;
-        meta[d]  = static_cast<uint64_t>(s) | (static_cast<uint64_t>(L) << 16) | (static_cast<uint64_t>(ccnt[k]) << 32);
-        delta[d] = cursor[k];
-        for (uint32_t g = 0; g < wr[k] / G; ++g) gmap[L + g] = static_cast<uint16_t>(d);
-        cursor[k] += wr[k];
-        if (cursor[k] > region_end[k]) s_abort = 1;  // region too small: nothing of this tile is written
-        run += static_cast<uint64_t>(tot[k] - ccnt[k]) | (static_cast<uint64_t>(wr[k] / G) << 32);
-        hist[d] = tot[k] - wr[k];  // next tile's ranks start behind the new carry
-      }
-    }
-    lds_barrier();
-    if (s_abort) {
-      if (threadIdx.x == 0) *a.overflow = 1;
-      return;
-    }
-    // stage the new records in (owner, partition) order
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      if (keep[k]) {
-        uint64_t const m   = meta[dig[k]];
-        uint32_t const pos = static_cast<uint32_t>(m & 0xffffu) + rank[k] - static_cast<uint32_t>(m >> 32);
-        stage[pos]         = u64x2{rec[k][0], rec[k][1]};
-      }
-    }
-    // the registers are free: the next tile's loads fly under the write-out
-    if (tile + T < sr.end) load_tile(tile + T);
-    lds_barrier();
-    // write-out: G lanes per granule; sequence index q < carry count comes from the carry area, the rest from the stage
-    for (uint32_t g = threadIdx.x / G; g < total_gr; g += B / G) {
-      int const d        = gmap[g];
-      uint64_t const m   = meta[d];
-      uint32_t const s   = static_cast<uint32_t>(m & 0xffffu), L = static_cast<uint32_t>(m >> 16) & 0xffffu,
-                     c   = static_cast<uint32_t>(m >> 32);
-      uint32_t const q   = (g - L) * G + (threadIdx.x % G);
-      u64x2 v;
-      if (q < c) v = carry[static_cast<uint32_t>(d) * CW + q];
-      else v = stage[s + q - c];
-      gstore(out + delta[d] + q, v);
-    }
-    lds_barrier();
-    // remainder: sequence [max(written, old carry), total) moves from the stage to the front of the carry area
-#pragma unroll
-    for (int k = 0; k < MAXE; ++k) {
-      int const d = threadIdx.x + k * B;
-      if (d < P) {
-        uint32_t const c = ccnt[k];
-        for (uint32_t q = wr[k] > c ? wr[k] : c; q < tot[k]; ++q) carry[static_cast<uint32_t>(d) * CW + q - wr[k]] = stage[sofs[k] + q - c];
-        ccnt[k] = tot[k] - wr[k];
-      }
-    }
-    // (no barrier: the next tile touches only hist and registers before its first barrier)
-  }
-  lds_barrier();
-  // flush the carried records (the only partial granules of the region)
-#pragma unroll
-  for (int k = 0; k < MAXE; ++k) {
-    int const d = threadIdx.x + k * B;
-    if (d < P) {
-      if (cursor[k] + ccnt[k] > region_end[k]) {
-        *a.overflow = 1;
-      } else {
-        for (uint32_t q = 0; q < ccnt[k]; ++q) gstore(out + cursor[k] + q, carry[static_cast<uint32_t>(d) * CW + q]);
-        cursor[k] += ccnt[k];
-      }
-      a.region_count[static_cast<int64_t>(d) * a.geom.slices + item] = static_cast<int32_t>(cursor[k] - (region_end[k] - a.region_cap));
-    }
-  }
+  auto digit_of = [&](uint64_t const (&rec)[UT]) {
+    uint64_t const h = mix64(0x9e3779b97f4a7c15ull ^ (rec[0] & kmask0));
+    return static_cast<uint32_t>(h >> shift) & pmask;
+  };
+  cudf::detail::wc_scatter_geom g;
+  g.P            = a.geom.P;
+  g.slices       = a.geom.slices;
+  g.item         = blockIdx.x;
+  g.begin        = sr.begin;
+  g.end          = sr.end;
+  g.region_cap   = a.region_cap;
+  g.region_count = a.region_count;
+  g.overflow     = a.overflow;
+  g.out          = reinterpret_cast<u64x2*>(a.out_records);
+  cudf::detail::wc_scatter_slice<RPT, G>(lds_raw, g, load_tile, digit_of);
 }
 
 }  // namespace
@@ -619,12 +481,7 @@ static void launch_scatter_t(part_args const& a, part_args const* d_args, hipStr
 }
 
 
-std::size_t partition_wc_lds_bytes(part_geom const& g, int G)
-{
-  std::size_t const T = g.tile_rows, P = g.P;
-  std::size_t const gmap_len = (T + (G - 1) * P) / G + 1;
-  return T * 16 + P * (G - 1) * 16 + P * (8 + 8 + 4) + ((gmap_len + 3) & ~std::size_t{3}) * 2 + 32 * 8;
-}
+std::size_t partition_wc_lds_bytes(part_geom const& g, int G) { return cudf::detail::wc_scatter_lds_bytes(g.tile_rows, g.P, G); }
 
 template <int RPT, int G, bool SIMPLE>
 static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hipStream_t stream)

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 
 namespace cudf {
@@ -51,6 +52,12 @@ bool is_single64(table_view const& t)
   return size_of_id(id) == 8 && (cls == CLS_SINT || cls == CLS_UINT);
 }
 
+int64_t env_flag(char const* name, int64_t dflt)
+{
+  char const* v = std::getenv(name);
+  return v ? std::atoll(v) : dflt;
+}
+
 template <typename T>
 struct dev_scalar {  // one T in device memory, stream ordered
   rmm::device_buffer buf;
@@ -84,11 +91,33 @@ class hash_join_impl {
     if (_is_empty) return;
     _build_dev        = make_device_table(right);
     auto const rows   = static_cast<uint64_t>(right.num_rows());
-    uint64_t capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / load_factor));
-    capacity          = std::clamp<uint64_t>(capacity, rows + 1, (uint64_t{1} << 32) - 1);  // always one empty slot
+    // `load_factor` is the caller's upper bound (reference default 0.5). The probe is bound by random memory requests
+    // and a multiset walk ends at the first empty slot: 2.5 slots at load 0.5, 1.4 at 0.25 - so the table is kept
+    // at <= 0.25 unless that would take more than 1/8 of the device memory.
+    double const target_load = std::min(load_factor, 0.01 * static_cast<double>(env_flag("CUDF_AMD_JOIN_MAX_LOAD_PCT", 25)));
+    uint64_t capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / target_load));
+    if (capacity * 8 > (uint64_t{36} << 30)) capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / load_factor));
+    capacity          = std::clamp<uint64_t>(capacity, rows + 1, (uint64_t{1} << 32) - 2);  // always one empty slot
+    // CUDF_AMD_JOIN_PARTITIONED=1 (experimental): one 8-byte integer key whose NULLs can never
+    // match is stored inline (16-byte slots), big tables are sliced by the top hash bits and big inner-join probe
+    // sides are radix-partitioned on the same bits. Default: 8-byte slots, direct windowed probe.
+    bool const build_check_nulls = _has_nulls && cudf::has_nulls(right);
+    bool const key64 = is_single64(right) && (!build_check_nulls || _nulls_equal != null_equality::EQUAL);
+    _slot_words      = (key64 && env_flag("CUDF_AMD_JOIN_PARTITIONED", 0)) ? 2 : 1;
+    // big inline-key tables are sliced by the top hash bits (~2-4 MB per slice, what one XCD's L2 holds) so that a
+    // radix-partitioned probe side walks one slice at a time
+    _part_bits = 0;
+    if (_slot_words == 2 && capacity * 16 >= (static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_SLICE_MIN_MB", 32)) << 20)) {
+      uint64_t const want = capacity * 16 / (static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_SLICE_KB", 2048)) << 10);
+      while ((uint64_t{1} << _part_bits) < want && _part_bits < env_flag("CUDF_AMD_JOIN_MAX_PART_BITS", 9)) ++_part_bits;
+      _part_bits = std::max(_part_bits, 3);  // region_of_block deals partitions to the 8 XCDs
+    }
+    uint64_t const P  = std::max<uint64_t>(uint64_t{1} << _part_bits, 2);  // even capacity: 16-byte aligned slot pairs
+    capacity          = std::min<uint64_t>((capacity + P - 1) / P * P, ((uint64_t{1} << 32) - 1) / P * P);
     _capacity         = capacity;
-    _table            = rmm::device_buffer{capacity * sizeof(uint64_t), stream.value(), mr};
-    CUDF_HIP_TRY(hipMemsetAsync(_table.data(), 0xff, capacity * sizeof(uint64_t), stream.value()));
+    _slice            = capacity >> _part_bits;
+    _table            = rmm::device_buffer{capacity * sizeof(uint64_t) * _slot_words, stream.value(), mr};
+    CUDF_HIP_TRY(hipMemsetAsync(_table.data(), 0xff, capacity * sizeof(uint64_t) * _slot_words, stream.value()));
     join_args a = base_args(right, 0);
     rmm::device_buffer d_args{sizeof(join_args), stream.value(), cudf::get_current_device_resource_ref()};
     join::launch_build(a, static_cast<join_args*>(d_args.data()), stream.value());
@@ -152,11 +181,40 @@ class hash_join_impl {
     // costs ~6% of the retrieve it replaces); a caller-supplied output_size is checked against it.
     std::size_t pairs = 0;
     join_args c = base_args(left, k == 0 ? 0 : 1);
+    // Partitioned probe: big inner joins on one 8-byte key first radix-partition the probe keys on the bits that
+    // select the table slice; the count/retrieve passes then take one region per workgroup (see engine.hpp).
+    rmm::device_buffer precs{}, region_count{}, ovf{};
+    if (k == 0 && c.single64 && _part_bits > 0 && left.num_rows() >= env_flag("CUDF_AMD_JOIN_PARTITION_MIN_ROWS", 16 << 20)) {
+      int64_t const P = int64_t{1} << _part_bits, S = 256;
+      double const mean   = static_cast<double>(left.num_rows()) / static_cast<double>(P * S);
+      int64_t const cap_r = (static_cast<int64_t>(mean * 1.25 + 6.0 * std::sqrt(mean) + 16.0) + 7) / 8 * 8;
+      auto const tmp      = cudf::get_current_device_resource_ref();
+      precs        = rmm::device_buffer{static_cast<std::size_t>(P * S * cap_r) * 16, s, tmp};
+      region_count = rmm::device_buffer{static_cast<std::size_t>(P * S) * sizeof(int32_t), s, tmp};
+      ovf          = rmm::device_buffer{sizeof(int32_t), s, tmp};
+      CUDF_HIP_TRY(hipMemsetAsync(ovf.data(), 0, sizeof(int32_t), s));
+      c.precs        = static_cast<uint64_t*>(precs.data());
+      c.region_count = static_cast<int32_t*>(region_count.data());
+      c.region_cap   = cap_r;
+      c.pslices      = static_cast<int32_t>(S);
+      c.overflow     = static_cast<int32_t*>(ovf.data());
+      join::launch_probe_partition(c, static_cast<join_args*>(d_args.data()), s);
+      int32_t h_ovf = 0;
+      CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipStreamSynchronize(s));
+      if (h_ovf == 0) {
+        c.partitioned = 1;
+        c.nblocks     = static_cast<int32_t>(8 * S);  // persistent workgroups, see region_of_segment
+      } else {  // heavily repeated probe keys: some region overflowed; probe directly
+        c.precs = nullptr;
+      }
+    }
+    std::size_t const cache_len = c.partitioned ? (std::size_t{1} << _part_bits) * static_cast<std::size_t>(c.pslices) * static_cast<std::size_t>(c.region_cap)
+                                                : static_cast<std::size_t>(left.num_rows());
     rmm::device_buffer counts{(static_cast<std::size_t>(c.nblocks) + 1) * sizeof(unsigned long long), s,
                               cudf::get_current_device_resource_ref()};
     c.block_counts = static_cast<unsigned long long*>(counts.data());
-    rmm::device_buffer cache{static_cast<std::size_t>(left.num_rows()) * sizeof(uint32_t), s,
-                             cudf::get_current_device_resource_ref()};
+    rmm::device_buffer cache{cache_len * sizeof(uint32_t), s, cudf::get_current_device_resource_ref()};
     c.match_cache = static_cast<uint32_t*>(cache.data());
     join::launch_count(c, static_cast<join_args*>(d_args.data()), s);
     join::launch_scan(c, s);
@@ -175,7 +233,8 @@ class hash_join_impl {
                  std::overflow_error);
     auto out_l = std::make_unique<rmm::device_uvector<size_type>>(room, s, mr);
     auto out_r = std::make_unique<rmm::device_uvector<size_type>>(room, s, mr);
-    join_args a = base_args(left, k);
+    join_args a = c;
+    a.kind      = k;
     dev_scalar<unsigned long long> cursor{static_cast<unsigned long long>(pairs), s};  // complement appends after the pairs
     a.total        = cursor.ptr();
     a.block_counts = c.block_counts;
@@ -227,6 +286,9 @@ class hash_join_impl {
     a.probe       = make_device_table(probe);
     a.table       = const_cast<uint64_t*>(static_cast<uint64_t const*>(_table.data()));
     a.capacity    = _capacity;
+    a.slot_words  = _slot_words;
+    a.part_bits   = _part_bits;
+    a.slice       = _slice;
     a.nulls_equal = _nulls_equal == null_equality::EQUAL;
     a.check_nulls = _has_nulls && (cudf::has_nulls(_right) || cudf::has_nulls(probe));
     a.kind        = kind;
@@ -277,6 +339,9 @@ class hash_join_impl {
   bool _is_empty;
   device_table _build_dev{};
   uint64_t _capacity{0};
+  int32_t _slot_words{1};
+  int32_t _part_bits{0};
+  uint64_t _slice{0};
   rmm::device_buffer _table{};
 };
 }  // namespace detail

@@ -148,3 +148,55 @@ def test_large_properties(G):
     assert li_t.numel() == int(present[lk].sum())
     assert bool((lk[li_t] == rk[ri_t]).all())
     assert torch.unique(li_t).numel() == li_t.numel()
+
+
+@pytest.fixture
+def force_partitioned_probe(monkeypatch):
+    """Makes small inputs take the sliced table + radix-partitioned probe path (engine.hpp) that big inner joins use."""
+    monkeypatch.setenv("CUDF_AMD_JOIN_PARTITIONED", "1")
+    monkeypatch.setenv("CUDF_AMD_JOIN_SLICE_MIN_MB", "0")
+    monkeypatch.setenv("CUDF_AMD_JOIN_PARTITION_MIN_ROWS", "1")
+
+
+@pytest.mark.parametrize("nulls", [False, True])
+def test_partitioned_probe_matches_oracle(G, oracle, force_partitioned_probe, nulls):
+    """int64 keys, duplicates on both sides (several matches per probe row), optionally 5 % NULLs with
+    null_equality::UNEQUAL; 1.2M probe rows over 8 slices x 256 workgroup regions."""
+    rng = np.random.default_rng(99)
+    nl, nr = 1_200_000, 90_000
+    rk = rng.integers(0, 60_000, nr, dtype=np.int64)
+    lk = np.where(rng.random(nl) < 0.3, rng.integers(0, 60_000, nl), rng.integers(60_000, 200_000, nl)).astype(np.int64)
+    if nulls:
+        lv, rv = rng.random(nl) > 0.05, rng.random(nr) > 0.05
+        _check(G, oracle, [(lk, lv)], [(rk, rv)], False, "inner")
+    else:
+        _check(G, oracle, [lk], [rk], True, "inner")
+        _check(G, oracle, [lk], [rk], True, "left")   # non-inner kinds probe the sliced table directly
+        _check(G, oracle, [lk], [rk], True, "full")
+
+
+def test_partitioned_probe_overflow_falls_back(G, oracle, force_partitioned_probe):
+    """Half of the probe rows carry ONE key: its partition's regions overflow and the join probes directly."""
+    rng = np.random.default_rng(100)
+    nl, nr = 600_000, 50_000
+    rk = rng.permutation(100_000)[:nr].astype(np.int64)
+    lk = rng.integers(0, 100_000, nl, dtype=np.int64)
+    lk[::2] = rk[7]
+    _check(G, oracle, [lk], [rk], True, "inner")
+
+
+def test_partitioned_hash_join_object_reuse(G, oracle, force_partitioned_probe):
+    """One sliced table, several probes of different sizes (partitioned and direct) and the size API."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(101)
+    rk = rng.integers(0, 30_000, 40_000, dtype=np.int64)
+    hj = HashJoin(cudf_amd.Table([G.to_device(rk)]), NullEquality.EQUAL)
+    for nl in (5, 70_000, 300_000):
+        lk = rng.integers(0, 60_000, nl, dtype=np.int64)
+        t = cudf_amd.Table([G.to_device(lk)])
+        li, ri = hj.inner_join(t)
+        el, er = oracle.join([lk], [rk], nulls_equal=True, kind="inner")
+        assert hj.inner_join_size(t) == len(el)
+        assert kat.sorted_pairs(li.to_numpy()[0], ri.to_numpy()[0]) == kat.sorted_pairs(el, er)
