@@ -14,6 +14,8 @@ __device__ __forceinline__ uint64_t acc_identity(int op)
     case MAX_I64: return static_cast<uint64_t>(INT64_MIN);
     case MAX_U64: return 0;
     case MAX_F64: return 0xfff0000000000000ull;  // -inf
+    case MUL_I64: return 1;
+    case MUL_F64: return 0x3ff0000000000000ull;  // 1.0
     default: return 0;                            // ADD_I64 / ADD_F64
   }
 }
@@ -35,6 +37,21 @@ __device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
       __hip_atomic_fetch_max(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v)),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       break;
+    case MUL_I64:
+    case MUL_F64: {
+      // no multiply atomic: compare-and-swap loop (ds_cmpst_rtn_b64), as the reference's product (device_atomics.cuh:226-337)
+      unsigned long long* p = reinterpret_cast<unsigned long long*>(slot);
+      unsigned long long old = *p, seen;
+      do {
+        seen = old;
+        unsigned long long const next =
+          op == MUL_I64 ? seen * static_cast<unsigned long long>(v)
+                        : static_cast<unsigned long long>(__double_as_longlong(__longlong_as_double(static_cast<long long>(seen)) *
+                                                                                __longlong_as_double(static_cast<long long>(v))));
+        old = atomicCAS(p, seen, next);
+      } while (old != seen);
+      break;
+    }
   }
 }
 

@@ -42,7 +42,7 @@ struct unit_desc {
 };
 
 // Merge operator of an accumulator (identities: reference device_operators.cuh:60-76,132-139,190-197).
-enum acc_op : int8_t { ADD_I64 = 0, ADD_F64, MIN_I64, MIN_U64, MIN_F64, MAX_I64, MAX_U64, MAX_F64 };
+enum acc_op : int8_t { ADD_I64 = 0, ADD_F64, MIN_I64, MIN_U64, MIN_F64, MAX_I64, MAX_U64, MAX_F64, MUL_I64, MUL_F64 };
 // How a RAW row contributes (reference device_aggregators.cuh:24-112,428-446: null source elements are
 // skipped for everything except COUNT_ALL).
 enum acc_src : int8_t { SRC_VALUE = 0, SRC_ONE_IF_VALID, SRC_ONE, SRC_SQUARE };

@@ -173,6 +173,7 @@ bool is_engine_kind(aggregation::Kind k)
 {
   switch (k) {
     case aggregation::SUM:
+    case aggregation::PRODUCT:
     case aggregation::MIN:
     case aggregation::MAX:
     case aggregation::COUNT_VALID:
@@ -341,6 +342,9 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
       switch (agg->kind) {
         case aggregation::SUM: rs.a0 = sum_acc(SRC_VALUE); break;
         case aggregation::SUM_OF_SQUARES: rs.a0 = sum_acc(SRC_SQUARE); break;
+        case aggregation::PRODUCT:
+          rs.a0 = find_or_add_acc(p, acc_desc{static_cast<int8_t>(is_float ? MUL_F64 : MUL_I64), SRC_VALUE, static_cast<int8_t>(vidx), vbit});
+          break;
         case aggregation::MIN:
           rs.a0 = find_or_add_acc(
             p, acc_desc{static_cast<int8_t>(is_float ? MIN_F64 : (cls == CLS_SINT ? MIN_I64 : MIN_U64)), SRC_VALUE,

@@ -154,6 +154,32 @@ def test_variance_std_m2(G, oracle, vt):
     assert got[1][0][1][1] is not None and not got[1][0][1][1].all()  # singleton groups -> null variance
 
 
+@pytest.mark.parametrize("vt", ["int8", "int64", "float64", "float32"])
+def test_product(G, oracle, vt):
+    """PRODUCT (integral -> int64 wrapping, float -> same type): LDS compare-and-swap loop; integer products are
+    order-independent mod 2^64 and must be bit-exact, float products carry one rounding per factor."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(22)
+    n = 40_000
+    k = rng.integers(0, 500, n, dtype=np.int64)
+    npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
+    v = (0.9 + 0.2 * rng.random(n)).astype(npt) if np.dtype(npt).kind == "f" else rng.integers(-3, 4, n).astype(npt)
+    vv = rng.random(n) > 0.1
+    got = kat.sort_groups(*G.groupby([k], [(HostColumn(v, vv, vt), ["product", "count_valid"])]))
+    exp = kat.sort_groups(*oracle.groupby([k], [(HostColumn(v, vv, vt), ["product", "count_valid"])]))
+    kat.compare_columns(got[0][0], exp[0][0], "keys")
+    kat.compare_columns(got[1][0][1], exp[1][0][1], "count_valid")
+    if np.dtype(npt).kind == "f":
+        a, e = got[1][0][0], exp[1][0][0]
+        assert a[2] == e[2] and np.array_equal(a[1], e[1])
+        # ~80 factors per group in [0.9, 1.1]: relative error <= factors * eps of the result type
+        rel = 200 * (np.finfo(np.float32).eps if vt == "float32" else np.finfo(np.float64).eps)
+        ok = a[1] if a[1] is not None else np.ones(len(a[0]), bool)
+        assert np.allclose(a[0][ok].astype(np.float64), e[0][ok].astype(np.float64), rtol=rel, atol=0.0)
+    else:
+        kat.compare_columns(got[1][0][0], exp[1][0][0], "product")
+
+
 def test_sliced_columns_offset(G, oracle):
     """Arrow offset: element i at data[offset+i], validity at bit offset+i."""
     from oracle.oracle import HostColumn
