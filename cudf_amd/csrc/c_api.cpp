@@ -292,6 +292,69 @@ cudf_amd_status cudf_amd_hash_join_size(cudf_amd_hash_join_t h, const cudf_amd_c
   });
 }
 
+cudf_amd_status cudf_amd_hash_join_match_counts(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys,
+                                                int32_t num_left, int32_t kind, void* stream, cudf_amd_table_t* out_counts)
+{
+  return guarded([&] {
+    *out_counts = nullptr;
+    CUDF_EXPECTS(h != nullptr && h->hj != nullptr, "null hash_join handle", std::invalid_argument);
+    CUDF_EXPECTS(kind >= 0 && kind <= 2, "join kind must be 0 (inner), 1 (left) or 2 (full)", std::invalid_argument);
+    auto const l = to_table(left_keys, num_left);
+    cudf::stream_ref const s{as_stream(stream)};
+    auto ctx = kind == 0 ? h->hj->inner_join_match_context(l, s)
+                         : kind == 1 ? h->hj->left_join_match_context(l, s) : h->hj->full_join_match_context(l, s);
+    auto t = std::make_unique<cudf_amd_table_s>();
+    t->cols.push_back(std::make_unique<cudf::column>(std::move(*ctx._match_counts), rmm::device_buffer{}, 0));
+    *out_counts = t.release();
+  });
+}
+
+cudf_amd_status cudf_amd_hash_join_probe_range(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys,
+                                               int32_t num_left, const int32_t* match_counts, int32_t kind,
+                                               int32_t left_start, int32_t left_end, void* stream,
+                                               cudf_amd_table_t* out_indices)
+{
+  return guarded([&] {
+    *out_indices = nullptr;
+    CUDF_EXPECTS(h != nullptr && h->hj != nullptr, "null hash_join handle", std::invalid_argument);
+    CUDF_EXPECTS(kind >= 0 && kind <= 2, "join kind must be 0 (inner), 1 (left) or 2 (full)", std::invalid_argument);
+    auto const l = to_table(left_keys, num_left);
+    cudf::stream_ref const s{as_stream(stream)};
+    cudf::join_partition_context ctx{nullptr, left_start, left_end};
+    if (match_counts != nullptr) {
+      // the context only has to carry the counts the caller already holds: a non-owning copy is not expressible
+      // with device_uvector, so the counts are duplicated (4 bytes per left row)
+      auto counts = std::make_unique<rmm::device_uvector<cudf::size_type>>(static_cast<std::size_t>(l.num_rows()), s.value(),
+                                                                          cudf::get_current_device_resource_ref());
+      if (l.num_rows() > 0)
+        CUDF_HIP_TRY(hipMemcpyAsync(counts->data(), match_counts, static_cast<std::size_t>(l.num_rows()) * sizeof(cudf::size_type),
+                                    hipMemcpyDeviceToDevice, s.value()));
+      ctx.left_table_context = std::make_unique<cudf::join_match_context>(l, std::move(counts));
+    }
+    auto p = kind == 0 ? h->hj->partitioned_inner_join(ctx, s)
+                       : kind == 1 ? h->hj->partitioned_left_join(ctx, s) : h->hj->partitioned_full_join(ctx, s);
+    *out_indices = indices_to_table(std::move(p));
+  });
+}
+
+cudf_amd_status cudf_amd_hash_join_finalize_full(const int32_t* const* left_partials, const int32_t* const* right_partials,
+                                                 const uint64_t* partial_sizes, int32_t num_partials,
+                                                 int32_t left_num_rows, int32_t right_num_rows, void* stream,
+                                                 cudf_amd_table_t* out_indices)
+{
+  return guarded([&] {
+    *out_indices = nullptr;
+    CUDF_EXPECTS(num_partials >= 0, "negative number of partial results", std::invalid_argument);
+    std::vector<std::pair<cudf::size_type const*, std::size_t>> lp, rp;
+    for (int32_t i = 0; i < num_partials; ++i) {
+      lp.emplace_back(left_partials[i], static_cast<std::size_t>(partial_sizes[i]));
+      rp.emplace_back(right_partials[i], static_cast<std::size_t>(partial_sizes[i]));
+    }
+    cudf::stream_ref const s{as_stream(stream)};
+    *out_indices = indices_to_table(cudf::hash_join::finalize_partitioned_full_join(lp, rp, left_num_rows, right_num_rows, s));
+  });
+}
+
 cudf_amd_status cudf_amd_hash_partition(const cudf_amd_column_view* input, int32_t num_columns,
                                         const int32_t* columns_to_hash, int32_t num_hash_columns, int32_t num_partitions,
                                         uint32_t seed, void* stream, cudf_amd_table_t* out_table, int32_t* out_offsets)

@@ -58,6 +58,10 @@ struct join_args {
   // there are further matches. The retrieve pass streams this array (coalesced) and only re-walks the table for
   // rows with several matches, instead of repeating 500M random probes (C3: 29 ms -> ~2 ms).
   uint32_t* match_cache;
+  // optional per-probe-row match counts (join_match_context); left/full kinds count a lonely row as 1
+  size_type* row_counts;
+  // probe rows are rows [probe_row_base, ...) of a larger left table (partitioned_*_join): added to emitted indices
+  int64_t probe_row_base;
 };
 constexpr uint32_t MATCH_NONE  = 0xffffffffu;
 constexpr uint32_t MATCH_MULTI = 0x80000000u;
@@ -71,5 +75,7 @@ void launch_scan(join_args const& a, hipStream_t stream);
 void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream);
 // full join: appends (JoinNoMatch, r) for every build row with build_matched[r] == 0
 void launch_complement(join_args const& a, join_args* d_args, hipStream_t stream);
+// finalize_partitioned_full_join: build_matched[r] = 1 for every r != JoinNoMatch in right_indices[0..n)
+void launch_mark_matched(size_type const* right_indices, std::size_t n, uint8_t* build_matched, hipStream_t stream);
 
 }  // namespace cudf::detail::join

@@ -8,6 +8,7 @@
 
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
+#include <cudf/null_mask.hpp>
 #include <cudf/utilities/error.hpp>
 
 #include <algorithm>
@@ -155,8 +156,60 @@ class hash_join_impl {
     return static_cast<std::size_t>(total);
   }
 
+  // Per-left-row match counts (reference inner/left/full_join_match_context, hash_join.hpp:276-329).
+  [[nodiscard]] std::unique_ptr<rmm::device_uvector<size_type>> match_counts(table_view const& left, join_kind kind,
+                                                                             stream_ref stream,
+                                                                             rmm::device_async_resource_ref mr) const
+  {
+    validate_probe(left);
+    hipStream_t const s = stream.value();
+    auto const n        = static_cast<std::size_t>(left.num_rows());
+    auto out            = std::make_unique<rmm::device_uvector<size_type>>(n, s, mr);
+    if (n == 0) return out;
+    if (_is_empty) {  // nothing to match: 0 per row, or the row's own JoinNoMatch pair
+      std::vector<size_type> h(n, kind == join_kind::INNER_JOIN ? 0 : 1);
+      CUDF_HIP_TRY(hipMemcpyAsync(out->data(), h.data(), n * sizeof(size_type), hipMemcpyHostToDevice, s));
+      CUDF_HIP_TRY(hipStreamSynchronize(s));
+      return out;
+    }
+    join_args a = base_args(left, kind == join_kind::INNER_JOIN ? 0 : 1);
+    rmm::device_buffer counts{(static_cast<std::size_t>(a.nblocks) + 1) * sizeof(unsigned long long), s,
+                              cudf::get_current_device_resource_ref()};
+    a.block_counts = static_cast<unsigned long long*>(counts.data());
+    rmm::device_buffer cache{n * sizeof(uint32_t), s, cudf::get_current_device_resource_ref()};
+    a.match_cache = static_cast<uint32_t*>(cache.data());
+    a.row_counts  = out->data();
+    rmm::device_buffer d_args{sizeof(join_args), s, cudf::get_current_device_resource_ref()};
+    join::launch_count(a, static_cast<join_args*>(d_args.data()), s);
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    return out;
+  }
+
+  // Join of rows [start, end) of the context's left table; left indices refer to the complete table (reference
+  // partitioned_inner/left/full_join, hash_join.hpp:353-412). The full-join form emits the probe side only.
+  [[nodiscard]] join_index_pair partitioned(join_partition_context const& ctx, join_kind kind, stream_ref stream,
+                                            rmm::device_async_resource_ref mr) const
+  {
+    CUDF_EXPECTS(ctx.left_table_context != nullptr, "join_partition_context has no match context", std::invalid_argument);
+    CUDF_EXPECTS(ctx.left_table_context->_match_counts != nullptr, "join match context has no match counts",
+                 std::invalid_argument);
+    auto const& left = ctx.left_table_context->_left_table;
+    CUDF_EXPECTS(ctx.left_start_idx >= 0 && ctx.left_start_idx <= ctx.left_end_idx && ctx.left_end_idx <= left.num_rows(),
+                 "join partition is outside the bounds of the left table", std::invalid_argument);
+    std::vector<column_view> cols;
+    for (auto const& c : left) {
+      size_type nulls = 0;
+      if (c.nullable() && c.null_count() > 0)
+        nulls = cudf::null_count(c.null_mask(), c.offset() + ctx.left_start_idx, c.offset() + ctx.left_end_idx, stream);
+      cols.emplace_back(c.type(), ctx.left_end_idx - ctx.left_start_idx, c.head(), c.null_mask(), nulls,
+                        c.offset() + ctx.left_start_idx);
+    }
+    auto const k = kind == join_kind::FULL_JOIN ? join_kind::LEFT_JOIN : kind;
+    return probe(table_view{cols}, k, std::nullopt, stream, mr, ctx.left_start_idx);
+  }
+
   [[nodiscard]] join_index_pair probe(table_view const& left, join_kind kind, std::optional<std::size_t> output_size,
-                                      stream_ref stream, rmm::device_async_resource_ref mr) const
+                                      stream_ref stream, rmm::device_async_resource_ref mr, int64_t row_base = 0) const
   {
     validate_probe(left);
     auto empty_pair = [&] {
@@ -166,7 +219,7 @@ class hash_join_impl {
     if (kind == join_kind::INNER_JOIN) {
       if (is_trivial_join(left, _right, kind)) return empty_pair();
     } else {
-      if (_is_empty) return trivial_left(left, stream, mr);
+      if (_is_empty) return trivial_left(left, stream, mr, row_base);
       if (is_trivial_join(left, _right, kind)) {
         // left side has no rows: a full join still returns every right row unmatched
         if (kind == join_kind::FULL_JOIN && !left.is_empty() && _right.num_rows() > 0) return trivial_right(stream, mr);
@@ -181,6 +234,7 @@ class hash_join_impl {
     // costs ~6% of the retrieve it replaces); a caller-supplied output_size is checked against it.
     std::size_t pairs = 0;
     join_args c = base_args(left, k == 0 ? 0 : 1);
+    c.probe_row_base = row_base;
     // Partitioned probe: big inner joins on one 8-byte key first radix-partition the probe keys on the bits that
     // select the table slice; the count/retrieve passes then take one region per workgroup (see engine.hpp).
     rmm::device_buffer precs{}, region_count{}, ovf{};
@@ -304,11 +358,12 @@ class hash_join_impl {
   }
 
   // right side empty: every left row pairs with JoinNoMatch (reference get_trivial_left_join_indices)
-  static join_index_pair trivial_left(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr)
+  static join_index_pair trivial_left(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr,
+                                      int64_t row_base = 0)
   {
     auto const n = static_cast<std::size_t>(left.num_rows());
     std::vector<size_type> l(n), r(n, JoinNoMatch);
-    for (std::size_t i = 0; i < n; ++i) l[i] = static_cast<size_type>(i);
+    for (std::size_t i = 0; i < n; ++i) l[i] = static_cast<size_type>(static_cast<int64_t>(i) + row_base);
     auto out_l = std::make_unique<rmm::device_uvector<size_type>>(n, stream.value(), mr);
     auto out_r = std::make_unique<rmm::device_uvector<size_type>>(n, stream.value(), mr);
     if (n) {
@@ -389,6 +444,93 @@ std::size_t hash_join::left_join_size(table_view const& left, stream_ref stream)
 std::size_t hash_join::full_join_size(table_view const& left, stream_ref stream, rmm::device_async_resource_ref) const
 {
   return _impl->join_size(left, join_kind::FULL_JOIN, stream);
+}
+
+join_match_context hash_join::inner_join_match_context(table_view const& left, stream_ref stream,
+                                                       rmm::device_async_resource_ref mr) const
+{
+  return join_match_context{left, _impl->match_counts(left, join_kind::INNER_JOIN, stream, mr)};
+}
+join_match_context hash_join::left_join_match_context(table_view const& left, stream_ref stream,
+                                                      rmm::device_async_resource_ref mr) const
+{
+  return join_match_context{left, _impl->match_counts(left, join_kind::LEFT_JOIN, stream, mr)};
+}
+join_match_context hash_join::full_join_match_context(table_view const& left, stream_ref stream,
+                                                      rmm::device_async_resource_ref mr) const
+{
+  return join_match_context{left, _impl->match_counts(left, join_kind::FULL_JOIN, stream, mr)};
+}
+join_index_pair hash_join::partitioned_inner_join(join_partition_context const& context, stream_ref stream,
+                                                  rmm::device_async_resource_ref mr) const
+{
+  return _impl->partitioned(context, join_kind::INNER_JOIN, stream, mr);
+}
+join_index_pair hash_join::partitioned_left_join(join_partition_context const& context, stream_ref stream,
+                                                 rmm::device_async_resource_ref mr) const
+{
+  return _impl->partitioned(context, join_kind::LEFT_JOIN, stream, mr);
+}
+join_index_pair hash_join::partitioned_full_join(join_partition_context const& context, stream_ref stream,
+                                                 rmm::device_async_resource_ref mr) const
+{
+  return _impl->partitioned(context, join_kind::FULL_JOIN, stream, mr);
+}
+// Concatenates the partial probe-side results and appends (JoinNoMatch, r) for every right row r that no partial
+// matched (reference hash_join.hpp:414-441, join_utils.cu:45-221).
+join_index_pair hash_join::finalize_partitioned_full_join(
+  std::vector<std::pair<size_type const*, std::size_t>> const& left_partials,
+  std::vector<std::pair<size_type const*, std::size_t>> const& right_partials, size_type left_table_num_rows,
+  size_type right_table_num_rows, stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(left_partials.size() == right_partials.size(), "left and right partial results differ in number",
+               std::invalid_argument);
+  CUDF_EXPECTS(left_table_num_rows >= 0 && right_table_num_rows >= 0, "negative table size", std::invalid_argument);
+  hipStream_t const s = stream.value();
+  std::size_t probe_pairs = 0;
+  for (std::size_t i = 0; i < left_partials.size(); ++i) {
+    CUDF_EXPECTS(left_partials[i].second == right_partials[i].second, "partial index vectors differ in size",
+                 std::invalid_argument);
+    probe_pairs += left_partials[i].second;
+  }
+  std::size_t const room = probe_pairs + static_cast<std::size_t>(right_table_num_rows);
+  CUDF_EXPECTS(room <= static_cast<std::size_t>(std::numeric_limits<size_type>::max()),
+               "Join result exceeds the maximum column size", std::overflow_error);
+  auto tmp = cudf::get_current_device_resource_ref();
+  rmm::device_uvector<size_type> l(room, s, tmp), r(room, s, tmp);
+  rmm::device_buffer matched{static_cast<std::size_t>(right_table_num_rows), s, tmp};
+  CUDF_HIP_TRY(hipMemsetAsync(matched.data(), 0, matched.size(), s));
+  std::size_t pos = 0;
+  for (std::size_t i = 0; i < left_partials.size(); ++i) {
+    std::size_t const m = left_partials[i].second;
+    if (m == 0) continue;
+    CUDF_HIP_TRY(hipMemcpyAsync(l.data() + pos, left_partials[i].first, m * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(r.data() + pos, right_partials[i].first, m * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+    detail::join::launch_mark_matched(right_partials[i].first, m, static_cast<uint8_t*>(matched.data()), s);
+    pos += m;
+  }
+  std::size_t total = probe_pairs;
+  if (right_table_num_rows > 0) {
+    detail::join_args a{};
+    a.build.nrows   = right_table_num_rows;
+    a.build_matched = static_cast<uint8_t*>(matched.data());
+    a.out_probe     = l.data();
+    a.out_build     = r.data();
+    a.out_capacity  = room;
+    detail::dev_scalar<unsigned long long> cursor{static_cast<unsigned long long>(probe_pairs), s};
+    a.total = cursor.ptr();
+    rmm::device_buffer d_args{sizeof(detail::join_args), s, tmp};
+    detail::join::launch_complement(a, static_cast<detail::join_args*>(d_args.data()), s);
+    total = static_cast<std::size_t>(cursor.value());
+  }
+  auto out_l = std::make_unique<rmm::device_uvector<size_type>>(total, s, mr);
+  auto out_r = std::make_unique<rmm::device_uvector<size_type>>(total, s, mr);
+  if (total) {
+    CUDF_HIP_TRY(hipMemcpyAsync(out_l->data(), l.data(), total * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(out_r->data(), r.data(), total * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+  }
+  CUDF_HIP_TRY(hipStreamSynchronize(s));
+  return {std::move(out_l), std::move(out_r)};
 }
 
 // ---------------------------------------------------------------- free functions

@@ -251,7 +251,11 @@ __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict
           }
         }
         gstore(a.match_cache + j[k], cnt > 1 ? (first | MATCH_MULTI) : first);
-        local_count += (cnt == 0 && kind != 0) ? 1u : cnt;  // left/full joins emit lonely probe rows once
+        unsigned int const emitted = (cnt == 0 && kind != 0) ? 1u : cnt;  // left/full joins emit lonely probe rows once
+        if constexpr (!PART) {
+          if (a.row_counts != nullptr) gstore(a.row_counts + j[k], static_cast<size_type>(emitted));
+        }
+        local_count += emitted;
       }
     }
   }
@@ -318,13 +322,13 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
     uint32_t const c  = live ? gload(a.match_cache + j) : MATCH_NONE;
     bool const none   = c == MATCH_NONE;
     bool const multi  = !none && (c & MATCH_MULTI);
-    size_type prow    = static_cast<size_type>(j);
+    size_type prow    = static_cast<size_type>(j + a.probe_row_base);
     uint64_t pkey     = 0;
     if constexpr (PART) {
       if (live && !none) {
         u64x2 const v = gload(precs + j);
         pkey          = v.x;
-        prow          = static_cast<size_type>(v.y);
+        prow          = static_cast<size_type>(static_cast<int64_t>(v.y) + a.probe_row_base);
       }
     }
     // zero or one match: straight from the cache
@@ -446,6 +450,15 @@ __global__ void __launch_bounds__(256) k_complement(join_args const* __restrict_
   }
 }
 
+__global__ void __launch_bounds__(256) k_mark_matched(size_type const* right_indices, std::size_t n, uint8_t* build_matched)
+{
+  for (std::size_t i = blockIdx.x * static_cast<std::size_t>(blockDim.x) + threadIdx.x; i < n;
+       i += static_cast<std::size_t>(gridDim.x) * blockDim.x) {
+    size_type const r = gload(right_indices + i);
+    if (r != JoinNoMatch) gstore(build_matched + r, uint8_t{1});
+  }
+}
+
 unsigned grid_for(int64_t n)
 {
   int64_t const blocks = (n + 255) / 256;
@@ -503,6 +516,12 @@ void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream)
   else if (a.single64 && a.slot_words == 2) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64_INLINE, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else if (a.single64) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else hipLaunchKernelGGL((k_probe_retrieve<MODE_GENERIC, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+void launch_mark_matched(size_type const* right_indices, std::size_t n, uint8_t* build_matched, hipStream_t stream)
+{
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_mark_matched, dim3(grid_for(static_cast<int64_t>(n))), dim3(256), 0, stream, right_indices, n, build_matched);
   CUDF_HIP_TRY(hipGetLastError());
 }
 void launch_complement(join_args const& a, join_args* d_args, hipStream_t stream)

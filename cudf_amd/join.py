@@ -31,6 +31,23 @@ def full_join(left_keys: Table, right_keys: Table, nulls_equal: NullEquality = N
     return _join(left_keys, right_keys, nulls_equal, "full", stream)
 
 
+class JoinMatchContext:
+    """cudf::join_match_context (reference join.hpp:81-108): the left table of a probe and its per-row match counts."""
+
+    def __init__(self, left_table: Table, match_counts):
+        self._left_table = left_table
+        self._match_counts = match_counts  # INT32 Column, one entry per left row
+
+
+class JoinPartitionContext:
+    """cudf::join_partition_context (reference join.hpp:120-125): rows [left_start_idx, left_end_idx) of a match context."""
+
+    def __init__(self, left_table_context: JoinMatchContext, left_start_idx: int, left_end_idx: int):
+        self.left_table_context = left_table_context
+        self.left_start_idx = int(left_start_idx)
+        self.left_end_idx = int(left_end_idx)
+
+
 class HashJoin:
     """cudf::hash_join(right, [has_nulls], compare_nulls, [load_factor]). `has_nulls`: True / False / None
     (None selects the two-argument constructor, which assumes nulls may be present)."""
@@ -64,6 +81,60 @@ class HashJoin:
         _lib.check(_lib.load().cudf_amd_hash_join_size(self._h, left_keys._views(), left_keys.num_columns(), _KIND[kind],
                                                        _stream_ptr(stream), C.byref(n)))
         return n.value
+
+    def _match_context(self, left_keys, kind, stream):
+        out = C.c_void_p()
+        _lib.check(_lib.load().cudf_amd_hash_join_match_counts(self._h, left_keys._views(), left_keys.num_columns(),
+                                                               _KIND[kind], _stream_ptr(stream), C.byref(out)))
+        return JoinMatchContext(left_keys, Table._from_handle(out).columns()[0])
+
+    def inner_join_match_context(self, left_keys, stream=None):
+        return self._match_context(left_keys, "inner", stream)
+
+    def left_join_match_context(self, left_keys, stream=None):
+        return self._match_context(left_keys, "left", stream)
+
+    def full_join_match_context(self, left_keys, stream=None):
+        return self._match_context(left_keys, "full", stream)
+
+    def _partitioned(self, context, kind, stream):
+        ctx = context.left_table_context
+        left = ctx._left_table if ctx is not None else None
+        if left is None:
+            raise ValueError("join_partition_context has no match context")
+        counts = ctx._match_counts
+        out = C.c_void_p()
+        _lib.check(_lib.load().cudf_amd_hash_join_probe_range(
+            self._h, left._views(), left.num_columns(), None if counts is None else C.c_void_p(counts.data_ptr()),
+            _KIND[kind], context.left_start_idx, context.left_end_idx, _stream_ptr(stream), C.byref(out)))
+        cols = Table._from_handle(out).columns()
+        return cols[0], cols[1]
+
+    def partitioned_inner_join(self, context, stream=None):
+        return self._partitioned(context, "inner", stream)
+
+    def partitioned_left_join(self, context, stream=None):
+        return self._partitioned(context, "left", stream)
+
+    def partitioned_full_join(self, context, stream=None):
+        return self._partitioned(context, "full", stream)
+
+    @staticmethod
+    def finalize_partitioned_full_join(left_partials, right_partials, left_table_num_rows, right_table_num_rows, stream=None):
+        n = len(left_partials)
+        if n != len(right_partials):
+            raise ValueError("left and right partial results differ in number")
+        lp = (C.c_void_p * max(n, 1))(*[c.data_ptr() for c in left_partials])
+        rp = (C.c_void_p * max(n, 1))(*[c.data_ptr() for c in right_partials])
+        for a, b in zip(left_partials, right_partials):
+            if a.size() != b.size():
+                raise ValueError("partial index vectors differ in size")
+        sz = (C.c_uint64 * max(n, 1))(*[c.size() for c in left_partials])
+        out = C.c_void_p()
+        _lib.check(_lib.load().cudf_amd_hash_join_finalize_full(lp, rp, sz, n, int(left_table_num_rows),
+                                                                int(right_table_num_rows), _stream_ptr(stream), C.byref(out)))
+        cols = Table._from_handle(out).columns()
+        return cols[0], cols[1]
 
     def inner_join(self, left_keys, output_size=None, stream=None):
         return self._probe(left_keys, "inner", output_size, stream)

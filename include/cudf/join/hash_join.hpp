@@ -48,6 +48,34 @@ class hash_join {
   [[nodiscard]] std::size_t full_join_size(table_view const& left, stream_ref stream = get_default_stream(),
                                            rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
 
+  // Chunked probing (reference hash_join.hpp:276-441): per-left-row match counts, then the join of a row range of the
+  // left table; returned left indices refer to the complete left table. Left/full contexts count a row without a
+  // match as 1 (its JoinNoMatch pair). partitioned_full_join emits the probe side only; the unmatched right rows are
+  // appended once by finalize_partitioned_full_join from the collected partial results.
+  [[nodiscard]] join_match_context inner_join_match_context(
+    table_view const& left, stream_ref stream = get_default_stream(),
+    rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] join_match_context left_join_match_context(
+    table_view const& left, stream_ref stream = get_default_stream(),
+    rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] join_match_context full_join_match_context(
+    table_view const& left, stream_ref stream = get_default_stream(),
+    rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] join_index_pair partitioned_inner_join(
+    join_partition_context const& context, stream_ref stream = get_default_stream(),
+    rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] join_index_pair partitioned_left_join(
+    join_partition_context const& context, stream_ref stream = get_default_stream(),
+    rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] join_index_pair partitioned_full_join(
+    join_partition_context const& context, stream_ref stream = get_default_stream(),
+    rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
+  [[nodiscard]] static join_index_pair finalize_partitioned_full_join(
+    std::vector<std::pair<size_type const*, std::size_t>> const& left_partials,
+    std::vector<std::pair<size_type const*, std::size_t>> const& right_partials, size_type left_table_num_rows,
+    size_type right_table_num_rows, stream_ref stream = get_default_stream(),
+    rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+
  private:
   std::unique_ptr<detail::hash_join_impl const> _impl;
 };

@@ -117,6 +117,25 @@ cudf_amd_status cudf_amd_hash_join_probe(cudf_amd_hash_join_t h, const cudf_amd_
 cudf_amd_status cudf_amd_hash_join_size(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys, int32_t num_left,
                                         int32_t kind, void* stream, uint64_t* out_size);
 
+/* hash_join::{inner,left,full}_join_match_context (reference hash_join.hpp:276-329): out_counts = table of ONE INT32
+ * column, the number of pairs each left row contributes (left/full kinds count a row without a match as 1). */
+cudf_amd_status cudf_amd_hash_join_match_counts(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys,
+                                                int32_t num_left, int32_t kind, void* stream, cudf_amd_table_t* out_counts);
+/* hash_join::partitioned_{inner,left,full}_join (reference hash_join.hpp:353-412): the join of rows
+ * [left_start, left_end) of the left table whose match counts are `match_counts` (device pointer to num_rows INT32,
+ * from cudf_amd_hash_join_match_counts); left indices refer to the complete left table. kind 2 emits the probe side
+ * only: finish with cudf_amd_hash_join_finalize_full. */
+cudf_amd_status cudf_amd_hash_join_probe_range(cudf_amd_hash_join_t h, const cudf_amd_column_view* left_keys,
+                                               int32_t num_left, const int32_t* match_counts, int32_t kind,
+                                               int32_t left_start, int32_t left_end, void* stream,
+                                               cudf_amd_table_t* out_indices);
+/* hash_join::finalize_partitioned_full_join (reference hash_join.hpp:414-441): concatenates the partial results
+ * (device pointers, sizes in elements) and appends (JoinNoMatch, r) for every right row no partial matched. */
+cudf_amd_status cudf_amd_hash_join_finalize_full(const int32_t* const* left_partials, const int32_t* const* right_partials,
+                                                 const uint64_t* partial_sizes, int32_t num_partials,
+                                                 int32_t left_num_rows, int32_t right_num_rows, void* stream,
+                                                 cudf_amd_table_t* out_indices);
+
 /* ---- cudf::hash_partition(input, columns_to_hash, num_partitions, HASH_MURMUR3, seed, stream, mr)
  * (reference cpp/include/cudf/partitioning.hpp; src/partitioning/partitioning.cu:925-947). out_offsets receives
  * num_partitions start offsets (first is 0), as the reference's std::vector<size_type>. */

@@ -200,3 +200,84 @@ def test_partitioned_hash_join_object_reuse(G, oracle, force_partitioned_probe):
         el, er = oracle.join([lk], [rk], nulls_equal=True, kind="inner")
         assert hj.inner_join_size(t) == len(el)
         assert kat.sorted_pairs(li.to_numpy()[0], ri.to_numpy()[0]) == kat.sorted_pairs(el, er)
+
+
+# ---------------------------------------------------------------- match contexts / partitioned probes
+_T0 = [(np.array([3, 1, 2, 0, 2], np.int32), None), (np.array([1, 1, 0, 4, 0], np.int32), np.array([1, 1, 0, 1, 1], bool))]
+_T1 = [(np.array([2, 2, 0, 4, 3], np.int32), None), (np.array([1, 0, 1, 2, 1], np.int32), np.array([1, 0, 1, 1, 1], bool))]
+# reference join_tests.cpp:2418-2482 (inner), :2484-2534 (left); the string key column is encoded as int32 codes
+_MATCH_KATS = [
+    ("inner", [0], True, [1, 0, 2, 1, 2]), ("inner", [0, 1], True, [1, 0, 1, 0, 0]),
+    ("inner", [0], False, [1, 0, 2, 1, 2]), ("inner", [0, 1], False, [1, 0, 0, 0, 0]),
+    ("left", [0], True, [1, 1, 2, 1, 2]), ("left", [0, 1], True, [1, 1, 1, 1, 1]), ("left", [0, 1], False, [1, 1, 1, 1, 1]),
+    ("full", [0], True, [1, 1, 2, 1, 2]),
+]
+
+
+def _hash_join(G, right_cols, nulls_equal):
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    t = cudf_amd.Table([G.to_device(c if c[1] is not None else c[0]) for c in right_cols])
+    return HashJoin(t, NullEquality.EQUAL if nulls_equal else NullEquality.UNEQUAL), t
+
+
+@pytest.mark.parametrize("kind,on,nulls_equal,expect", _MATCH_KATS)
+def test_match_context_kat(G, kind, on, nulls_equal, expect):
+    import cudf_amd
+    hj, _keep = _hash_join(G, [_T1[i] for i in on], nulls_equal)
+    left = cudf_amd.Table([G.to_device(_T0[i] if _T0[i][1] is not None else _T0[i][0]) for i in on])
+    ctx = getattr(hj, f"{kind}_join_match_context")(left)
+    counts = ctx._match_counts.to_numpy()[0]
+    assert counts.dtype == np.int32 and counts.tolist() == expect
+    assert int(counts.sum()) == getattr(hj, f"{kind}_join_size")(left) or kind == "full"
+
+
+@pytest.mark.parametrize("kind", ["inner", "left", "full"])
+@pytest.mark.parametrize("nulls_equal", [True, False])
+def test_partitioned_join_equals_whole_join(G, oracle, kind, nulls_equal):
+    """Chunked probing (reference join_tests.cpp:1120-1180 shape): the union of partitioned_*_join over row ranges of
+    the left table equals the whole join; per-range sizes equal the sums of the match counts; left indices refer to
+    the complete left table. Full join: finalize_partitioned_full_join appends the unmatched right rows."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin, JoinPartitionContext
+    rng = np.random.default_rng(77)
+    nl, nr = 50_000, 6_000
+    rk = rng.integers(0, 4_000, nr, dtype=np.int64)
+    lk = rng.integers(0, 8_000, nl, dtype=np.int64)
+    lv, rv = rng.random(nl) > 0.05, rng.random(nr) > 0.05
+    hj, _keep = _hash_join(G, [(rk, rv)], nulls_equal)
+    left = cudf_amd.Table([G.to_device((lk, lv))])
+    ctx = getattr(hj, f"{kind}_join_match_context")(left)
+    counts = ctx._match_counts.to_numpy()[0]
+    bounds = [0, 1, 7, 20_000, 20_000, 49_999, nl]  # includes an empty and two single-row ranges
+    ls, rs, lparts, rparts = [], [], [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        li, ri = getattr(hj, f"partitioned_{kind}_join")(JoinPartitionContext(ctx, a, b))
+        lparts.append(li)
+        rparts.append(ri)
+        l, r = li.to_numpy()[0], ri.to_numpy()[0]
+        assert len(l) == int(counts[a:b].sum())
+        assert len(l) == 0 or (l.min() >= a and l.max() < b)
+        ls.append(l)
+        rs.append(r)
+    if kind == "full":
+        fl, fr = HashJoin.finalize_partitioned_full_join(lparts, rparts, nl, nr)
+        got_l, got_r = fl.to_numpy()[0], fr.to_numpy()[0]
+    else:
+        got_l, got_r = np.concatenate(ls), np.concatenate(rs)
+    el, er = oracle.join([(lk, lv)], [(rk, rv)], nulls_equal=nulls_equal, kind=kind)
+    assert kat.sorted_pairs(got_l, got_r) == kat.sorted_pairs(el, er)
+
+
+def test_partitioned_join_invalid_context(G):
+    import cudf_amd
+    from cudf_amd.join import JoinMatchContext, JoinPartitionContext
+    hj, _keep = _hash_join(G, [(np.array([1, 2, 3], np.int64), None)], True)
+    left = cudf_amd.Table([G.to_device(np.array([1, 2], np.int64))])
+    ctx = hj.inner_join_match_context(left)
+    for a, b in ((-1, 1), (1, 0), (0, 3)):  # out of bounds (reference hash_join.hpp:341-343)
+        with pytest.raises(ValueError):
+            hj.partitioned_inner_join(JoinPartitionContext(ctx, a, b))
+    with pytest.raises(ValueError):
+        hj.partitioned_inner_join(JoinPartitionContext(JoinMatchContext(left, None), 0, 1))
