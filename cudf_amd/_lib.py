@@ -45,6 +45,8 @@ SYMBOLS = {
     "cudf_amd_hash_join_probe": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.c_int32, C.c_int64, _P,
                                            C.POINTER(_P)]),
     "cudf_amd_hash_join_size": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.c_int32, _P, C.POINTER(C.c_uint64)]),
+    "cudf_amd_from_arrow": (C.c_int, [_P, _P, _P, C.POINTER(_P)]),
+    "cudf_amd_to_arrow_host": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.POINTER(C.c_char_p), _P, _P, _P]),
     "cudf_amd_hash_join_match_counts": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     "cudf_amd_hash_join_probe_range": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32,
                                                  _P, C.POINTER(_P)]),

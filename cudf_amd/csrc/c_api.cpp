@@ -8,6 +8,7 @@
 #include <cudf/copying.hpp>
 #include <cudf/groupby.hpp>
 #include <cudf/partitioning.hpp>
+#include <cudf/interop.hpp>
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
 #include <cudf/table/table.hpp>
@@ -352,6 +353,38 @@ cudf_amd_status cudf_amd_hash_join_finalize_full(const int32_t* const* left_part
     }
     cudf::stream_ref const s{as_stream(stream)};
     *out_indices = indices_to_table(cudf::hash_join::finalize_partitioned_full_join(lp, rp, left_num_rows, right_num_rows, s));
+  });
+}
+
+cudf_amd_status cudf_amd_from_arrow(const struct ArrowSchema* schema, const struct ArrowArray* array, void* stream,
+                                    cudf_amd_table_t* out_table)
+{
+  return guarded([&] {
+    *out_table = nullptr;
+    cudf::stream_ref const s{as_stream(stream)};
+    auto tbl = cudf::from_arrow(schema, array, s);
+    auto t   = std::make_unique<cudf_amd_table_s>();
+    t->cols  = tbl->release();
+    *out_table = t.release();
+  });
+}
+
+cudf_amd_status cudf_amd_to_arrow_host(const cudf_amd_column_view* columns, int32_t num_columns, const char* const* names,
+                                       void* stream, struct ArrowSchema* out_schema, struct ArrowArray* out_array)
+{
+  return guarded([&] {
+    CUDF_EXPECTS(out_schema != nullptr && out_array != nullptr, "output ArrowSchema / ArrowArray must not be NULL",
+                 std::invalid_argument);
+    auto const tv = to_table(columns, num_columns);
+    std::vector<cudf::column_metadata> meta;
+    for (int32_t i = 0; i < num_columns; ++i) meta.emplace_back(names != nullptr && names[i] != nullptr ? names[i] : "");
+    cudf::stream_ref const s{as_stream(stream)};
+    auto schema = cudf::to_arrow_schema(tv, meta);
+    auto arr    = cudf::to_arrow_host(tv, s);
+    *out_schema = *schema;          // move: the caller's copy now owns the contents
+    schema->release = nullptr;
+    *out_array  = arr->array;
+    arr->array.release = nullptr;
   });
 }
 

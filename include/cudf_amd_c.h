@@ -136,6 +136,18 @@ cudf_amd_status cudf_amd_hash_join_finalize_full(const int32_t* const* left_part
                                                  int32_t left_num_rows, int32_t right_num_rows, void* stream,
                                                  cudf_amd_table_t* out_indices);
 
+/* ---- Arrow C Data Interface (reference cpp/include/cudf/interop.hpp: from_arrow :685-689, to_arrow_host :618-621,
+ * to_arrow_schema :473-475). The structs are the ones the Arrow specification publishes.
+ * cudf_amd_from_arrow: host Arrow struct array (one child per column) -> owning device table; the input is not
+ * released. cudf_amd_to_arrow_host: device columns -> host Arrow data MOVED into the caller's *out_schema / *out_array
+ * (the caller, or whoever imports them, calls their release callbacks). */
+struct ArrowSchema;
+struct ArrowArray;
+cudf_amd_status cudf_amd_from_arrow(const struct ArrowSchema* schema, const struct ArrowArray* array, void* stream,
+                                    cudf_amd_table_t* out_table);
+cudf_amd_status cudf_amd_to_arrow_host(const cudf_amd_column_view* columns, int32_t num_columns, const char* const* names,
+                                       void* stream, struct ArrowSchema* out_schema, struct ArrowArray* out_array);
+
 /* ---- cudf::hash_partition(input, columns_to_hash, num_partitions, HASH_MURMUR3, seed, stream, mr)
  * (reference cpp/include/cudf/partitioning.hpp; src/partitioning/partitioning.cu:925-947). out_offsets receives
  * num_partitions start offsets (first is 0), as the reference's std::vector<size_type>. */
