@@ -206,13 +206,13 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
           continue;
         }
         if (acc_pay[q] != last_pay) {
-          if constexpr (INPUT == IN_COLUMNS) {
-            if constexpr (SIMPLE) value = gload(p.simple_base[KU + acc_pay[q]] + r);
-            else value = col_load_acc_bits(p.cols[p.nkeycols + acc_pay[q]], r);
-          } else if constexpr (PAYT > 0) {
+          if constexpr (PAYT > 0) {
 #pragma unroll
             for (int w = 0; w < PAYT; ++w)
               if (acc_pay[q] == w) value = pay[w];
+          } else if constexpr (INPUT == IN_COLUMNS) {
+            if constexpr (SIMPLE) value = gload(p.simple_base[KU + acc_pay[q]] + r);
+            else value = col_load_acc_bits(p.cols[p.nkeycols + acc_pay[q]], r);
           } else {
             value = gload(records + r * U + KU + acc_pay[q]);
           }
@@ -248,6 +248,12 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
   auto load_row = [&](int64_t r, uint64_t (&key)[KUT], uint64_t (&pay)[PAYT > 0 ? PAYT : 1], uint32_t& valvalid) -> bool {
     valvalid = 0xffffffffu;
     if constexpr (INPUT == IN_COLUMNS) {
+      // plain 8-byte columns: the payload is loaded WITH the key (a lazy load at accumulate time is a second exposed
+      // HBM round trip per batch)
+      if constexpr (SIMPLE && PAYT > 0) {
+#pragma unroll
+        for (int v = 0; v < PAYT; ++v) pay[v] = gload(p.simple_base[KU + v] + r);
+      }
       return build_key_units<KUT, SIMPLE>(p, r, key, valvalid);
     } else if constexpr (EXACT && KUT == 1 && PAYT == 1) {
       u64x2 const v = gload(reinterpret_cast<u64x2 const*>(records) + r);
@@ -298,7 +304,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     // main loop: R full rows per lane, all loads issued before the LDS work
     // (narrow records: the NEXT batch's loads are issued before the LDS work of this one - a wave walks its
     // batches one after the other and 4 waves per SIMD do not hide a full HBM round trip per batch)
-    constexpr bool PREFETCH = (KUT + PAYT <= 2) && INPUT != IN_COLUMNS;
+    constexpr bool PREFETCH = (KUT + PAYT <= 2) && (INPUT != IN_COLUMNS || (SIMPLE && PAYT > 0));
     int64_t const bstep     = multi ? 1 : nwaves;
     uint64_t nkey[R][KUT];
     uint64_t npay[R][PAYT > 0 ? PAYT : 1];
@@ -648,6 +654,14 @@ void launch_aggregate(agg_args const& a, agg_args* d_args, hipStream_t stream)
   if (a.input == IN_RAW_RECORDS) return launch_aggregate_records<IN_RAW_RECORDS>(a, d_args, stream);
   if (a.input == IN_PARTIAL_RECORDS) return launch_aggregate_records<IN_PARTIAL_RECORDS>(a, d_args, stream);
   bool const simple = a.plan.simple;
+  if (simple && KU == 1 && a.plan.NPAY == 1) {  // one plain key column, one plain value column
+    uint64_t const sig = plan_sig(a.plan);
+    if (sig == SIG_SUMF_CNT) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, true, true, SIG_SUMF_CNT>(a, d_args, stream);
+    if (sig == SIG_SUMI_CNT) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, true, true, SIG_SUMI_CNT>(a, d_args, stream);
+    if (sig == SIG_SUMF) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, true, true, SIG_SUMF>(a, d_args, stream);
+    if (sig == SIG_SUMI) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, true, true, SIG_SUMI>(a, d_args, stream);
+    return launch_aggregate_t<IN_COLUMNS, 1, 1, true, true>(a, d_args, stream);
+  }
   if (KU <= 1) simple ? launch_aggregate_t<IN_COLUMNS, 1, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 1, 0, false, false>(a, d_args, stream);
   else if (KU <= 2) simple ? launch_aggregate_t<IN_COLUMNS, 2, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 2, 0, false, false>(a, d_args, stream);
   else simple ? launch_aggregate_t<IN_COLUMNS, 4, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 4, 0, false, false>(a, d_args, stream);
