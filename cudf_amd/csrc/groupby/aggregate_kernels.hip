@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
   int64_t const B     = blockDim.x;
   constexpr int64_t W = R * 64;
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  bool const multi = a.seg == SEG_STRIDED;
+  // few long sources (the regions of a second partition level): every wave works on every source
+  bool const multi = a.seg == SEG_STRIDED && nsrc >= nwaves;
   for (int sidx = multi ? wave : 0; sidx < nsrc; sidx += multi ? nwaves : 1) {
     int64_t begin, end;
     if (a.seg == SEG_ROW_CHUNKS) {

@@ -308,6 +308,43 @@ __device__ __forceinline__ slice_range slice_of(part_args const& a, int item)
   return r;
 }
 
+// Virtual row range over a strided list of level-1 regions (part_args::from_regions). `pre` is a workgroup-shared
+// prefix array of MAX_REGION_LIST + 1 entries filled by build(); record_of(v) maps virtual row v to its record index.
+constexpr int MAX_REGION_LIST = 256;
+struct region_input {
+  int32_t* pre;
+  int nreg;
+  int64_t first;   // record index of region 0's base
+  int64_t stride;  // records between the bases of consecutive listed regions
+  __device__ __forceinline__ void build(part_args const& a, int item, int32_t* lds_pre)
+  {
+    int const g = item / a.geom.slices, s = item % a.geom.slices;
+    pre    = lds_pre;
+    nreg   = (a.in_slices - s + a.geom.slices - 1) / a.geom.slices;
+    first  = (static_cast<int64_t>(g) * a.in_slices + s) * a.in_region_cap;
+    stride = static_cast<int64_t>(a.geom.slices) * a.in_region_cap;
+    if (threadIdx.x == 0) {
+      int32_t run = 0;
+      for (int j = 0; j < nreg; ++j) {
+        pre[j] = run;
+        run += max(a.in_region_count[static_cast<int64_t>(g) * a.in_slices + s + static_cast<int64_t>(j) * a.geom.slices], 0);
+      }
+      pre[nreg] = run;
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ int64_t total() const { return pre[nreg]; }
+  __device__ __forceinline__ int64_t record_of(int64_t v) const
+  {
+    int lo = 0, hi = nreg;  // invariant: pre[lo] <= v < pre[hi]
+    while (hi - lo > 1) {
+      int const mid = (lo + hi) >> 1;
+      if (pre[mid] <= v) lo = mid; else hi = mid;
+    }
+    return first + static_cast<int64_t>(lo) * stride + (v - pre[lo]);
+  }
+};
+
 inline int next_ut(int u)
 {
   for (int c : {2, 3, 4, 6, 8, 12, 16})

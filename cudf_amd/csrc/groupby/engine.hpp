@@ -168,6 +168,14 @@ struct part_args {
   int64_t region_cap;
   int32_t* region_count;
   int32_t* overflow;
+  // Second optimistic level: the input of work item (g, s) is not a contiguous segment but the level-1 regions
+  // (g, w), w = s, s + slices, s + 2*slices, ... < in_slices, each [(g*in_slices + w) * in_region_cap, + count).
+  // The item sees them as one virtual row range (device_common.hpp region_input); its output regions are those of
+  // the GLOBAL partition g*P + d: [((g*P + d) * slices + s) * region_cap, +region_cap).
+  int32_t from_regions;
+  int32_t const* in_region_count;
+  int64_t in_region_cap;
+  int32_t in_slices;
   // Write-combining scatter (optimistic, 16-byte records): records per output granule (4 = 64 B, 8 = 128 B); every
   // global store of the tile loop is a whole, aligned granule; 0 = classic run-per-tile scatter.
   int32_t wc_granule;

@@ -502,7 +502,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     double const ds = h_set >= m ? m * 20 : -m * std::log(1.0 - h_set / m);  // distinct keys in the sample
     // population estimate under uniform frequencies: solve G (1 - exp(-S/G)) = ds
     double const S = static_cast<double>(sample);
-    if (ds >= 0.98 * S || sample == n) {
+    // (few duplicates in the sample still carry information: distinct ~ S - S^2 / 2G; only a sample without any
+    // duplicate leaves G unbounded)
+    if (ds >= S - 0.5 || sample == n) {
       est_groups = sample == n ? ds : static_cast<double>(n);
     } else {
       double lo = ds, hi = static_cast<double>(n);
@@ -617,7 +619,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       // the slice; its relative spread has a key-count part 1/sqrt(G/P) (which keys hash there) and a row-sampling
       // part 1/sqrt(mean). Six sigmas of slack; if that needs more than 2x the memory, use the exact pipeline.
       double const cell_mean   = static_cast<double>(n) / static_cast<double>(items1) / static_cast<double>(P1);
-      double const keys_per_p  = std::max(1.0, est_groups / static_cast<double>(P1));
+      // (half the estimated key count: an over-estimate would under-size the regions)
+      double const keys_per_p  = std::max(1.0, 0.5 * est_groups / static_cast<double>(P1));
       double const rel_sigma   = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, cell_mean));
       bool const optimistic = allow_optimistic && P2 == 1 && !forced_exact && n >= (int64_t{1} << 22) && 6.0 * rel_sigma <= 1.0;
       uint64_t* recA = nullptr;
@@ -674,6 +677,85 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         d_overflow = sc.alloc<int32_t>(1);
         --attempt;
         continue;
+      }
+      // two optimistic levels (more than 1024 partitions): level 1 as above into per-(slice, partition) regions; the
+      // level-2 items read their level-1 partition as a strided list of those regions and write per-(item, final
+      // partition) regions, which the aggregate walks. No histogram pass on either level.
+      if (allow_optimistic && P2 > 1 && !forced_exact && n >= (int64_t{1} << 22) && env_i64("CUDF_AMD_GB_OPTIMISTIC2", 1)) {
+        int64_t const S1      = 256;
+        int64_t const slices2 = std::max<int64_t>(1, 512 / P1);
+        double const mean1    = static_cast<double>(n) / static_cast<double>(S1 * P1);
+        double const sigma1   = std::sqrt(1.0 / std::max(1.0, 0.5 * est_groups / static_cast<double>(P1)) + 1.0 / std::max(1.0, mean1));
+        double const mean2    = static_cast<double>(n) / static_cast<double>(P1 * slices2 * P2);
+        double const sigma2   = std::sqrt(1.0 / std::max(1.0, 0.5 * est_groups / static_cast<double>(P1 * P2)) + 1.0 / std::max(1.0, mean2));
+        // (very many tiny tables: the per-table partial buffers dominate the memory; keep to one attempt there)
+        bool const partials_fit = static_cast<double>(P1 * P2) * ag.cap * PU * 8.0 <= 32.0 * 1024 * 1024 * 1024;
+        if (6.0 * sigma1 <= 1.0 && 6.0 * sigma2 <= 1.0 && S1 / slices2 <= 256 && partials_fit) {
+          int64_t const cap1 = (static_cast<int64_t>(mean1 * (1.0 + 6.0 * sigma1) + 16.0) + 7) / 8 * 8;
+          int64_t const cap2 = (static_cast<int64_t>(mean2 * (1.0 + 6.0 * sigma2) + 16.0) + 7) / 8 * 8;
+          bool const wc      = RU == 2 && p.KU == 1 && env_i64("CUDF_AMD_GB_WC", 1) != 0;
+          pa.geom.slices     = static_cast<int32_t>(S1);
+          pa.optimistic      = 1;
+          pa.region_cap      = cap1;
+          pa.region_count    = sc.alloc<int32_t>(static_cast<size_t>(S1 * P1));
+          pa.overflow        = d_overflow;
+          recA               = sc.alloc<uint64_t>(static_cast<size_t>(S1 * P1) * static_cast<size_t>(cap1) * RU);
+          pa.out_records     = recA;
+          if (wc) pa.wc_granule = P1 > 512 ? 4 : 8;
+          store_args(pa, d_pa, s);
+          launch_partition_scatter(pa, d_pa, s);
+          part_args pb{};
+          pb.plan            = p;
+          pb.geom.nseg       = static_cast<int32_t>(P1);
+          pb.geom.slices     = static_cast<int32_t>(slices2);
+          pb.geom.P          = static_cast<int32_t>(P2);
+          pb.geom.shift      = 64 - log2P1 - log2P2;
+          pb.geom.block      = 1024;
+          pb.geom.tile_rows  = pa.geom.tile_rows;
+          pb.from_columns    = 0;
+          pb.in_records      = recA;
+          pb.from_regions    = 1;
+          pb.in_region_count = pa.region_count;
+          pb.in_region_cap   = cap1;
+          pb.in_slices       = static_cast<int32_t>(S1);
+          pb.optimistic      = 1;
+          pb.region_cap      = cap2;
+          size_t const nreg2 = static_cast<size_t>(P1 * P2 * slices2);
+          pb.region_count    = sc.alloc<int32_t>(nreg2);
+          pb.overflow        = d_overflow;
+          uint64_t* recB     = sc.alloc<uint64_t>(nreg2 * static_cast<size_t>(cap2) * RU);
+          pb.out_records     = recB;
+          if (wc) pb.wc_granule = P2 > 512 ? 4 : 8;
+          part_args* d_pb = sc.alloc<part_args>(1);
+          store_args(pb, d_pb, s);
+          launch_partition_scatter(pb, d_pb, s);
+          nitems         = static_cast<int32_t>(P1 * P2);
+          partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);
+          d_count        = sc.alloc<int32_t>(nitems);
+          aa.input       = IN_RAW_RECORDS;
+          aa.seg         = SEG_STRIDED;
+          aa.records     = recB;
+          aa.src_count   = pb.region_count;
+          aa.src_stride  = cap2;
+          aa.fan         = static_cast<int32_t>(slices2);
+          aa.nsrc        = static_cast<int32_t>(nreg2);
+          aa.out_records = partial;
+          aa.out_count   = d_count;
+          aa.nitems      = nitems;
+          launch_aggregate(aa, sc.alloc<agg_args>(1), s);
+          int32_t h_ov = 0;
+          CUDF_HIP_TRY(hipMemcpyAsync(&h_ov, d_overflow, 4, hipMemcpyDeviceToHost, s));
+          CUDF_HIP_TRY(hipStreamSynchronize(s));
+          if (env_i64("CUDF_AMD_DEBUG", 0))
+            fprintf(stderr, "[cudf_amd] two-level optimistic P1=%ld P2=%ld slices2=%ld cap1=%ld cap2=%ld overflow=%d\n", (long)P1,
+                    (long)P2, (long)slices2, (long)cap1, (long)cap2, h_ov);
+          if (h_ov == 0) break;
+          allow_optimistic = false;  // a region or a table overflowed: redo with exact offsets
+          sc.bufs.clear();
+          d_overflow = sc.alloc<int32_t>(1);
+          --attempt;
+          continue;
+        }
       }
       pa.counts       = sc.alloc<uint32_t>(items1 * P1);
       pa.item_base    = sc.alloc<int64_t>(items1 * P1);

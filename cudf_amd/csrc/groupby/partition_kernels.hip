@@ -157,7 +157,18 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
   uint32_t* wave_sums = reinterpret_cast<uint32_t*>(pid + T + (T & 1));
 
   int const item       = blockIdx.x;
-  slice_range const sr = slice_of(a, item);
+  __shared__ int32_t s_pre[MAX_REGION_LIST + 1];
+  region_input rin{};
+  int const from_regions = a.from_regions;
+  slice_range sr;
+  if (from_regions) {
+    rin.build(a, item, s_pre);
+    sr.seg_begin = 0;
+    sr.begin     = 0;
+    sr.end       = rin.total();
+  } else {
+    sr = slice_of(a, item);
+  }
   int const from_cols  = a.from_columns;
   uint64_t const* in_records = a.in_records;
   uint64_t* out_records      = a.out_records;
@@ -179,7 +190,10 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
   for (int k = 0; k < MAXE; ++k) {
     int const d = threadIdx.x * MAXE + k;
     if (optimistic) {
-      cursor[k]     = (static_cast<int64_t>(d) * a.geom.slices + item) * a.region_cap;
+      // level 1: region (d, item); level 2 (from_regions): region (g*P + d, s) with item = (g, s)
+      int64_t const region = from_regions ? (static_cast<int64_t>(item / a.geom.slices) * P + d) * a.geom.slices + item % a.geom.slices
+                                          : static_cast<int64_t>(d) * a.geom.slices + item;
+      cursor[k]     = region * a.region_cap;
       region_end[k] = cursor[k] + a.region_cap;
     } else {
       cursor[k]     = d < P ? a.item_base[static_cast<int64_t>(item) * P + d] : 0;
@@ -241,12 +255,14 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
 #pragma unroll
           for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? SCATTER_LOAD(sbase[u] + r) : 0;
         } else if constexpr (EXACT && UT == 2) {
-          u64x2 const v = SCATTER_LOAD(reinterpret_cast<u64x2 const*>(in_records) + r);
+          int64_t const ri = from_regions ? rin.record_of(r) : r;
+          u64x2 const v = SCATTER_LOAD(reinterpret_cast<u64x2 const*>(in_records) + ri);
           rec[k][0]     = v.x;
           rec[k][1]     = v.y;
         } else {
+          int64_t const ri = from_regions ? rin.record_of(r) : r;
 #pragma unroll
-          for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? gload(in_records + r * U + u) : 0;
+          for (int u = 0; u < UT; ++u) rec[k][u] = (u < U) ? gload(in_records + ri * U + u) : 0;
         }
       }
     }
@@ -356,7 +372,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) {
       int const d = threadIdx.x * MAXE + k;
-      if (d < P) a.region_count[static_cast<int64_t>(d) * a.geom.slices + item] = static_cast<int32_t>(cursor[k] - (region_end[k] - a.region_cap));
+      if (d < P) a.region_count[(region_end[k] - a.region_cap) / a.region_cap] = static_cast<int32_t>(cursor[k] - (region_end[k] - a.region_cap));
     }
   }
 }
@@ -373,7 +389,18 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   plan_dev const& p  = a.plan;
   int const shift = a.geom.shift, B = blockDim.x;
   constexpr int UT = 2;
-  slice_range const sr = slice_of(a, blockIdx.x);
+  __shared__ int32_t s_pre[MAX_REGION_LIST + 1];
+  region_input rin{};
+  int const from_regions = a.from_regions;
+  slice_range sr;
+  if (from_regions) {
+    rin.build(a, blockIdx.x, s_pre);
+    sr.seg_begin = 0;
+    sr.begin     = 0;
+    sr.end       = rin.total();
+  } else {
+    sr = slice_of(a, blockIdx.x);
+  }
   int const from_cols  = a.from_columns;
   uint64_t const* in_records = a.in_records;
   uint64_t const kmask0 = p.key_mask[0];
@@ -404,7 +431,8 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
           rec[k][0] = gload(sbase[0] + r);
           rec[k][1] = gload(sbase[1] + r);
         } else {
-          u64x2 const v = gload(reinterpret_cast<u64x2 const*>(in_records) + r);
+          int64_t const ri = from_regions ? rin.record_of(r) : r;
+          u64x2 const v = gload(reinterpret_cast<u64x2 const*>(in_records) + ri);
           rec[k][0]     = v.x;
           rec[k][1]     = v.y;
         }
@@ -416,15 +444,18 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
     return static_cast<uint32_t>(h >> shift) & pmask;
   };
   cudf::detail::wc_scatter_geom g;
+  // level 2 (from_regions): item = (seg, s) writes the regions of the global partitions seg*P + d
+  int const seg           = from_regions ? blockIdx.x / a.geom.slices : 0;
+  int64_t const region0   = static_cast<int64_t>(seg) * a.geom.P * a.geom.slices;
   g.P            = a.geom.P;
   g.slices       = a.geom.slices;
-  g.item         = blockIdx.x;
+  g.item         = from_regions ? blockIdx.x % a.geom.slices : blockIdx.x;
   g.begin        = sr.begin;
   g.end          = sr.end;
   g.region_cap   = a.region_cap;
-  g.region_count = a.region_count;
+  g.region_count = a.region_count + region0;
   g.overflow     = a.overflow;
-  g.out          = reinterpret_cast<u64x2*>(a.out_records);
+  g.out          = reinterpret_cast<u64x2*>(a.out_records) + region0 * a.region_cap;
   cudf::detail::wc_scatter_slice<RPT, G>(lds_raw, g, load_tile, digit_of);
 }
 
