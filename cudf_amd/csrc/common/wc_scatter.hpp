@@ -1,6 +1,7 @@
 // SPDX-License-Identifier: Apache-2.0
-// Write-combining radix scatter of 16-byte records into per-(partition, workgroup) regions - shared by the groupby
-// partition pass and the join's probe-side partition pass.
+// Write-combining radix scatter of fixed-size records (U 8-byte units; 16-byte records have their own 128-bit path)
+// into per-(partition, workgroup) regions - shared by the groupby partition passes and the join's probe-side
+// partition pass.
 //
 // A run-per-tile scatter writes, per tile and partition, one run of ~T/P records at an arbitrary 16-byte offset:
 // almost every 128-byte line is written in two pieces and relies on the L2 to merge them (with the merge disabled -
@@ -23,10 +24,10 @@
 
 namespace cudf::detail {
 
-inline std::size_t wc_scatter_lds_bytes(std::size_t tile_rows, std::size_t P, int G)
+inline std::size_t wc_scatter_lds_bytes(std::size_t tile_rows, std::size_t P, int G, int U = 2)
 {
   std::size_t const gmap_len = (tile_rows + (G - 1) * P) / G + 1;
-  return tile_rows * 16 + P * (G - 1) * 16 + P * (8 + 8 + 4) + ((gmap_len + 3) & ~std::size_t{3}) * 2 + 32 * 8;
+  return tile_rows * U * 8 + P * (G - 1) * U * 8 + P * (8 + 8 + 4) + ((gmap_len + 3) & ~std::size_t{3}) * 2 + 32 * 8;
 }
 
 #if defined(__HIPCC__)
@@ -38,7 +39,7 @@ struct wc_scatter_geom {
   int64_t region_cap;     // records per region (multiple of 8)
   int32_t* region_count;  // [P * slices]
   int32_t* overflow;
-  u64x2* out;
+  uint64_t* out;          // records of U units
 };
 
 // LDS-only barrier (global loads/stores stay in flight across it)
@@ -46,22 +47,23 @@ __device__ __forceinline__ void wc_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 // load_tile(tile_base, rec, keep): fills rec[k] / keep[k] for row tile_base + k * blockDim.x + threadIdx.x (k < RPT),
 // issuing all loads back to back. digit_of(rec[k]) -> partition in [0, P).
-template <int RPT, int G, class LoadTile, class DigitOf>
+template <int RPT, int G, int U, class LoadTile, class DigitOf>
 __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scatter_geom const& g, LoadTile&& load_tile,
                                                  DigitOf&& digit_of)
 {
   int const P = g.P, B = blockDim.x, T = B * RPT;
-  constexpr int UT = 2, CW = G - 1;
-  u64x2* stage        = reinterpret_cast<u64x2*>(lds_raw);
-  u64x2* carry        = stage + T;
-  uint64_t* meta      = reinterpret_cast<uint64_t*>(carry + static_cast<size_t>(P) * CW);
+  constexpr int UT = U, CW = G - 1;
+  static_assert((G * U) % 2 == 0, "a granule is written in 16-byte chunks");
+  uint64_t* stage     = reinterpret_cast<uint64_t*>(lds_raw);           // [T][U]
+  uint64_t* carry     = stage + static_cast<size_t>(T) * U;             // [P][G-1][U]
+  uint64_t* meta      = carry + static_cast<size_t>(P) * CW * U;
   int64_t* delta      = reinterpret_cast<int64_t*>(meta + P);
   uint32_t* hist      = reinterpret_cast<uint32_t*>(delta + P);
   int const gmap_len  = (T + CW * P) / G + 1;
   uint16_t* gmap      = reinterpret_cast<uint16_t*>(hist + P);
   uint64_t* wave_sums = reinterpret_cast<uint64_t*>(gmap + ((gmap_len + 3) & ~3));
   int const item      = g.item;
-  u64x2* out          = g.out;
+  uint64_t* out       = g.out;
   // thread t owns partitions d = t + k*B: output cursor and carry count live in its registers
   constexpr int MAXE = 2;  // P <= 2 * B
   int64_t cursor[MAXE], region_end[MAXE];
@@ -150,23 +152,47 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
       if (keep[k]) {
         uint64_t const m   = meta[dig[k]];
         uint32_t const pos = static_cast<uint32_t>(m & 0xffffu) + rank[k] - static_cast<uint32_t>(m >> 32);
-        stage[pos]         = u64x2{rec[k][0], rec[k][1]};
+        if constexpr (U == 2) {
+          reinterpret_cast<u64x2*>(stage)[pos] = u64x2{rec[k][0], rec[k][1]};
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) stage[pos * U + u] = rec[k][u];
+        }
       }
     }
     // the registers are free: the next tile's loads fly under the write-out
     if (tile + T < g.end) load_tile(tile + T, rec, keep);
     wc_lds_barrier();
-    // write-out: G lanes per granule; sequence index q < carry count comes from the carry area, the rest from the stage
-    for (uint32_t g = threadIdx.x / G; g < total_gr; g += B / G) {
-      int const d        = gmap[g];
-      uint64_t const m   = meta[d];
-      uint32_t const s   = static_cast<uint32_t>(m & 0xffffu), L = static_cast<uint32_t>(m >> 16) & 0xffffu,
-                     c   = static_cast<uint32_t>(m >> 32);
-      uint32_t const q   = (g - L) * G + (threadIdx.x % G);
-      u64x2 v;
-      if (q < c) v = carry[static_cast<uint32_t>(d) * CW + q];
-      else v = stage[s + q - c];
-      gstore(out + delta[d] + q, v);
+    // write-out in 16-byte chunks; sequence index q < carry count comes from the carry area, the rest from the stage
+    if constexpr (U == 2) {  // one lane per record, G lanes per granule
+      for (uint32_t g = threadIdx.x / G; g < total_gr; g += B / G) {
+        int const d        = gmap[g];
+        uint64_t const m   = meta[d];
+        uint32_t const s   = static_cast<uint32_t>(m & 0xffffu), L = static_cast<uint32_t>(m >> 16) & 0xffffu,
+                       c   = static_cast<uint32_t>(m >> 32);
+        uint32_t const q   = (g - L) * G + (threadIdx.x % G);
+        u64x2 v;
+        if (q < c) v = reinterpret_cast<u64x2 const*>(carry)[static_cast<uint32_t>(d) * CW + q];
+        else v = reinterpret_cast<u64x2 const*>(stage)[s + q - c];
+        gstore(reinterpret_cast<u64x2*>(out) + delta[d] + q, v);
+      }
+    } else {  // G*U/2 lanes per granule, each moving two consecutive units of the granule's record sequence
+      constexpr uint32_t CG = G * U / 2;
+      for (uint32_t ch = threadIdx.x; ch < total_gr * CG; ch += B) {
+        uint32_t const gi  = ch / CG, ci = ch - gi * CG;
+        int const d        = gmap[gi];
+        uint64_t const m   = meta[d];
+        uint32_t const s   = static_cast<uint32_t>(m & 0xffffu), L = static_cast<uint32_t>(m >> 16) & 0xffffu,
+                       c   = static_cast<uint32_t>(m >> 32);
+        uint32_t const w0  = (gi - L) * (G * U) + 2 * ci;  // unit index in the partition's sequence of this tile
+        uint64_t val[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint32_t const w = w0 + j, q = w / U, u = w - q * U;
+          val[j] = q < c ? carry[(static_cast<uint32_t>(d) * CW + q) * U + u] : stage[(s + q - c) * U + u];
+        }
+        gstore(reinterpret_cast<u64x2*>(out + delta[d] * U + w0), u64x2{val[0], val[1]});
+      }
     }
     wc_lds_barrier();
     // remainder: sequence [max(written, old carry), total) moves from the stage to the front of the carry area
@@ -175,7 +201,10 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
       int const d = threadIdx.x + k * B;
       if (d < P) {
         uint32_t const c = ccnt[k];
-        for (uint32_t q = wr[k] > c ? wr[k] : c; q < tot[k]; ++q) carry[static_cast<uint32_t>(d) * CW + q - wr[k]] = stage[sofs[k] + q - c];
+        for (uint32_t q = wr[k] > c ? wr[k] : c; q < tot[k]; ++q) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) carry[(static_cast<uint32_t>(d) * CW + q - wr[k]) * U + u] = stage[(sofs[k] + q - c) * U + u];
+        }
         ccnt[k] = tot[k] - wr[k];
       }
     }
@@ -190,7 +219,10 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
       if (cursor[k] + ccnt[k] > region_end[k]) {
         *g.overflow = 1;
       } else {
-        for (uint32_t q = 0; q < ccnt[k]; ++q) gstore(out + cursor[k] + q, carry[static_cast<uint32_t>(d) * CW + q]);
+        for (uint32_t q = 0; q < ccnt[k]; ++q) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) gstore(out + (cursor[k] + q) * U + u, carry[(static_cast<uint32_t>(d) * CW + q) * U + u]);
+        }
         cursor[k] += ccnt[k];
       }
       g.region_count[static_cast<int64_t>(d) * g.slices + item] = static_cast<int32_t>(cursor[k] - (region_end[k] - g.region_cap));

@@ -206,5 +206,7 @@ void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int6
 
 std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g);
 std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g);
+// write-combining scatter: can records of U units be partitioned P ways with granules of G records?
+bool partition_wc_fits(int U, int P, int G);
 
 }  // namespace cudf::groupby::detail

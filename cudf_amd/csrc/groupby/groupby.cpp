@@ -599,6 +599,13 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       while ((int64_t{1} << log2P1) < P1) ++log2P1;
       while ((int64_t{1} << log2P2) < P2) ++log2P2;
 
+      // granule (records) of the write-combining scatter for a fan-out, 0 = run-per-tile kernel: 64-byte granules for
+      // 16-byte records at P = 1024 (a 128-byte carry area would not leave room for a tile), else 128-256 bytes
+      auto wc_granule_for = [&](int64_t P) -> int32_t {
+        if (!env_i64("CUDF_AMD_GB_WC", 1)) return 0;
+        int const G = RU == 2 ? static_cast<int>(env_i64("CUDF_AMD_GB_WC_G", P > 512 ? 4 : 8)) : (RU == 4 ? 4 : 8);
+        return partition_wc_fits(RU, static_cast<int>(P), G) ? G : 0;
+      };
       part_args pa{};
       pa.plan         = p;
       pa.geom.nseg    = 1;
@@ -634,7 +641,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         pa.out_records      = recA;
         // 16-byte records: write-combining scatter (whole aligned granules only); 64-byte granules at P = 1024
         // (the carry area of 128-byte granules would not leave room for a tile), 128-byte granules at P <= 512
-        if (RU == 2 && p.KU == 1 && env_i64("CUDF_AMD_GB_WC", 1)) pa.wc_granule = static_cast<int32_t>(env_i64("CUDF_AMD_GB_WC_G", P1 > 512 ? 4 : 8));
+        pa.wc_granule = wc_granule_for(P1);
         if (env_i64("CUDF_AMD_GB_STAMPS", 0)) pa.stamps = sc.alloc<unsigned long long>(items1 * 8);
         store_args(pa, d_pa, s);
         launch_partition_scatter(pa, d_pa, s);
@@ -693,7 +700,6 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         if (6.0 * sigma1 <= 1.0 && 6.0 * sigma2 <= 1.0 && S1 / slices2 <= 256 && partials_fit) {
           int64_t const cap1 = (static_cast<int64_t>(mean1 * (1.0 + 6.0 * sigma1) + 16.0) + 7) / 8 * 8;
           int64_t const cap2 = (static_cast<int64_t>(mean2 * (1.0 + 6.0 * sigma2) + 16.0) + 7) / 8 * 8;
-          bool const wc      = RU == 2 && p.KU == 1 && env_i64("CUDF_AMD_GB_WC", 1) != 0;
           pa.geom.slices     = static_cast<int32_t>(S1);
           pa.optimistic      = 1;
           pa.region_cap      = cap1;
@@ -701,7 +707,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           pa.overflow        = d_overflow;
           recA               = sc.alloc<uint64_t>(static_cast<size_t>(S1 * P1) * static_cast<size_t>(cap1) * RU);
           pa.out_records     = recA;
-          if (wc) pa.wc_granule = P1 > 512 ? 4 : 8;
+          pa.wc_granule      = wc_granule_for(P1);
           store_args(pa, d_pa, s);
           launch_partition_scatter(pa, d_pa, s);
           part_args pb{};
@@ -725,7 +731,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           pb.overflow        = d_overflow;
           uint64_t* recB     = sc.alloc<uint64_t>(nreg2 * static_cast<size_t>(cap2) * RU);
           pb.out_records     = recB;
-          if (wc) pb.wc_granule = P2 > 512 ? 4 : 8;
+          pb.wc_granule      = wc_granule_for(P2);
           part_args* d_pb = sc.alloc<part_args>(1);
           store_args(pb, d_pb, s);
           launch_partition_scatter(pb, d_pb, s);
@@ -747,8 +753,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           CUDF_HIP_TRY(hipMemcpyAsync(&h_ov, d_overflow, 4, hipMemcpyDeviceToHost, s));
           CUDF_HIP_TRY(hipStreamSynchronize(s));
           if (env_i64("CUDF_AMD_DEBUG", 0))
-            fprintf(stderr, "[cudf_amd] two-level optimistic P1=%ld P2=%ld slices2=%ld cap1=%ld cap2=%ld overflow=%d\n", (long)P1,
-                    (long)P2, (long)slices2, (long)cap1, (long)cap2, h_ov);
+            fprintf(stderr, "[cudf_amd] two-level optimistic P1=%ld P2=%ld slices2=%ld cap1=%ld cap2=%ld RU=%d wc=%d/%d overflow=%d\n",
+                    (long)P1, (long)P2, (long)slices2, (long)cap1, (long)cap2, RU, pa.wc_granule, pb.wc_granule, h_ov);
           if (h_ov == 0) break;
           allow_optimistic = false;  // a region or a table overflowed: redo with exact offsets
           sc.bufs.clear();

@@ -379,16 +379,15 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
 
 
 // ------------------------------------------------------------------ K_scatter, write-combining form
-// Optimistic regions, 16-byte records (one key unit + one payload unit): common/wc_scatter.hpp does the work; this
-// kernel supplies the row loader (plain columns, generic columns, or records) and the partition digit.
-template <int RPT, int G, bool SIMPLE>
+// Optimistic regions, records of exactly UT units: common/wc_scatter.hpp does the work; this kernel supplies the row
+// loader (plain columns, generic columns, records, or a strided list of level-1 regions) and the partition digit.
+template <int UT, int RPT, int G, bool SIMPLE>
 __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   part_args const& a = *ap;
   plan_dev const& p  = a.plan;
   int const shift = a.geom.shift, B = blockDim.x;
-  constexpr int UT = 2;
   __shared__ int32_t s_pre[MAX_REGION_LIST + 1];
   region_input rin{};
   int const from_regions = a.from_regions;
@@ -403,12 +402,16 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   }
   int const from_cols  = a.from_columns;
   uint64_t const* in_records = a.in_records;
-  uint64_t const kmask0 = p.key_mask[0];
+  constexpr int KUM = UT < MAX_KU ? UT : MAX_KU;
+  int const KU = p.KU;
+  uint64_t kmask[KUM];
+#pragma unroll
+  for (int u = 0; u < KUM; ++u) kmask[u] = u < KU ? p.key_mask[u] : 0;
   uint32_t const pmask  = static_cast<uint32_t>(a.geom.P - 1);
   uint64_t const* sbase[UT];
   if constexpr (SIMPLE) {
-    sbase[0] = p.simple_base[0];
-    sbase[1] = p.simple_base[1];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) sbase[u] = p.simple_base[u];
   }
   auto load_tile = [&](int64_t tile, uint64_t (&rec)[RPT][UT], bool (&keep)[RPT]) {
     if (!SIMPLE && from_cols) {
@@ -428,19 +431,27 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
       keep[k]         = r < sr.end;
       if (keep[k]) {
         if constexpr (SIMPLE) {
-          rec[k][0] = gload(sbase[0] + r);
-          rec[k][1] = gload(sbase[1] + r);
+#pragma unroll
+          for (int u = 0; u < UT; ++u) rec[k][u] = gload(sbase[u] + r);
         } else {
           int64_t const ri = from_regions ? rin.record_of(r) : r;
-          u64x2 const v = gload(reinterpret_cast<u64x2 const*>(in_records) + ri);
-          rec[k][0]     = v.x;
-          rec[k][1]     = v.y;
+          if constexpr (UT == 2) {
+            u64x2 const v = gload(reinterpret_cast<u64x2 const*>(in_records) + ri);
+            rec[k][0]     = v.x;
+            rec[k][1]     = v.y;
+          } else {
+#pragma unroll
+            for (int u = 0; u < UT; ++u) rec[k][u] = gload(in_records + ri * UT + u);
+          }
         }
       }
     }
   };
   auto digit_of = [&](uint64_t const (&rec)[UT]) {
-    uint64_t const h = mix64(0x9e3779b97f4a7c15ull ^ (rec[0] & kmask0));
+    uint64_t h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int u = 0; u < KUM; ++u)
+      if (u < KU) h = mix64(h ^ (rec[u] & kmask[u]));
     return static_cast<uint32_t>(h >> shift) & pmask;
   };
   cudf::detail::wc_scatter_geom g;
@@ -455,8 +466,8 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   g.region_cap   = a.region_cap;
   g.region_count = a.region_count + region0;
   g.overflow     = a.overflow;
-  g.out          = reinterpret_cast<u64x2*>(a.out_records) + region0 * a.region_cap;
-  cudf::detail::wc_scatter_slice<RPT, G>(lds_raw, g, load_tile, digit_of);
+  g.out          = a.out_records + region0 * a.region_cap * UT;
+  cudf::detail::wc_scatter_slice<RPT, G, UT>(lds_raw, g, load_tile, digit_of);
 }
 
 }  // namespace
@@ -512,22 +523,30 @@ static void launch_scatter_t(part_args const& a, part_args const* d_args, hipStr
 }
 
 
-std::size_t partition_wc_lds_bytes(part_geom const& g, int G) { return cudf::detail::wc_scatter_lds_bytes(g.tile_rows, g.P, G); }
+// Tile rows per thread and granule of the write-combining kernel for a record width; 0 = no instantiation.
+int wc_rpt(int U) { return U == 2 ? 5 : U == 3 ? 4 : U == 4 ? 3 : 0; }
+bool partition_wc_fits(int U, int P, int G)
+{
+  int const rpt = wc_rpt(U);
+  if (rpt == 0 || (G != 4 && G != 8) || (U != 2 && G != (U == 4 ? 4 : 8))) return false;
+  // static LDS of the kernel (region prefix list, abort flag) is ~1.1 KB
+  return cudf::detail::wc_scatter_lds_bytes(static_cast<std::size_t>(1024) * rpt, P, G, U) + 1200 <= 160 * 1024;
+}
 
-template <int RPT, int G, bool SIMPLE>
+template <int UT, int RPT, int G, bool SIMPLE>
 static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hipStream_t stream)
 {
   part_geom g  = a.geom;
   g.tile_rows  = g.block * RPT;
-  auto const lds = partition_wc_lds_bytes(g, G);
-  CUDF_EXPECTS(lds <= 160 * 1024, "write-combining partition kernel: LDS budget exceeded");
+  auto const lds = cudf::detail::wc_scatter_lds_bytes(g.tile_rows, g.P, G, UT);
+  CUDF_EXPECTS(lds + 1200 <= 160 * 1024, "write-combining partition kernel: LDS budget exceeded");
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<RPT, G, SIMPLE>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SIMPLE>));
     attr_set = true;
   }
   cudf::detail::prof::scope prof_{"partition_scatter", stream};
-  hipLaunchKernelGGL((k_partition_scatter_wc<RPT, G, SIMPLE>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args);
+  hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SIMPLE>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
@@ -537,11 +556,16 @@ void launch_partition_scatter(part_args const& a, part_args const* d_args, hipSt
   int const U       = a.plan.KU + a.plan.NPAY;
   bool const simple = a.plan.simple && a.from_columns;
   if (a.wc_granule != 0) {
-    CUDF_EXPECTS(a.optimistic && U == 2 && a.plan.KU == 1 && a.geom.block == 1024, "write-combining scatter: 16-byte records, optimistic regions");
-    if (a.wc_granule == 4)
-      simple ? launch_scatter_wc_t<5, 4, true>(a, d_args, stream) : launch_scatter_wc_t<5, 4, false>(a, d_args, stream);
+    CUDF_EXPECTS(a.optimistic && a.geom.block == 1024 && partition_wc_fits(U, a.geom.P, a.wc_granule),
+                 "write-combining scatter: optimistic regions, records of 2-4 units, carry area within the LDS");
+    if (U == 2 && a.wc_granule == 4)
+      simple ? launch_scatter_wc_t<2, 5, 4, true>(a, d_args, stream) : launch_scatter_wc_t<2, 5, 4, false>(a, d_args, stream);
+    else if (U == 2)
+      simple ? launch_scatter_wc_t<2, 5, 8, true>(a, d_args, stream) : launch_scatter_wc_t<2, 5, 8, false>(a, d_args, stream);
+    else if (U == 3)
+      simple ? launch_scatter_wc_t<3, 4, 8, true>(a, d_args, stream) : launch_scatter_wc_t<3, 4, 8, false>(a, d_args, stream);
     else
-      simple ? launch_scatter_wc_t<5, 8, true>(a, d_args, stream) : launch_scatter_wc_t<5, 8, false>(a, d_args, stream);
+      simple ? launch_scatter_wc_t<4, 3, 4, true>(a, d_args, stream) : launch_scatter_wc_t<4, 3, 4, false>(a, d_args, stream);
     return;
   }
   switch (next_ut(U)) {

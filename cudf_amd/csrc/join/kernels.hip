@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(1024) k_probe_partition(join_args const* __res
   g.region_cap   = a.region_cap;
   g.region_count = a.region_count;
   g.overflow     = a.overflow;
-  g.out          = reinterpret_cast<u64x2*>(a.precs);
+  g.out          = a.precs;
   int64_t const end = g.end;
   auto load_tile = [&](int64_t tile, uint64_t (&rec)[RPT][2], bool (&keep)[RPT]) {
 #pragma unroll
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(1024) k_probe_partition(join_args const* __res
     }
   };
   auto digit_of = [&](uint64_t const (&rec)[2]) { return static_cast<uint32_t>(hash64_single(rec[0]) >> shift); };
-  wc_scatter_slice<RPT, G>(lds_raw, g, load_tile, digit_of);
+  wc_scatter_slice<RPT, G, 2>(lds_raw, g, load_tile, digit_of);
 }
 
 // ------------------------------------------------------------------ probe: count pass
