@@ -83,8 +83,12 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
   uint64_t rec[RPT][UT];
   bool keep[RPT];
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
-  if (g.begin < g.end) load_tile(g.begin, rec, keep);
-  for (int64_t tile = g.begin; tile < g.end; tile += T) {
+  // The loop runs one extra leading round that only loads: the (possibly large) row loader is instantiated at ONE call
+  // site (the generic column reader inlined twice made the kernel 17,000 instructions long).
+  for (int64_t tile = g.begin - T; tile < g.end; tile += T) {
+    bool const cur = tile >= g.begin;  // a tile sits in the registers
+    uint32_t tot[MAXE], wr[MAXE], sofs[MAXE], total_gr = 0;
+    if (cur) {
     uint32_t dig[RPT], rank[RPT];
     // rank within the partition's sequence: the histogram starts at the carry count
 #pragma unroll
@@ -96,7 +100,6 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
     }
     wc_lds_barrier();
     // owners: new-record count and granule count per partition; one packed scan gives stage and granule offsets
-    uint32_t tot[MAXE], wr[MAXE];
     uint64_t local = 0;
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) {
@@ -124,8 +127,7 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
     }
     wc_lds_barrier();
     uint64_t run             = (wave == 0 ? 0 : wave_sums[16 + wave - 1]) + inc - local;
-    uint32_t const total_gr  = static_cast<uint32_t>(wave_sums[16 + nwaves - 1] >> 32);
-    uint32_t sofs[MAXE];
+    total_gr                 = static_cast<uint32_t>(wave_sums[16 + nwaves - 1] >> 32);
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) {
       int const d = threadIdx.x + k * B;
@@ -160,8 +162,10 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
         }
       }
     }
+    }
     // the registers are free: the next tile's loads fly under the write-out
     if (tile + T < g.end) load_tile(tile + T, rec, keep);
+    if (!cur) continue;
     wc_lds_barrier();
     // write-out in 16-byte chunks; sequence index q < carry count comes from the carry area, the rest from the stage
     if constexpr (U == 2) {  // one lane per record, G lanes per granule

@@ -612,6 +612,11 @@ constexpr uint64_t SIG_MEAN_MIN_MAX_F_NULLS =
   make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0), sig_acc(MIN_F64, SRC_VALUE, 0, 0),
            sig_acc(MAX_F64, SRC_VALUE, 0, 0));
 
+// the same without nulls: SUM, COUNT_ALL (as the count of MEAN), MIN, MAX
+constexpr uint64_t SIG_MEAN_MIN_MAX_F =
+  make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1), sig_acc(MIN_F64, SRC_VALUE, 0, -1),
+           sig_acc(MAX_F64, SRC_VALUE, 0, -1));
+
 template <int INPUT, int KUT, int PAYT, bool SIMPLE, bool EXACT>
 static void launch_aggregate_t(agg_args const& a, agg_args* d_args, hipStream_t stream)
 {
@@ -637,6 +642,10 @@ static void launch_aggregate_records(agg_args const& a, agg_args* d_args, hipStr
     }
     if (KU == 2 && npay == 1 && sig == SIG_MEAN_MIN_MAX_F_NULLS)
       return launch_aggregate_n<INPUT, 2, 1, 4, false, true, SIG_MEAN_MIN_MAX_F_NULLS>(a, d_args, stream);
+    if (KU == 2 && npay == 1 && a.plan.flags_unit < 0 && sig == SIG_MEAN_MIN_MAX_F)
+      return launch_aggregate_n<INPUT, 2, 1, 4, false, true, SIG_MEAN_MIN_MAX_F>(a, d_args, stream);
+    if (KU == 1 && npay == 1 && a.plan.flags_unit < 0 && sig == SIG_MEAN_MIN_MAX_F)
+      return launch_aggregate_n<INPUT, 1, 1, 4, false, true, SIG_MEAN_MIN_MAX_F>(a, d_args, stream);
   }
   // exact shapes get the payload prefetched with the key; everything else fetches it lazily
   if (KU == 1 && npay == 1) return launch_aggregate_t<INPUT, 1, 1, false, true>(a, d_args, stream);

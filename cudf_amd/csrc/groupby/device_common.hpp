@@ -230,6 +230,11 @@ template <int NR, int UT>
 __device__ __forceinline__ void batch_units(plan_dev const& p, int nunits, int64_t const (&row)[NR], bool (&live)[NR],
                                             uint64_t (&rec)[NR][UT], uint32_t (&valvalid)[NR])
 {
+  // the data loads are predicated on the row being in range only - not on its validity bits - so that they do not wait
+  // for the mask loads (a second exposed HBM round trip per tile); dropped rows are simply never used
+  bool inrange[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) inrange[k] = live[k];
   uint32_t keynulls[NR];
   batch_validity<NR>(p, row, live, keynulls, valvalid);
 #pragma unroll
@@ -241,7 +246,7 @@ __device__ __forceinline__ void batch_units(plan_dev const& p, int nunits, int64
     if (full) {
       device_column const col = p.cols[lo];
       uint64_t raw[NR];
-      batch_load_bits<NR>(col, row, live, raw);
+      batch_load_bits<NR>(col, row, inrange, raw);
       if (is_key) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) rec[k][u] = ((keynulls[k] >> lo) & 1u) ? 0 : normalize_key_bits(raw[k], col.cls);
@@ -251,8 +256,8 @@ __device__ __forceinline__ void batch_units(plan_dev const& p, int nunits, int64
       }
     } else {
       uint32_t l[NR], h[NR];
-      batch_half<NR>(p, lo, row, live, keynulls, valvalid, l);
-      batch_half<NR>(p, hi, row, live, keynulls, valvalid, h);
+      batch_half<NR>(p, lo, row, inrange, keynulls, valvalid, l);
+      batch_half<NR>(p, hi, row, inrange, keynulls, valvalid, h);
 #pragma unroll
       for (int k = 0; k < NR; ++k) rec[k][u] = static_cast<uint64_t>(l[k]) | (static_cast<uint64_t>(h[k]) << 32);
     }

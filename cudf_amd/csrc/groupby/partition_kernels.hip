@@ -381,7 +381,12 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
 // ------------------------------------------------------------------ K_scatter, write-combining form
 // Optimistic regions, records of exactly UT units: common/wc_scatter.hpp does the work; this kernel supplies the row
 // loader (plain columns, generic columns, records, or a strided list of level-1 regions) and the partition digit.
-template <int UT, int RPT, int G, bool SIMPLE>
+// SRC: where the rows come from - one instantiation each, the generic column reader and the region reader together
+// did not fit 128 VGPRs (39-54 spilled registers).
+constexpr int WC_SRC_SIMPLE = 0;   // plain 8-byte columns
+constexpr int WC_SRC_COLUMNS = 1;  // any fixed-width columns, nulls (records built column-at-a-time)
+constexpr int WC_SRC_RECORDS = 2;  // records: one contiguous range, or a strided list of level-1 regions
+template <int UT, int RPT, int G, int SRC>
 __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -389,8 +394,9 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   plan_dev const& p  = a.plan;
   int const shift = a.geom.shift, B = blockDim.x;
   __shared__ int32_t s_pre[MAX_REGION_LIST + 1];
+  constexpr bool SIMPLE = SRC == WC_SRC_SIMPLE;
   region_input rin{};
-  int const from_regions = a.from_regions;
+  int const from_regions = SRC == WC_SRC_RECORDS ? a.from_regions : 0;
   slice_range sr;
   if (from_regions) {
     rin.build(a, blockIdx.x, s_pre);
@@ -400,7 +406,6 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   } else {
     sr = slice_of(a, blockIdx.x);
   }
-  int const from_cols  = a.from_columns;
   uint64_t const* in_records = a.in_records;
   constexpr int KUM = UT < MAX_KU ? UT : MAX_KU;
   int const KU = p.KU;
@@ -414,7 +419,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
     for (int u = 0; u < UT; ++u) sbase[u] = p.simple_base[u];
   }
   auto load_tile = [&](int64_t tile, uint64_t (&rec)[RPT][UT], bool (&keep)[RPT]) {
-    if (!SIMPLE && from_cols) {
+    if constexpr (SRC == WC_SRC_COLUMNS) {
       int64_t row[RPT];
       uint32_t vv[RPT];
 #pragma unroll
@@ -423,8 +428,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
         keep[k] = row[k] < sr.end;
       }
       batch_units<RPT, UT>(p, UT, row, keep, rec, vv);
-      return;
-    }
+    } else {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       int64_t const r = tile + static_cast<int64_t>(k) * B + threadIdx.x;
@@ -445,6 +449,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
           }
         }
       }
+    }
     }
   };
   auto digit_of = [&](uint64_t const (&rec)[UT]) {
@@ -533,8 +538,8 @@ bool partition_wc_fits(int U, int P, int G)
   return cudf::detail::wc_scatter_lds_bytes(static_cast<std::size_t>(1024) * rpt, P, G, U) + 1200 <= 160 * 1024;
 }
 
-template <int UT, int RPT, int G, bool SIMPLE>
-static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hipStream_t stream)
+template <int UT, int RPT, int G, int SRC>
+static void launch_scatter_wc_src(part_args const& a, part_args const* d_args, hipStream_t stream)
 {
   part_geom g  = a.geom;
   g.tile_rows  = g.block * RPT;
@@ -542,12 +547,20 @@ static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hip
   CUDF_EXPECTS(lds + 1200 <= 160 * 1024, "write-combining partition kernel: LDS budget exceeded");
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SIMPLE>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SRC>));
     attr_set = true;
   }
   cudf::detail::prof::scope prof_{"partition_scatter", stream};
-  hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SIMPLE>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args);
+  hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SRC>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
+}
+
+template <int UT, int RPT, int G>
+static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hipStream_t stream)
+{
+  if (!a.from_columns) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_RECORDS>(a, d_args, stream);
+  if (a.plan.simple) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE>(a, d_args, stream);
+  return launch_scatter_wc_src<UT, RPT, G, WC_SRC_COLUMNS>(a, d_args, stream);
 }
 
 void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream)
@@ -558,14 +571,10 @@ void launch_partition_scatter(part_args const& a, part_args const* d_args, hipSt
   if (a.wc_granule != 0) {
     CUDF_EXPECTS(a.optimistic && a.geom.block == 1024 && partition_wc_fits(U, a.geom.P, a.wc_granule),
                  "write-combining scatter: optimistic regions, records of 2-4 units, carry area within the LDS");
-    if (U == 2 && a.wc_granule == 4)
-      simple ? launch_scatter_wc_t<2, 5, 4, true>(a, d_args, stream) : launch_scatter_wc_t<2, 5, 4, false>(a, d_args, stream);
-    else if (U == 2)
-      simple ? launch_scatter_wc_t<2, 5, 8, true>(a, d_args, stream) : launch_scatter_wc_t<2, 5, 8, false>(a, d_args, stream);
-    else if (U == 3)
-      simple ? launch_scatter_wc_t<3, 4, 8, true>(a, d_args, stream) : launch_scatter_wc_t<3, 4, 8, false>(a, d_args, stream);
-    else
-      simple ? launch_scatter_wc_t<4, 3, 4, true>(a, d_args, stream) : launch_scatter_wc_t<4, 3, 4, false>(a, d_args, stream);
+    if (U == 2 && a.wc_granule == 4) launch_scatter_wc_t<2, 5, 4>(a, d_args, stream);
+    else if (U == 2) launch_scatter_wc_t<2, 5, 8>(a, d_args, stream);
+    else if (U == 3) launch_scatter_wc_t<3, 4, 8>(a, d_args, stream);
+    else launch_scatter_wc_t<4, 3, 4>(a, d_args, stream);
     return;
   }
   switch (next_ut(U)) {

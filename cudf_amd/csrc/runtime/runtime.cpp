@@ -300,7 +300,9 @@ struct pool_memory_resource::impl {
     std::size_t size;
     hipEvent_t freed;      // recorded on `stream` when the block was returned
     hipStream_t stream;
+    uint64_t tick;         // when it was returned (eviction order)
   };
+  uint64_t clock{0};
   std::mutex mu;
   std::map<std::size_t, std::vector<block>> free_lists;  // rounded size -> blocks
   std::unordered_map<void*, block> live;
@@ -365,7 +367,7 @@ void* pool_memory_resource::do_allocate(std::size_t bytes, hipStream_t stream)
     if (e == hipErrorOutOfMemory) throw std::bad_alloc{};
     cudf::detail::throw_hip_error(e, __FILE__, __LINE__);
   }
-  impl::block b{p, sz, nullptr, stream};
+  impl::block b{p, sz, nullptr, stream, 0};
   e = hipEventCreateWithFlags(&b.freed, hipEventDisableTiming);
   if (e != hipSuccess) cudf::detail::throw_hip_error(e, __FILE__, __LINE__);
   std::lock_guard<std::mutex> g{_impl->mu};
@@ -381,25 +383,35 @@ void pool_memory_resource::do_deallocate(void* p, std::size_t, hipStream_t strea
   b.stream = stream;
   _impl->live.erase(it);
   (void)hipEventRecord(b.freed, stream);
+  b.tick = ++_impl->clock;
   _impl->free_lists[b.size].push_back(b);
   _impl->cached += b.size;
   // Bound what the cache may hold (every distinct rounded size keeps its own list): beyond the limit
-  // (CUDF_AMD_POOL_MAX_CACHED_GB, default 128 of the 288 GB) everything cached goes back to the driver.
+  // (CUDF_AMD_POOL_MAX_CACHED_GB, default 128 of the 288 GB) the least recently returned blocks go back to the
+  // driver first, so a caller that changes its shapes does not lose the blocks of its current working set.
   static std::size_t const limit = [] {
     char const* e = std::getenv("CUDF_AMD_POOL_MAX_CACHED_GB");
     std::size_t const gb = (e != nullptr && *e != 0) ? std::strtoull(e, nullptr, 10) : 128;
     return gb << 30;
   }();
-  if (_impl->cached > limit) {
-    for (auto& [sz, v] : _impl->free_lists) {
-      for (auto& blk : v) {
-        (void)hipEventSynchronize(blk.freed);
-        (void)hipEventDestroy(blk.freed);
-        (void)hipFree(blk.ptr);
-      }
-    }
-    _impl->free_lists.clear();
-    _impl->cached = 0;
+  while (_impl->cached > limit) {
+    std::vector<impl::block>* oldest_list = nullptr;
+    std::size_t oldest_idx = 0;
+    uint64_t oldest_tick   = ~uint64_t{0};
+    for (auto& [sz, v] : _impl->free_lists)
+      for (std::size_t i = 0; i < v.size(); ++i)
+        if (v[i].tick < oldest_tick) {
+          oldest_tick = v[i].tick;
+          oldest_list = &v;
+          oldest_idx  = i;
+        }
+    if (oldest_list == nullptr) break;
+    auto const blk = (*oldest_list)[oldest_idx];
+    oldest_list->erase(oldest_list->begin() + static_cast<std::ptrdiff_t>(oldest_idx));
+    (void)hipEventSynchronize(blk.freed);
+    (void)hipEventDestroy(blk.freed);
+    (void)hipFree(blk.ptr);
+    _impl->cached -= blk.size;
   }
 }
 
