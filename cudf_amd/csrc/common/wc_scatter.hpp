@@ -47,7 +47,9 @@ __device__ __forceinline__ void wc_lds_barrier() { asm volatile("s_waitcnt lgkmc
 
 // load_tile(tile_base, rec, keep): fills rec[k] / keep[k] for row tile_base + k * blockDim.x + threadIdx.x (k < RPT),
 // issuing all loads back to back. digit_of(rec[k]) -> partition in [0, P).
-template <int RPT, int G, int U, class LoadTile, class DigitOf>
+// PEEL: the first tile's loads are issued ahead of the loop (two call sites of the loader: fine for a small one);
+// otherwise the loop runs one extra leading round that only loads, so that a large loader is instantiated once.
+template <int RPT, int G, int U, bool PEEL, class LoadTile, class DigitOf>
 __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scatter_geom const& g, LoadTile&& load_tile,
                                                  DigitOf&& digit_of)
 {
@@ -83,10 +85,12 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
   uint64_t rec[RPT][UT];
   bool keep[RPT];
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
-  // The loop runs one extra leading round that only loads: the (possibly large) row loader is instantiated at ONE call
-  // site (the generic column reader inlined twice made the kernel 17,000 instructions long).
-  for (int64_t tile = g.begin - T; tile < g.end; tile += T) {
-    bool const cur = tile >= g.begin;  // a tile sits in the registers
+  // (the generic column reader inlined twice made the kernel 17,000 instructions long)
+  if constexpr (PEEL) {
+    if (g.begin < g.end) load_tile(g.begin, rec, keep);
+  }
+  for (int64_t tile = PEEL ? g.begin : g.begin - T; tile < g.end; tile += T) {
+    bool const cur = PEEL || tile >= g.begin;  // a tile sits in the registers
     uint32_t tot[MAXE], wr[MAXE], sofs[MAXE], total_gr = 0;
     if (cur) {
     uint32_t dig[RPT], rank[RPT];

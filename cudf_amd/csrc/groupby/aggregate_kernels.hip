@@ -110,6 +110,28 @@ __device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask
   return -1;
 }
 
+// Slot of a key that is known to be in the table (second sweep of ARGMIN / ARGMAX); -1 if the table was saturated.
+template <int KUT>
+__device__ __forceinline__ int lds_lookup(int KU, uint64_t const (&kmask)[KUT], uint32_t const* st, uint64_t const* keys, int cap,
+                                          uint64_t const (&key)[KUT], uint64_t h)
+{
+  uint32_t const tag = tag_of(h);
+  int slot           = 4 * home_bucket(h, cap);
+  for (int probes = 0; probes < cap; ++probes) {
+    uint32_t const s = st[slot];
+    if (s == ST_EMPTY) return -1;
+    if (s == tag) {
+      bool eq = true;
+#pragma unroll
+      for (int u = 0; u < KUT; ++u)
+        if (u < KU) eq = eq && (keys[static_cast<uint32_t>(u * cap + slot)] == (key[u] & kmask[u]));
+      if (eq) return slot;
+    }
+    slot = slot + 1 == cap ? 0 : slot + 1;
+  }
+  return -1;
+}
+
 // INPUT: agg_input. KUT: key units held in registers. PAYT: payload units of a RECORD prefetched into
 // registers together with the key (0 = payload fetched lazily per accumulator: column input, wide records).
 // NACCT: compile-time bound of the accumulator loop (descriptors sit in registers, statically indexed).
@@ -189,6 +211,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     for (int q = 0; q < NACCT; ++q) {
       if (q >= NACC) break;
       uint64_t* tgt = accs + (static_cast<uint32_t>(q) * static_cast<uint32_t>(cap) + static_cast<uint32_t>(slot));
+      if (acc_src[q] >= SRC_ARG_IDX) continue;  // filled by the second sweep
       if constexpr (INPUT == IN_PARTIAL_RECORDS) {
         uint64_t v;
         if constexpr (PAYT > 0) v = q < PAYT ? pay[q < PAYT ? q : 0] : 0;
@@ -429,6 +452,58 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     }
   }
   __syncthreads();
+  // ---- ARGMIN / ARGMAX: every group's extreme value is final; a second sweep over the same rows takes the smallest
+  // row index among the rows that attain it
+  if (p.narg > 0 && s_overflow == 0) {
+    for (int sidx = 0; sidx < nsrc; ++sidx) {
+      int64_t begin, end;
+      if (a.seg == SEG_ROW_CHUNKS) {
+        begin = static_cast<int64_t>(item) * a.chunk;
+        end   = min(a.nrows, begin + a.chunk);
+      } else if (a.seg == SEG_OFFSETS) {
+        begin = a.offsets[item];
+        end   = a.offsets[item + 1];
+      } else {
+        begin = static_cast<int64_t>(src0 + sidx) * a.src_stride;
+        end   = begin + min<int64_t>(max(a.src_count[src0 + sidx], 0), a.src_stride);
+      }
+      for (int64_t r = begin + threadIdx.x; r < end; r += blockDim.x) {
+        uint64_t key[KUT];
+        uint64_t pay[PAYT > 0 ? PAYT : 1];
+        uint32_t valvalid;
+        if (!load_row(r, key, pay, valvalid)) continue;
+        int const slot = lds_lookup<KUT>(KU, kmask, st, keys, cap, key, hash_of(key));
+        if (slot < 0) continue;
+        for (int i = 0; i < p.narg; ++i) {
+          int const qv = p.arg[i].valacc, qi = p.arg[i].idxacc;
+          uint64_t v, rowid;
+          if constexpr (INPUT == IN_PARTIAL_RECORDS) {
+            v     = gload(records + r * U + KU + qv);
+            rowid = gload(records + r * U + KU + qi);
+            if (rowid == static_cast<uint64_t>(INT64_MAX)) continue;  // that partial saw no valid row
+          } else {
+            int const vb = p.acc[qi].valid_bit, pw = p.acc[qi].pay;
+            if (vb >= 0 && !((valvalid >> vb) & 1u)) continue;
+            if constexpr (INPUT == IN_COLUMNS) {
+              v     = col_load_acc_bits(p.cols[p.nkeycols + pw], r);
+              rowid = static_cast<uint64_t>(r);
+            } else {
+              v     = gload(records + r * U + KU + pw);
+              rowid = gload(records + r * U + p.rowid_unit) & 0xffffffffull;
+            }
+          }
+          uint64_t const best = accs[static_cast<uint32_t>(qv) * static_cast<uint32_t>(cap) + static_cast<uint32_t>(slot)];
+          bool const same     = p.arg[i].is_float
+                                  ? __longlong_as_double(static_cast<long long>(v)) == __longlong_as_double(static_cast<long long>(best))
+                                  : v == best;
+          if (same)
+            atomicMin(reinterpret_cast<long long*>(accs + (static_cast<uint32_t>(qi) * static_cast<uint32_t>(cap) + static_cast<uint32_t>(slot))),
+                      static_cast<long long>(rowid));
+        }
+      }
+    }
+    __syncthreads();
+  }
   // dump the table as compact partial records
   uint64_t* out = a.out_records + static_cast<int64_t>(item) * cap * PU;
   for (int s = threadIdx.x; s < cap; s += blockDim.x) {
@@ -596,7 +671,7 @@ static uint64_t plan_sig(plan_dev const& p)
   uint64_t a[4] = {0, 0, 0, 0};
   for (int q = 0; q < p.NACC; ++q) {
     auto const& d = p.acc[q];
-    if (d.pay > 5 || d.valid_bit > 5) return 0;
+    if (d.pay > 5 || d.valid_bit > 5 || d.src > 3) return 0;
     a[q] = sig_acc(d.op, d.src, d.pay, d.valid_bit);
   }
   return make_sig(p.NACC, a[0], a[1], a[2], a[3]);

@@ -67,6 +67,7 @@ __device__ __forceinline__ uint32_t half_bits(plan_dev const& p, int8_t src, int
   if (src == H_NONE) return 0;
   if (src == H_KEYNULLS) return keynulls;
   if (src == H_VALVALID) return valvalid;
+  if (src == H_ROWID) return static_cast<uint32_t>(row);
   if ((keynulls >> src) & 1u) return 0;  // NULL key element: data zeroed so equal NULLs compare equal
   return static_cast<uint32_t>(normalize_key_bits(col_load_bits(p.cols[src], row), p.cols[src].cls));
 }
@@ -215,6 +216,9 @@ __device__ __forceinline__ void batch_half(plan_dev const& p, int8_t src, int64_
   } else if (src == H_VALVALID) {
 #pragma unroll
     for (int k = 0; k < NR; ++k) out[k] = valvalid[k];
+  } else if (src == H_ROWID) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) out[k] = static_cast<uint32_t>(row[k]);
   } else {
     device_column const col = p.cols[src];
     uint64_t raw[NR];

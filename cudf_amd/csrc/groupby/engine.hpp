@@ -33,6 +33,7 @@ constexpr int MAX_UNITS = 16;  // units per record (raw or partial)
 constexpr int8_t H_NONE     = -1;
 constexpr int8_t H_KEYNULLS = -2;  // bit c set = key column c is NULL at this row (null_policy::INCLUDE)
 constexpr int8_t H_VALVALID = -3;  // bit v set = value column v is valid at this row
+constexpr int8_t H_ROWID    = -4;  // the row's index in the input table (ARGMIN / ARGMAX)
 
 struct unit_desc {
   int8_t full;  // 1: the unit is the 8-byte column `lo`
@@ -45,7 +46,9 @@ struct unit_desc {
 enum acc_op : int8_t { ADD_I64 = 0, ADD_F64, MIN_I64, MIN_U64, MIN_F64, MAX_I64, MAX_U64, MAX_F64, MUL_I64, MUL_F64 };
 // How a RAW row contributes (reference device_aggregators.cuh:24-112,428-446: null source elements are
 // skipped for everything except COUNT_ALL).
-enum acc_src : int8_t { SRC_VALUE = 0, SRC_ONE_IF_VALID, SRC_ONE, SRC_SQUARE };
+enum acc_src : int8_t { SRC_VALUE = 0, SRC_ONE_IF_VALID, SRC_ONE, SRC_SQUARE, SRC_ARG_IDX, SRC_ARG_IDX_OF_MAX };
+// SRC_ARG_IDX (of a minimum) / SRC_ARG_IDX_OF_MAX: the row-index half of an ARGMIN / ARGMAX pair (arg_desc): untouched by the first sweep, filled by a second
+// sweep over the same rows once the extreme value of every group is final.
 
 struct acc_desc {
   int8_t op;
@@ -53,6 +56,17 @@ struct acc_desc {
   int8_t pay;        // raw payload unit holding the value (or -1)
   int8_t valid_bit;  // bit in VALVALID, or -1 if the value column has no nulls
 };
+
+// ARGMIN / ARGMAX = (MIN / MAX accumulator of the value, MIN_I64 accumulator of the row index among the rows that
+// attain it). Ties resolve to the smallest row index: one of the outcomes of the reference's arrival-order CAS loop
+// (device_aggregators.cuh:131-160), made deterministic.
+struct arg_desc {
+  int8_t valacc;
+  int8_t idxacc;
+  int8_t is_float;  // compare values numerically (-0.0 == +0.0) instead of bitwise
+  int8_t pad;
+};
+constexpr int MAX_ARG = 4;
 
 struct plan_dev {
   device_column cols[MAX_COLS];  // key columns first, then the distinct value columns
@@ -64,6 +78,9 @@ struct plan_dev {
   int32_t drop_null_keys;  // null_policy::EXCLUDE and some key column is nullable
   int32_t flags_unit;      // raw unit holding VALVALID (-1: none)
   int32_t flags_hi;        // 1: in the high half
+  int32_t rowid_unit;      // raw unit holding the row index in its low half (-1: none)
+  int32_t narg;
+  arg_desc arg[MAX_ARG];
   unit_desc unit[MAX_UNITS];
   uint64_t key_mask[MAX_KU];
   acc_desc acc[MAX_ACC];

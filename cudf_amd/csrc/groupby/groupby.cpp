@@ -182,7 +182,9 @@ bool is_engine_kind(aggregation::Kind k)
     case aggregation::SUM_OF_SQUARES:
     case aggregation::M2:
     case aggregation::VARIANCE:
-    case aggregation::STD: return true;
+    case aggregation::STD:
+    case aggregation::ARGMAX:
+    case aggregation::ARGMIN: return true;
     default: return false;
   }
 }
@@ -245,6 +247,9 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
   bool const need_keynulls   = keys_have_nulls && policy == null_policy::INCLUDE;
   bool need_valvalid         = false;
   for (auto const& v : hp.value_cols) need_valvalid = need_valvalid || v.has_nulls();
+  bool need_rowid = false;  // ARGMIN / ARGMAX: records carry the row index
+  for (auto const& r : requests)
+    for (auto const& a : r.aggregations) need_rowid = need_rowid || a->kind == aggregation::ARGMIN || a->kind == aggregation::ARGMAX;
 
   // ---- key units: 8-byte columns take a full unit, narrower ones share units two per unit
   int u = 0;
@@ -304,6 +309,18 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
     CUDF_EXPECTS(u < MAX_UNITS, "Record too wide.");
     p.unit[u++] = unit_desc{1, static_cast<int8_t>(p.nkeycols + v), H_NONE, 0};
   }
+  p.rowid_unit = -1;
+  if (need_rowid) {  // row index in the low half; VALVALID rides in the high half if it still needs a home
+    CUDF_EXPECTS(u < MAX_UNITS, "Record too wide.");
+    bool const with_flags = need_valvalid && p.flags_unit < 0;
+    p.unit[u]    = unit_desc{0, H_ROWID, with_flags ? H_VALVALID : H_NONE, 0};
+    p.rowid_unit = u;
+    if (with_flags) {
+      p.flags_unit = u;
+      p.flags_hi   = 1;
+    }
+    ++u;
+  }
   if (need_valvalid && p.flags_unit < 0) {
     CUDF_EXPECTS(u < MAX_UNITS, "Record too wide.");
     p.unit[u]    = unit_desc{0, H_VALVALID, H_NONE, 0};
@@ -355,6 +372,23 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
             p, acc_desc{static_cast<int8_t>(is_float ? MAX_F64 : (cls == CLS_SINT ? MAX_I64 : MAX_U64)), SRC_VALUE,
                         static_cast<int8_t>(vidx), vbit});
           break;
+        case aggregation::ARGMIN:
+        case aggregation::ARGMAX: {
+          bool const is_min = agg->kind == aggregation::ARGMIN;
+          int const valacc  = find_or_add_acc(
+            p, acc_desc{static_cast<int8_t>(is_min ? (is_float ? MIN_F64 : (cls == CLS_SINT ? MIN_I64 : MIN_U64))
+                                                   : (is_float ? MAX_F64 : (cls == CLS_SINT ? MAX_I64 : MAX_U64))),
+                        SRC_VALUE, static_cast<int8_t>(vidx), vbit});
+          int const before = p.NACC;
+          rs.a0 = find_or_add_acc(p, acc_desc{MIN_I64, static_cast<int8_t>(is_min ? SRC_ARG_IDX : SRC_ARG_IDX_OF_MAX),
+                                              static_cast<int8_t>(vidx), vbit});
+          if (p.NACC != before) {  // a new pair (the same request twice shares it)
+            CUDF_EXPECTS(p.narg < MAX_ARG, "Too many ARGMIN / ARGMAX aggregations in one call (limit 4).");
+            p.arg[p.narg++] = arg_desc{static_cast<int8_t>(valacc), static_cast<int8_t>(rs.a0), static_cast<int8_t>(is_float), 0};
+          }
+          rs.acc_cls = CLS_SINT;
+          break;
+        }
         case aggregation::COUNT_VALID:
           rs.a0       = count_valid_acc();
           rs.nullable = false;
@@ -399,7 +433,7 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
     if (!plain) { p.simple = 0; break; }
     p.simple_base[w] = static_cast<uint64_t const*>(c.head) + c.offset;
   }
-  if (env_i64("CUDF_AMD_GB_NO_SIMPLE", 0)) p.simple = 0;
+  if (env_i64("CUDF_AMD_GB_NO_SIMPLE", 0) || need_rowid) p.simple = 0;
   p.simple_vec16 = p.simple;
   for (int w = 0; p.simple && w < p.KU + p.NPAY; ++w)
     if (reinterpret_cast<uintptr_t>(p.simple_base[w]) % 16 != 0) p.simple_vec16 = 0;

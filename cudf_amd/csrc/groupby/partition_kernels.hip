@@ -472,7 +472,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   g.region_count = a.region_count + region0;
   g.overflow     = a.overflow;
   g.out          = a.out_records + region0 * a.region_cap * UT;
-  cudf::detail::wc_scatter_slice<RPT, G, UT>(lds_raw, g, load_tile, digit_of);
+  cudf::detail::wc_scatter_slice<RPT, G, UT, SRC != WC_SRC_COLUMNS>(lds_raw, g, load_tile, digit_of);
 }
 
 }  // namespace

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(1024) k_probe_partition(join_args const* __res
     }
   };
   auto digit_of = [&](uint64_t const (&rec)[2]) { return static_cast<uint32_t>(hash64_single(rec[0]) >> shift); };
-  wc_scatter_slice<RPT, G, 2>(lds_raw, g, load_tile, digit_of);
+  wc_scatter_slice<RPT, G, 2, true>(lds_raw, g, load_tile, digit_of);
 }
 
 // ------------------------------------------------------------------ probe: count pass

@@ -11,7 +11,7 @@ from oracle.oracle import KIND, HostColumn
 _AGG = {"sum": agg.sum, "min": agg.min, "max": agg.max, "mean": agg.mean,
         "count_valid": lambda: agg.count(NullPolicy.EXCLUDE), "count_all": lambda: agg.count(NullPolicy.INCLUDE),
         "sum_of_squares": agg.sum_of_squares, "nth_element": lambda: agg.nth_element(0), "median": agg.median,
-        "variance": agg.variance, "std": agg.std, "m2": agg.m2, "product": agg.product}
+        "variance": agg.variance, "std": agg.std, "m2": agg.m2, "product": agg.product, "argmin": agg.argmin, "argmax": agg.argmax}
 
 
 def to_host_column(c):

@@ -35,7 +35,7 @@ def host_col(values, type_name, valid=None):
 
 def expected_type_id(value_type, agg):
     integral = value_type in ("int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "bool")
-    if agg in ("count_valid", "count_all"):
+    if agg in ("count_valid", "count_all", "argmin", "argmax"):
         return TYPE_ID["int32"]
     if agg == "mean":
         return TYPE_ID["float64"]

@@ -180,6 +180,27 @@ def test_product(G, oracle, vt):
         kat.compare_columns(got[1][0][0], exp[1][0][0], "product")
 
 
+@pytest.mark.parametrize("vt", ["int32", "int64", "float64", "float32"])
+@pytest.mark.parametrize("n,groups", [(30_000, 300), (6_000_000, 3_000), (5_000_000, 2_500_000)])
+def test_argmin_argmax(G, oracle, vt, n, groups):
+    """ARGMIN / ARGMAX = smallest row index among the rows that attain the group's extreme value (two sweeps over the
+    rows; deterministic where the reference's CAS loop is arrival-order dependent). Values repeat, so ties are common;
+    sizes cover the single-table, merged and partitioned (row index carried in the records) paths."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(23)
+    k = rng.integers(0, groups, n, dtype=np.int64)
+    npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
+    v = rng.integers(-20, 20, n).astype(npt)
+    vv = rng.random(n) > 0.1
+    col = HostColumn(v, vv, vt)
+    aggs = ["argmin", "argmax", "min", "max"]
+    got = kat.sort_groups(*G.groupby([k], [(col, aggs)]))
+    exp = kat.sort_groups(*oracle.groupby([k], [(col, aggs)]))
+    kat.compare_columns(got[0][0], exp[0][0], "keys")
+    for name, a, e in zip(aggs, got[1][0], exp[1][0]):
+        kat.compare_columns(a, e, name)
+
+
 def test_sliced_columns_offset(G, oracle):
     """Arrow offset: element i at data[offset+i], validity at bit offset+i."""
     from oracle.oracle import HostColumn
