@@ -316,3 +316,14 @@ def test_two_level_optimistic_partition(G, oracle, shape, monkeypatch):
             kat.compare_columns(a, e, "keys")
         for name, a, e in zip(aggs, got[1][0], exp[1][0]):
             kat.compare_columns(a, e, name, atol=kat.sum_atol(16, 1.0))
+
+
+def test_two_level_optimistic_overflow_falls_back(G, oracle):
+    """Two optimistic levels with a heavy hitter: a third of the rows carry one key, its level-1 (or level-2) region
+    overflows and the exact two-level pipeline repairs the call."""
+    rng = np.random.default_rng(32)
+    n = 6_000_000
+    k = rng.integers(0, 6_000_000, n, dtype=np.int64)
+    k[rng.random(n) < 0.33] = 123_456
+    v = rng.random(n)
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all", "max"])], expect_path="PARTITIONED_LDS")
