@@ -7,6 +7,7 @@
 #include <cudf/aggregation.hpp>
 #include <cudf/copying.hpp>
 #include <cudf/groupby.hpp>
+#include <cudf/interop.hpp>
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
 #include <cudf/table/table.hpp>
@@ -17,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <map>
+#include <string>
 #include <vector>
 
 #define CHECK(cond)                                                                  \
@@ -126,6 +128,36 @@ int main()
   CHECK(a == b);  // joined keys agree row by row
   std::sort(a.begin(), a.end());
   CHECK((a == std::vector<int32_t>{0, 2, 2, 2, 2, 3}));
+  // ---- chunked probing (hash_join.hpp:276-412): match counts {1,0,2,1,2} (join_tests.cpp:2445-2449), then the join of
+  // left rows [2, 5) with indices that refer to the complete left table
+  {
+    auto ctx = hj.inner_join_match_context(t0v);
+    std::vector<cudf::size_type> counts(5);
+    (void)hipMemcpy(counts.data(), ctx._match_counts->data(), 20, hipMemcpyDeviceToHost);
+    CHECK((counts == std::vector<cudf::size_type>{1, 0, 2, 1, 2}));
+    cudf::join_partition_context part{std::make_unique<cudf::join_match_context>(std::move(ctx)), 2, 5};
+    auto [cl, cr] = hj.partitioned_inner_join(part);
+    CHECK(cl->size() == 5);
+    std::vector<cudf::size_type> hcl(5);
+    (void)hipMemcpy(hcl.data(), cl->data(), 20, hipMemcpyDeviceToHost);
+    CHECK(std::all_of(hcl.begin(), hcl.end(), [](auto x) { return x >= 2 && x < 5; }));
+  }
+
+  // ---- Arrow C Data Interface: export the groupby result to host Arrow memory and import it again (interop.hpp)
+  {
+    std::vector<cudf::column_view> out_cols{result.first->view().column(0), result.second[0].results[0]->view()};
+    cudf::table_view out_tv{out_cols};
+    auto schema = cudf::to_arrow_schema(out_tv, {cudf::column_metadata{"k"}, cudf::column_metadata{"sum"}});
+    auto arr    = cudf::to_arrow_host(out_tv);
+    CHECK(std::string{schema->format} == "+s" && schema->n_children == 2);
+    CHECK(std::string{schema->children[0]->format} == "i" && std::string{schema->children[1]->format} == "l");
+    CHECK(arr->device_type == ARROW_DEVICE_CPU && arr->array.length == 3 && arr->array.n_children == 2);
+    auto back = cudf::from_arrow(schema.get(), &arr->array);
+    CHECK(back->num_rows() == 3 && back->num_columns() == 2);
+    auto k2 = to_host<int32_t>(back->view().column(0));
+    auto s2 = to_host<int64_t>(back->view().column(1));
+    CHECK(k2 == k && s2 == s);
+  }
   std::puts("api_compat OK");
   return 0;
 }
