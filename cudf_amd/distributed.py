@@ -24,6 +24,14 @@ class GpuBackend:
     def __init__(self, stream=None):
         self.stream = stream
 
+    def inner_join(self, left_keys, right_keys):
+        """Local inner join of two 1-D key tensors -> (left row indices, right row indices) as int64 cuda tensors."""
+        import cudf_amd
+        from cudf_amd import join as J
+        li, ri = J.inner_join(cudf_amd.Table([cudf_amd.Column.from_torch(left_keys)]),
+                              cudf_amd.Table([cudf_amd.Column.from_torch(right_keys)]), stream=self.stream)
+        return li.to_torch().to(torch.int64), ri.to_torch().to(torch.int64)
+
     def partition(self, columns, num_partitions):
         """columns: list of 1-D cuda tensors, column 0 is the key. -> (list of partitioned tensors, offsets list)."""
         import cudf_amd
@@ -121,3 +129,30 @@ def distributed_groupby_sum_count(keys, vals, stream=None, mode="shuffle", backe
         k2, sums2, _ = backend.groupby_sum(rk, [rs, rc], count=False)
         return k2, sums2[0], sums2[1]
     raise ValueError(f"unknown mode {mode!r}")
+
+
+def distributed_inner_join(left_keys, right_keys, stream=None, backend=None, group=None, max_message_bytes=None):
+    """Inner join of two tables sharded by rows over the ranks: both sides are hash-partitioned
+    by key with the same hash, every partition meets on its owner rank (one all-to-all per side, the GLOBAL row id
+    = rank offset + local index travels as a payload column), and the owner joins locally. Every matching
+    (left row, right row) pair of the whole tables is returned exactly once, by the rank that owns the key:
+    -> (global left row ids, global right row ids) as int64 tensors."""
+    backend = backend or GpuBackend(stream)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = left_keys.device
+
+    def global_ids(n):
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        counts[rank] = n
+        dist.all_reduce(counts, group=group)  # rows per rank; exclusive prefix = this rank's first global row id
+        first = int(counts[:rank].sum().item())
+        return torch.arange(first, first + n, dtype=torch.int64, device=dev)
+
+    sides = []
+    for keys in (left_keys, right_keys):
+        cols, offs = backend.partition([keys, global_ids(keys.numel())], world)
+        sides.append(exchange(cols, offs, group, max_message_bytes))
+    (lk, lid), (rk, rid) = sides
+    li, ri = backend.inner_join(lk, rk)
+    return lid[li], rid[ri]

@@ -33,6 +33,46 @@ class HostBackend:
         return torch.from_numpy(kc[0][0].copy()), sums, cnt
 
 
+def _host_inner_join(self, left_keys, right_keys):
+    from oracle import oracle as O
+    li, ri = O.join([left_keys.numpy()], [right_keys.numpy()], nulls_equal=True, kind="inner")
+    return torch.from_numpy(np.asarray(li, dtype=np.int64)), torch.from_numpy(np.asarray(ri, dtype=np.int64))
+
+
+HostBackend.inner_join = _host_inner_join
+
+
+def _join_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cudf_amd import distributed as D
+        rng = np.random.default_rng(7 + rank)
+        lk = torch.from_numpy(rng.integers(0, 4000, 9_000 + 500 * rank, dtype=np.int64))   # ragged shards, duplicates
+        rk = torch.from_numpy(rng.integers(0, 4000, 2_000 + 300 * rank, dtype=np.int64))
+        gl, gr = D.distributed_inner_join(lk, rk, backend=HostBackend())
+        np.savez(os.path.join(out_dir, f"j{rank}.npz"), gl=gl.numpy(), gr=gr.numpy(), lk=lk.numpy(), rk=rk.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_inner_join(tmp_path):
+    """Both sides sharded over two ranks: the union of the ranks' (global left id, global right id) pairs equals the
+    inner join of the concatenated tables, each pair exactly once."""
+    world = 2
+    mp.spawn(_join_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"j{r}.npz") for r in range(world)]
+    all_l = np.concatenate([p["lk"] for p in parts])
+    all_r = np.concatenate([p["rk"] for p in parts])
+    from oracle import oracle as O
+    el, er = O.join([all_l], [all_r], nulls_equal=True, kind="inner")
+    got = sorted(zip(np.concatenate([p["gl"] for p in parts]).tolist(), np.concatenate([p["gr"] for p in parts]).tolist()))
+    assert got == sorted(zip(np.asarray(el).tolist(), np.asarray(er).tolist()))
+    assert len(set(got)) == len(got)
+
+
 def _worker(rank, world, port, mode, out_dir, max_message_bytes=None):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -143,3 +143,25 @@ def test_distributed_single_rank_rccl(G, oracle, mode):
         assert np.allclose(gs[o].cpu().numpy(), rc[0][0][0], rtol=1e-12)
     finally:
         dist.destroy_process_group()
+
+
+def test_distributed_inner_join_single_rank_rccl(G, oracle):
+    """distributed_inner_join over the nccl (RCCL) backend at world_size 1: hash partition of (key, global row id) on both
+    sides -> all-to-all -> local cudf::inner_join -> global row ids."""
+    import torch
+    import torch.distributed as dist
+    import kat
+    from cudf_amd import distributed as D
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(6)
+        lk = rng.integers(0, 50_000, 300_000, dtype=np.int64)
+        rk = rng.integers(0, 50_000, 40_000, dtype=np.int64)
+        gl, gr = D.distributed_inner_join(torch.from_numpy(lk).cuda(), torch.from_numpy(rk).cuda())
+        el, er = oracle.join([lk], [rk], nulls_equal=True, kind="inner")
+        assert kat.sorted_pairs(gl.cpu().numpy(), gr.cpu().numpy()) == kat.sorted_pairs(el, er)
+    finally:
+        dist.destroy_process_group()
