@@ -37,6 +37,7 @@ __device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
       __hip_atomic_fetch_max(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v)),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       break;
+    case ANY_U64: *slot = v; break;  // any contributing row will do: a plain store
     case MUL_I64:
     case MUL_F64: {
       // no multiply atomic: compare-and-swap loop (ds_cmpst_rtn_b64), as the reference's product (device_atomics.cuh:226-337)
@@ -559,6 +560,10 @@ __global__ void __launch_bounds__(256) k_finalize(finalize_args const* __restric
       if (d.kind == OUT_KEY) {
         uint64_t const unit = rec[d.key_unit];
         bits                = d.key_full ? unit : (d.key_hi ? (unit >> 32) : (unit & 0xffffffffull));
+        if (d.key_acc >= 0) {  // float key: the bits of a representative input row (carried as float64)
+          uint64_t const raw = rec[p.KU + d.key_acc];
+          bits = d.width == 4 ? __float_as_uint(static_cast<float>(__longlong_as_double(static_cast<long long>(raw)))) : raw;
+        }
         if (d.key_null_bit >= 0) {
           uint64_t const kn = rec[d.keynulls_unit];
           uint32_t const w  = d.keynulls_hi ? static_cast<uint32_t>(kn >> 32) : static_cast<uint32_t>(kn);

@@ -43,7 +43,10 @@ struct unit_desc {
 };
 
 // Merge operator of an accumulator (identities: reference device_operators.cuh:60-76,132-139,190-197).
-enum acc_op : int8_t { ADD_I64 = 0, ADD_F64, MIN_I64, MIN_U64, MIN_F64, MAX_I64, MAX_U64, MAX_F64, MUL_I64, MUL_F64 };
+enum acc_op : int8_t { ADD_I64 = 0, ADD_F64, MIN_I64, MIN_U64, MIN_F64, MAX_I64, MAX_U64, MAX_F64, MUL_I64, MUL_F64, ANY_U64 };
+// ANY_U64: keeps the value of one (any) contributing row - the un-normalised bits of a float key column, so that the
+// output key is a representative INPUT row as in the reference (compute_groupby.cu:104-111) and not the normalised
+// +0.0 / canonical NaN the key units carry.
 // How a RAW row contributes (reference device_aggregators.cuh:24-112,428-446: null source elements are
 // skipped for everything except COUNT_ALL).
 enum acc_src : int8_t { SRC_VALUE = 0, SRC_ONE_IF_VALID, SRC_ONE, SRC_SQUARE, SRC_ARG_IDX, SRC_ARG_IDX_OF_MAX };
@@ -113,6 +116,7 @@ struct out_desc {
   int8_t width;         // output element width
   int8_t out_cls;       // elem_class of the output type
   int8_t key_unit, key_hi, key_full;  // OUT_KEY: where the key lives
+  int8_t key_acc;       // OUT_KEY of a float column: accumulator (ANY_U64, float64 bits) holding a representative row's value (-1 none)
   int8_t key_null_bit;  // OUT_KEY with INCLUDE: bit in KEYNULLS (-1 none)
   int8_t keynulls_unit, keynulls_hi;
 };

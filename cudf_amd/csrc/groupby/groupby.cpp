@@ -206,6 +206,8 @@ struct host_plan {
   // key column c -> (unit, half: 0 lo / 1 hi / 2 full)
   int key_unit[MAX_COLS]{};
   int key_half[MAX_COLS]{};
+  int key_raw_vidx[MAX_COLS];  // float key column -> its slot among the value columns (-1: not a float key)
+  int key_acc[MAX_COLS];       // ... -> the ANY_U64 accumulator carrying a representative row's bits
   int keynulls_unit{-1}, keynulls_hi{0};
 };
 
@@ -230,6 +232,19 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
     bool found = false;
     for (auto const& v : hp.value_cols) found = found || cudf::detail::is_shallow_equivalent(v, r.values);
     if (!found) hp.value_cols.push_back(r.values);
+  }
+  // float key columns also travel as value columns: the key units hold NORMALISED bits (-0.0 -> +0.0, one NaN), the output
+  // key must be a representative input row (reference compute_groupby.cu:104-111)
+  for (int c = 0; c < keys.num_columns(); ++c) {
+    hp.key_raw_vidx[c] = -1;
+    hp.key_acc[c]      = -1;
+    auto const cls     = class_of(keys.column(c).type().id());
+    if (cls != CLS_F32 && cls != CLS_F64) continue;
+    int vidx = 0;
+    for (; vidx < static_cast<int>(hp.value_cols.size()); ++vidx)
+      if (cudf::detail::is_shallow_equivalent(hp.value_cols[vidx], keys.column(c))) break;
+    if (vidx == static_cast<int>(hp.value_cols.size())) hp.value_cols.push_back(keys.column(c));
+    hp.key_raw_vidx[c] = vidx;
   }
   CUDF_EXPECTS(static_cast<int>(hp.value_cols.size()) <= MAX_PAY - 1, "Too many distinct value columns (limit 7).");
   CUDF_EXPECTS(keys.num_columns() + static_cast<int>(hp.value_cols.size()) <= MAX_COLS,
@@ -421,6 +436,9 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
       hp.results.push_back(rs);
     }
   }
+  for (int c = 0; c < p.nkeycols; ++c)
+    if (hp.key_raw_vidx[c] >= 0)
+      hp.key_acc[c] = find_or_add_acc(p, acc_desc{ANY_U64, SRC_VALUE, static_cast<int8_t>(hp.key_raw_vidx[c]), -1});
   // ---- fast path: all units are plain 8-byte columns (no nulls, no conversion, no normalisation)
   p.simple = 1;
   for (int w = 0; w < p.KU + p.NPAY; ++w) {
@@ -904,6 +922,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     d.keynulls_unit = static_cast<int8_t>(hp.keynulls_unit);
     d.keynulls_hi   = static_cast<int8_t>(hp.keynulls_hi);
     d.valid_acc     = -1;
+    d.key_acc       = static_cast<int8_t>(hp.key_acc[c]);
     fin.out[fin.nout++] = d;
     key_cols.push_back(std::move(col));
   }
@@ -929,6 +948,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     d.width      = static_cast<int8_t>(size_of(rs.target));
     d.out_cls    = static_cast<int8_t>(class_of(rs.target.id()));
     d.key_null_bit = -1;
+    d.key_acc      = -1;
     fin.out[fin.nout++] = d;
     res_cols.push_back(std::move(col));
   }

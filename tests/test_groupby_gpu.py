@@ -327,3 +327,34 @@ def test_two_level_optimistic_overflow_falls_back(G, oracle):
     k[rng.random(n) < 0.33] = 123_456
     v = rng.random(n)
     _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all", "max"])], expect_path="PARTITIONED_LDS")
+
+
+@pytest.mark.parametrize("vt", ["float64", "float32"])
+def test_float_keys_output_a_representative_input_row(G, oracle, vt):
+    """-0.0 == +0.0 and NaN == NaN group together (row equality, equality.cuh:59-89), but the OUTPUT key is one of the
+    group's input rows, bit for bit (compute_groupby.cu:104-111): a group of only -0.0 comes back as -0.0, a group
+    of NaNs as a NaN, a mixed +-0.0 group as either zero."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
+    rng = np.random.default_rng(41)
+    n = 50_000
+    k = rng.integers(1, 200, n).astype(npt) * npt(0.5)
+    k[::7] = npt(-0.0)              # a group of negative zeros only
+    k[1::11] = npt("nan")
+    second = rng.integers(0, 2, n).astype(np.int32)  # second key: (-0.0, 0) and (-0.0, 1) groups
+    v = rng.random(n)
+    kc, rc = G.groupby([HostColumn(k, None, vt), HostColumn(second, None, "int32")], [(HostColumn(v, None, "float64"), ["count_all", "sum"])])
+    out_k = kc[0][0]
+    zeros = out_k[out_k == 0]
+    assert len(zeros) == 2 and np.signbit(zeros).all()                 # both zero groups hold only -0.0 rows
+    assert np.isnan(out_k).sum() == 2                                   # the two NaN groups come back as NaN
+    ek, er = oracle.groupby([HostColumn(k, None, vt), HostColumn(second, None, "int32")], [(HostColumn(v, None, "float64"), ["count_all", "sum"])])
+    got, exp = kat.sort_groups(kc, rc), kat.sort_groups(ek, er)
+    for a, e in zip(got[0], exp[0]):
+        kat.compare_columns(a, e, "keys")
+    kat.compare_columns(got[1][0][0], exp[1][0][0], "count_all")
+    # a mixed group may return either zero
+    k2 = np.array([0.0, -0.0, 0.0, 1.5], dtype=npt)
+    kc2, rc2 = G.groupby([HostColumn(k2, None, vt)], [(HostColumn(np.ones(4), None, "float64"), ["count_all"])])
+    o = np.argsort(kc2[0][0])
+    assert kc2[0][0][o].tolist() == [0.0, 1.5] and rc2[0][0][0][o].tolist() == [3, 1]
