@@ -37,7 +37,7 @@ def expected_type_id(value_type, agg):
     integral = value_type in ("int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "bool")
     if agg in ("count_valid", "count_all", "argmin", "argmax"):
         return TYPE_ID["int32"]
-    if agg == "mean":
+    if agg in ("mean", "variance", "std", "m2"):
         return TYPE_ID["float64"]
     if agg in ("sum", "sum_of_squares", "product"):
         return TYPE_ID["int64"] if integral else TYPE_ID[value_type]
