@@ -281,3 +281,50 @@ def test_partitioned_join_invalid_context(G):
             hj.partitioned_inner_join(JoinPartitionContext(ctx, a, b))
     with pytest.raises(ValueError):
         hj.partitioned_inner_join(JoinPartitionContext(JoinMatchContext(left, None), 0, 1))
+
+
+_JOIN_FUZZ_TYPES = ["int8", "int16", "int32", "int64", "uint32", "uint64", "float32", "float64", "bool"]
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_joins_against_oracle(G, oracle, seed, monkeypatch):
+    """Seeded random joins: 1-3 key columns of mixed types, nulls on either side, both null equalities, all three kinds,
+    duplicate keys on both sides, sliced inputs, empty sides; every fourth seed goes through the sliced-table /
+    partitioned-probe path."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(5000 + seed)
+    if seed % 4 == 3:
+        monkeypatch.setenv("CUDF_AMD_JOIN_PARTITIONED", "1")
+        monkeypatch.setenv("CUDF_AMD_JOIN_SLICE_MIN_MB", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_PARTITION_MIN_ROWS", "1")
+    nl = int(rng.choice([0, 1, 50, 3_000, 120_000]))
+    nr = int(rng.choice([0, 1, 40, 2_000, 30_000]))
+    ncols = int(rng.integers(1, 4))
+    types = [str(rng.choice(_JOIN_FUZZ_TYPES)) for _ in range(ncols)]
+    spread = int(rng.choice([4, 60, 5000]))
+    # keep the result enumerable on the host: about nl * nr / (distinct keys) pairs
+    while nl * nr / float(np.prod([2 if t == "bool" else spread for t in types])) > 2e6:
+        spread *= 4
+
+    def side(n):
+        cols = []
+        for t in types:
+            npt = NP_OF_TYPE_ID[TYPE_ID[t]]
+            off = int(rng.choice([0, 0, 4]))
+            m = n + off
+            if t == "bool":
+                data = rng.integers(0, 2, m).astype(npt)
+            elif np.dtype(npt).kind == "f":
+                data = (rng.integers(0, spread, m) - spread // 2).astype(npt) * npt(0.5)
+                if m:
+                    data[rng.integers(0, m, max(1, m // 50))] = npt("nan")
+            else:
+                data = rng.integers(0, min(spread, int(np.iinfo(npt).max) - 1), m).astype(npt)
+            valid = (rng.random(m) > 0.1) if rng.random() < 0.4 else None
+            cols.append(HostColumn(data, valid, t, offset=off) if off else HostColumn(data, valid, t))
+        return cols
+
+    left, right = side(nl), side(nr)
+    nulls_equal = bool(rng.random() < 0.5)
+    kind = str(rng.choice(["inner", "left", "full"]))
+    _check(G, oracle, left, right, nulls_equal, kind)
