@@ -268,17 +268,34 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     int const slot   = lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key, h, &s_nfilled, fill_limit, &s_overflow);
     if (slot >= 0) accumulate(r, slot, pay, valvalid);
   };
+  // Generic columns (narrow types, nulls) whose record shape is known at compile time: records of a whole batch are built
+  // column-at-a-time (descriptors decoded once per batch, typed loads issued back to back) - row-at-a-time record
+  // building with lazily loaded payloads ran the single-pass path at 13.5 ms per 1B rows against 3.1 ms for plain columns.
+  constexpr bool BATCH_COLS = INPUT == IN_COLUMNS && !SIMPLE && EXACT && PAYT > 0;
   // loads one row; false if the row is dropped
   auto load_row = [&](int64_t r, uint64_t (&key)[KUT], uint64_t (&pay)[PAYT > 0 ? PAYT : 1], uint32_t& valvalid) -> bool {
     valvalid = 0xffffffffu;
     if constexpr (INPUT == IN_COLUMNS) {
-      // plain 8-byte columns: the payload is loaded WITH the key (a lazy load at accumulate time is a second exposed
-      // HBM round trip per batch)
+      // the payload is loaded WITH the key (a lazy load at accumulate time is a second exposed HBM round trip per batch)
       if constexpr (SIMPLE && PAYT > 0) {
 #pragma unroll
         for (int v = 0; v < PAYT; ++v) pay[v] = gload(p.simple_base[KU + v] + r);
       }
-      return build_key_units<KUT, SIMPLE>(p, r, key, valvalid);
+      if constexpr (BATCH_COLS) {  // a single row through the batched record builder (tail rows)
+        int64_t row[1] = {r};
+        bool live[1]   = {true};
+        uint64_t rec[1][KUT + PAYT];
+        uint32_t vv[1];
+        batch_units<1, KUT + PAYT>(p, KUT + PAYT, row, live, rec, vv);
+#pragma unroll
+        for (int u = 0; u < KUT; ++u) key[u] = rec[0][u];
+#pragma unroll
+        for (int v = 0; v < PAYT; ++v) pay[v] = rec[0][KUT + v];
+        valvalid = vv[0];
+        return live[0];
+      } else {
+        return build_key_units<KUT, SIMPLE>(p, r, key, valvalid);
+      }
     } else if constexpr (EXACT && KUT == 1 && PAYT == 1) {
       u64x2 const v = gload(reinterpret_cast<u64x2 const*>(records) + r);
       key[0]        = v.x;
@@ -311,6 +328,70 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
   int64_t const B     = blockDim.x;
   constexpr int64_t W = R * 64;
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  // Bucketed probe of R rows per lane together: per round, the four state words of each pending row's bucket (one
+  // ds_read_b128 each, issued back to back), then the key words of the slot whose tag matches, then the verdict.
+  auto probe_batch = [&](uint64_t const (&key)[R][KUT], uint64_t const (&h)[R], int (&bkt)[R], int (&sl)[R], uint32_t pend) {
+    int const nbkt = cap >> 2;
+      int guard = 0;
+    while (pend != 0) {
+      asm volatile("" ::: "memory");  // the state words change under us: read them again every round
+      u32x4 sw[R];
+      int cand[R];
+      uint64_t kc[R][KUT];
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        if ((pend >> k) & 1u) sw[k] = *reinterpret_cast<u32x4 const*>(st + 4 * bkt[k]);
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (!((pend >> k) & 1u)) continue;
+        uint32_t const tag = tag_of(h[k]);
+        cand[k] = sw[k].x == tag ? 0 : (sw[k].y == tag ? 1 : (sw[k].z == tag ? 2 : (sw[k].w == tag ? 3 : -1)));
+        if (cand[k] >= 0) {
+#pragma unroll
+          for (int u = 0; u < KUT; ++u) kc[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + 4 * bkt[k] + cand[k])] : 0;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (!((pend >> k) & 1u)) continue;
+        uint32_t const tag = tag_of(h[k]);
+        if (cand[k] >= 0) {
+          bool eq = true;
+#pragma unroll
+          for (int u = 0; u < KUT; ++u)
+            if (u < KU) eq = eq && (kc[k][u] == (key[k][u] & kmask[u]));
+          // a different key with the same tag (2^-30 per occupied slot): resolve this row slot by slot
+          sl[k] = eq ? 4 * bkt[k] + cand[k]
+                     : lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
+          pend &= ~(1u << k);
+          continue;
+        }
+        bool const locked = sw[k].x == ST_LOCKED || sw[k].y == ST_LOCKED || sw[k].z == ST_LOCKED || sw[k].w == ST_LOCKED;
+        if (locked) continue;  // a slot of this bucket is being published (it may be this key): read again
+        int const e = sw[k].x == ST_EMPTY ? 0 : (sw[k].y == ST_EMPTY ? 1 : (sw[k].z == ST_EMPTY ? 2 : (sw[k].w == ST_EMPTY ? 3 : -1)));
+        if (e < 0) {  // full of other keys
+          bkt[k] = bkt[k] + 1 == nbkt ? 0 : bkt[k] + 1;
+          continue;
+        }
+        int const c = 4 * bkt[k] + e;
+        if (atomicCAS(&st[c], ST_EMPTY, ST_LOCKED) == ST_EMPTY) {
+#pragma unroll
+          for (int u = 0; u < KUT; ++u)
+            if (u < KU) keys[static_cast<uint32_t>(u * cap + c)] = key[k][u] & kmask[u];
+          __hip_atomic_store(&st[c], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          uint32_t const nf = atomicAdd(&s_nfilled, 1u);
+          if (static_cast<int>(nf) >= fill_limit) s_overflow = 1;
+          sl[k] = c;
+          pend &= ~(1u << k);
+        }
+        // lost the race (possibly to an earlier row of this lane): read the bucket again
+      }
+      if (++guard > cap + 64) {  // saturated table
+        s_overflow = 1;
+        pend       = 0;
+      }
+    }
+  };
   // few long sources (the regions of a second partition level): every wave works on every source
   bool const multi = a.seg == SEG_STRIDED && nsrc >= nwaves;
   for (int sidx = multi ? wave : 0; sidx < nsrc; sidx += multi ? nwaves : 1) {
@@ -363,6 +444,23 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
           for (int k = 0; k < R; ++k)
             nkeep[k] = load_row(begin + (b + bstep) * W + k * 64 + lane, nkey[k], npay[k], nvalvalid[k]);
         }
+      } else if constexpr (BATCH_COLS) {
+        // (no software pipeline here: a second register set for the next batch spills - measured slower)
+        int64_t row[R];
+        uint64_t rec[R][KUT + PAYT];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          row[k]  = base + k * 64 + lane;
+          keep[k] = true;
+        }
+        batch_units<R, KUT + PAYT>(p, KUT + PAYT, row, keep, rec, valvalid);
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+#pragma unroll
+          for (int u = 0; u < KUT; ++u) key[k][u] = rec[k][u];
+#pragma unroll
+          for (int v = 0; v < PAYT; ++v) pay[k][v] = rec[k][KUT + v];
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) keep[k] = load_row(base + k * 64 + lane, key[k], pay[k], valvalid[k]);
@@ -372,7 +470,6 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
       uint64_t h[R];
       int bkt[R], sl[R];
       uint32_t pend   = 0;
-      int const nbkt  = cap >> 2;
 #pragma unroll
       for (int k = 0; k < R; ++k) {
         h[k]   = hash_of(key[k]);
@@ -380,65 +477,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
         sl[k]  = -1;
         if (keep[k]) pend |= 1u << k;
       }
-      int guard = 0;
-      while (pend != 0) {
-        asm volatile("" ::: "memory");  // the state words change under us: read them again every round
-        u32x4 sw[R];
-        int cand[R];
-        uint64_t kc[R][KUT];
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-          if ((pend >> k) & 1u) sw[k] = *reinterpret_cast<u32x4 const*>(st + 4 * bkt[k]);
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          if (!((pend >> k) & 1u)) continue;
-          uint32_t const tag = tag_of(h[k]);
-          cand[k] = sw[k].x == tag ? 0 : (sw[k].y == tag ? 1 : (sw[k].z == tag ? 2 : (sw[k].w == tag ? 3 : -1)));
-          if (cand[k] >= 0) {
-#pragma unroll
-            for (int u = 0; u < KUT; ++u) kc[k][u] = u < KU ? keys[static_cast<uint32_t>(u * cap + 4 * bkt[k] + cand[k])] : 0;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-          if (!((pend >> k) & 1u)) continue;
-          uint32_t const tag = tag_of(h[k]);
-          if (cand[k] >= 0) {
-            bool eq = true;
-#pragma unroll
-            for (int u = 0; u < KUT; ++u)
-              if (u < KU) eq = eq && (kc[k][u] == (key[k][u] & kmask[u]));
-            // a different key with the same tag (2^-30 per occupied slot): resolve this row slot by slot
-            sl[k] = eq ? 4 * bkt[k] + cand[k]
-                       : lds_find_or_insert<KUT>(KU, kmask, st, keys, cap, key[k], h[k], &s_nfilled, fill_limit, &s_overflow);
-            pend &= ~(1u << k);
-            continue;
-          }
-          bool const locked = sw[k].x == ST_LOCKED || sw[k].y == ST_LOCKED || sw[k].z == ST_LOCKED || sw[k].w == ST_LOCKED;
-          if (locked) continue;  // a slot of this bucket is being published (it may be this key): read again
-          int const e = sw[k].x == ST_EMPTY ? 0 : (sw[k].y == ST_EMPTY ? 1 : (sw[k].z == ST_EMPTY ? 2 : (sw[k].w == ST_EMPTY ? 3 : -1)));
-          if (e < 0) {  // full of other keys
-            bkt[k] = bkt[k] + 1 == nbkt ? 0 : bkt[k] + 1;
-            continue;
-          }
-          int const c = 4 * bkt[k] + e;
-          if (atomicCAS(&st[c], ST_EMPTY, ST_LOCKED) == ST_EMPTY) {
-#pragma unroll
-            for (int u = 0; u < KUT; ++u)
-              if (u < KU) keys[static_cast<uint32_t>(u * cap + c)] = key[k][u] & kmask[u];
-            __hip_atomic_store(&st[c], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            uint32_t const nf = atomicAdd(&s_nfilled, 1u);
-            if (static_cast<int>(nf) >= fill_limit) s_overflow = 1;
-            sl[k] = c;
-            pend &= ~(1u << k);
-          }
-          // lost the race (possibly to an earlier row of this lane): read the bucket again
-        }
-        if (++guard > cap + 64) {  // saturated table
-          s_overflow = 1;
-          pend       = 0;
-        }
-      }
+      probe_batch(key, h, bkt, sl, pend);
 #pragma unroll
       for (int k = 0; k < R; ++k)
         if (keep[k] && sl[k] >= 0) accumulate(base + k * 64 + lane, sl[k], pay[k], valvalid[k]);
@@ -687,6 +726,9 @@ constexpr uint64_t SIG_SUMI_CNT = make_sig(2, sig_acc(ADD_I64, SRC_VALUE, 0, -1)
 constexpr uint64_t SIG_SUMF     = make_sig(1, sig_acc(ADD_F64, SRC_VALUE, 0, -1));
 constexpr uint64_t SIG_SUMI     = make_sig(1, sig_acc(ADD_I64, SRC_VALUE, 0, -1));
 constexpr uint64_t SIG_CNT      = make_sig(1, sig_acc(ADD_I64, SRC_ONE, -1, -1));
+// SUM + COUNT_VALID (and MEAN) of a NULLABLE column: both accumulators test the row's validity bit
+constexpr uint64_t SIG_SUMF_CNT_NULLS = make_sig(2, sig_acc(ADD_F64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0));
+constexpr uint64_t SIG_SUMI_CNT_NULLS = make_sig(2, sig_acc(ADD_I64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0));
 // C4: MEAN + MIN + MAX of a nullable float64 column -> SUM, COUNT_VALID, MIN, MAX
 constexpr uint64_t SIG_MEAN_MIN_MAX_F_NULLS =
   make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0), sig_acc(MIN_F64, SRC_VALUE, 0, 0),
@@ -720,6 +762,14 @@ static void launch_aggregate_records(agg_args const& a, agg_args* d_args, hipStr
       if (sig == SIG_SUMI) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMI>(a, d_args, stream);
       if (sig == SIG_CNT) return launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_CNT>(a, d_args, stream);
     }
+    if (KU == 1 && (npay == 1 || npay == 2)) {  // nullable value: the validity flags ride in the key's spare half or in their own unit
+      if (sig == SIG_SUMF_CNT_NULLS)
+        return npay == 1 ? launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMF_CNT_NULLS>(a, d_args, stream)
+                         : launch_aggregate_n<INPUT, 1, 2, 2, false, true, SIG_SUMF_CNT_NULLS>(a, d_args, stream);
+      if (sig == SIG_SUMI_CNT_NULLS)
+        return npay == 1 ? launch_aggregate_n<INPUT, 1, 1, 2, false, true, SIG_SUMI_CNT_NULLS>(a, d_args, stream)
+                         : launch_aggregate_n<INPUT, 1, 2, 2, false, true, SIG_SUMI_CNT_NULLS>(a, d_args, stream);
+    }
     if (KU == 2 && npay == 1 && sig == SIG_MEAN_MIN_MAX_F_NULLS)
       return launch_aggregate_n<INPUT, 2, 1, 4, false, true, SIG_MEAN_MIN_MAX_F_NULLS>(a, d_args, stream);
     if (KU == 2 && npay == 1 && a.plan.flags_unit < 0 && sig == SIG_MEAN_MIN_MAX_F)
@@ -751,6 +801,23 @@ void launch_aggregate(agg_args const& a, agg_args* d_args, hipStream_t stream)
     if (sig == SIG_SUMF) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, true, true, SIG_SUMF>(a, d_args, stream);
     if (sig == SIG_SUMI) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, true, true, SIG_SUMI>(a, d_args, stream);
     return launch_aggregate_t<IN_COLUMNS, 1, 1, true, true>(a, d_args, stream);
+  }
+  if (!simple && a.plan.NPAY >= 1 && a.plan.NPAY <= 2 && KU >= 1 && KU <= 2) {  // generic columns, known record shape
+    uint64_t const sig = plan_sig(a.plan);
+    if (KU == 1 && a.plan.NPAY == 1) {
+      if (sig == SIG_SUMF_CNT) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, false, true, SIG_SUMF_CNT>(a, d_args, stream);
+      if (sig == SIG_SUMI_CNT) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, false, true, SIG_SUMI_CNT>(a, d_args, stream);
+      if (sig == SIG_SUMF_CNT_NULLS) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, false, true, SIG_SUMF_CNT_NULLS>(a, d_args, stream);
+      if (sig == SIG_SUMI_CNT_NULLS) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, false, true, SIG_SUMI_CNT_NULLS>(a, d_args, stream);
+      return launch_aggregate_t<IN_COLUMNS, 1, 1, false, true>(a, d_args, stream);
+    }
+    if (KU == 1 && a.plan.NPAY == 2) {
+      if (sig == SIG_SUMF_CNT_NULLS) return launch_aggregate_n<IN_COLUMNS, 1, 2, 2, false, true, SIG_SUMF_CNT_NULLS>(a, d_args, stream);
+      if (sig == SIG_SUMI_CNT_NULLS) return launch_aggregate_n<IN_COLUMNS, 1, 2, 2, false, true, SIG_SUMI_CNT_NULLS>(a, d_args, stream);
+      return launch_aggregate_t<IN_COLUMNS, 1, 2, false, true>(a, d_args, stream);
+    }
+    if (KU == 2 && a.plan.NPAY == 1) return launch_aggregate_t<IN_COLUMNS, 2, 1, false, true>(a, d_args, stream);
+    return launch_aggregate_t<IN_COLUMNS, 2, 2, false, true>(a, d_args, stream);
   }
   if (KU <= 1) simple ? launch_aggregate_t<IN_COLUMNS, 1, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 1, 0, false, false>(a, d_args, stream);
   else if (KU <= 2) simple ? launch_aggregate_t<IN_COLUMNS, 2, 0, true, false>(a, d_args, stream) : launch_aggregate_t<IN_COLUMNS, 2, 0, false, false>(a, d_args, stream);
