@@ -584,7 +584,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     // Planned table load. Bucketed probing resolves a row in two LDS round trips up to ~0.4; a lighter table means
     // more partitions. 16-byte records (write-combining scatter): halving the fan-out saves more in the scatter
     // (C2: 8.3 -> 7.1 ms) than the fuller tables cost the aggregate (3.1 -> 3.7 ms), so plan for 0.45/safety = 0.35.
-    bool const wc_eligible = RU == 2 && p.KU == 1 && env_i64("CUDF_AMD_GB_WC", 1) != 0;
+    bool const wc_eligible = (RU == 2 || RU == 3) && p.KU == 1 && env_i64("CUDF_AMD_GB_WC", 1) != 0;
     double const plan_fill = std::max(1.0, ag.cap * 0.01 * static_cast<double>(env_i64("CUDF_AMD_GB_PLAN_LOAD_PCT", wc_eligible ? 45 : 25)));
     double const need = std::min(est_groups * safety, static_cast<double>(n)) / plan_fill;
     agg_args aa{};
@@ -656,7 +656,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       auto wc_granule_for = [&](int64_t P) -> int32_t {
         if (!env_i64("CUDF_AMD_GB_WC", 1)) return 0;
         int const G = RU == 2 ? static_cast<int>(env_i64("CUDF_AMD_GB_WC_G", P > 512 ? 4 : 8)) : (RU == 4 ? 4 : 8);
-        return partition_wc_fits(RU, static_cast<int>(P), G) ? G : 0;
+        if (partition_wc_fits(RU, static_cast<int>(P), G)) return G;
+        return (RU == 3 && partition_wc_fits(RU, static_cast<int>(P), 4)) ? 4 : 0;  // 24-byte records: 96-byte granules
       };
       part_args pa{};
       pa.plan         = p;

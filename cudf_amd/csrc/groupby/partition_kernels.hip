@@ -533,7 +533,9 @@ int wc_rpt(int U) { return U == 2 ? 5 : U == 3 ? 4 : U == 4 ? 3 : 0; }
 bool partition_wc_fits(int U, int P, int G)
 {
   int const rpt = wc_rpt(U);
-  if (rpt == 0 || (G != 4 && G != 8) || (U != 2 && G != (U == 4 ? 4 : 8))) return false;
+  // 24-byte records: 192-byte granules (G = 8), or 96-byte ones (G = 4: whole 32-byte sectors) where the carry area of
+  // G = 8 does not fit; 32-byte records: 128-byte granules
+  if (rpt == 0 || (G != 4 && G != 8) || (U == 4 && G != 4)) return false;
   // static LDS of the kernel (region prefix list, abort flag) is ~1.1 KB
   return cudf::detail::wc_scatter_lds_bytes(static_cast<std::size_t>(1024) * rpt, P, G, U) + 1200 <= 160 * 1024;
 }
@@ -573,6 +575,7 @@ void launch_partition_scatter(part_args const& a, part_args const* d_args, hipSt
                  "write-combining scatter: optimistic regions, records of 2-4 units, carry area within the LDS");
     if (U == 2 && a.wc_granule == 4) launch_scatter_wc_t<2, 5, 4>(a, d_args, stream);
     else if (U == 2) launch_scatter_wc_t<2, 5, 8>(a, d_args, stream);
+    else if (U == 3 && a.wc_granule == 4) launch_scatter_wc_t<3, 4, 4>(a, d_args, stream);
     else if (U == 3) launch_scatter_wc_t<3, 4, 8>(a, d_args, stream);
     else launch_scatter_wc_t<4, 3, 4>(a, d_args, stream);
     return;
