@@ -272,6 +272,8 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
   // column-at-a-time (descriptors decoded once per batch, typed loads issued back to back) - row-at-a-time record
   // building with lazily loaded payloads ran the single-pass path at 13.5 ms per 1B rows against 3.1 ms for plain columns.
   constexpr bool BATCH_COLS = INPUT == IN_COLUMNS && !SIMPLE && EXACT && PAYT > 0;
+  units_local<BATCH_COLS ? KUT + PAYT : 1> L{};
+  if constexpr (BATCH_COLS) L.load(p, KUT + PAYT);
   // loads one row; false if the row is dropped
   auto load_row = [&](int64_t r, uint64_t (&key)[KUT], uint64_t (&pay)[PAYT > 0 ? PAYT : 1], uint32_t& valvalid) -> bool {
     valvalid = 0xffffffffu;
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
         bool live[1]   = {true};
         uint64_t rec[1][KUT + PAYT];
         uint32_t vv[1];
-        batch_units<1, KUT + PAYT>(p, KUT + PAYT, row, live, rec, vv);
+        batch_units_local<1, KUT + PAYT>(L, KUT + PAYT, row, live, rec, vv);
 #pragma unroll
         for (int u = 0; u < KUT; ++u) key[u] = rec[0][u];
 #pragma unroll
@@ -453,7 +455,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
           row[k]  = base + k * 64 + lane;
           keep[k] = true;
         }
-        batch_units<R, KUT + PAYT>(p, KUT + PAYT, row, keep, rec, valvalid);
+        batch_units_local<R, KUT + PAYT>(L, KUT + PAYT, row, keep, rec, valvalid);
 #pragma unroll
         for (int k = 0; k < R; ++k) {
 #pragma unroll
@@ -802,7 +804,7 @@ void launch_aggregate(agg_args const& a, agg_args* d_args, hipStream_t stream)
     if (sig == SIG_SUMI) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, true, true, SIG_SUMI>(a, d_args, stream);
     return launch_aggregate_t<IN_COLUMNS, 1, 1, true, true>(a, d_args, stream);
   }
-  if (!simple && a.plan.NPAY >= 1 && a.plan.NPAY <= 2 && KU >= 1 && KU <= 2) {  // generic columns, known record shape
+  if (!simple && a.plan.NPAY >= 1 && a.plan.NPAY <= 2 && KU >= 1 && KU <= 2 && a.plan.ncols <= MAX_LOCAL_COLS) {  // generic columns, known record shape
     uint64_t const sig = plan_sig(a.plan);
     if (KU == 1 && a.plan.NPAY == 1) {
       if (sig == SIG_SUMF_CNT) return launch_aggregate_n<IN_COLUMNS, 1, 1, 2, false, true, SIG_SUMF_CNT>(a, d_args, stream);

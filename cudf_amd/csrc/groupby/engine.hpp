@@ -28,6 +28,7 @@ constexpr int MAX_KU    = 4;   // key units (8 B each) per record
 constexpr int MAX_PAY   = 8;   // raw payload units
 constexpr int MAX_ACC   = 12;  // accumulators per group
 constexpr int MAX_UNITS = 16;  // units per record (raw or partial)
+constexpr int MAX_LOCAL_COLS = 6;  // columns the register-resident record builder resolves (device_common.hpp units_local)
 
 // Source of one 32-bit half of a key/payload unit.
 constexpr int8_t H_NONE     = -1;

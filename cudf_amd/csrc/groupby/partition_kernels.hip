@@ -427,6 +427,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
         row[k]  = tile + static_cast<int64_t>(k) * B + threadIdx.x;
         keep[k] = row[k] < sr.end;
       }
+      // (descriptors from the plan: resolving them once into registers - units_local - measured 7 % SLOWER here)
       batch_units<RPT, UT>(p, UT, row, keep, rec, vv);
     } else {
 #pragma unroll
