@@ -243,6 +243,49 @@ __global__ void __launch_bounds__(256) k_gather_data(device_column src, int32_t 
   }
 }
 
+// Gather of up to GATHER_COLS columns that share one map: R rows per thread, the map elements first, then every
+// column's R random loads back to back (the random reads are what the pass waits for: bytes in flight buy throughput,
+// and the map is read once instead of once per column), then the stores.
+constexpr int GATHER_COLS = 4;
+struct gather_cols {
+  device_column src[GATHER_COLS];
+  void* out[GATHER_COLS];
+  int32_t ncols;
+  int32_t src_rows;
+};
+__global__ void __launch_bounds__(256) k_gather_multi(gather_cols g, size_type const* map, int64_t n)
+{
+  constexpr int R = 4;
+  int64_t const base = (blockIdx.x * static_cast<int64_t>(blockDim.x)) * R + threadIdx.x;
+  int64_t s[R];
+  bool in[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    int64_t const i = base + static_cast<int64_t>(k) * blockDim.x;
+    s[k]            = i < n ? gload(map + i) : -1;
+    in[k]           = s[k] >= 0 && s[k] < g.src_rows;
+  }
+#pragma unroll
+  for (int c = 0; c < GATHER_COLS; ++c) {
+    if (c >= g.ncols) break;
+    device_column const col = g.src[c];
+    uint64_t v[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = in[k] ? col_load_bits(col, s[k]) : 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      int64_t const i = base + static_cast<int64_t>(k) * blockDim.x;
+      if (i >= n) continue;
+      switch (col.width) {
+        case 1: gstore(static_cast<uint8_t*>(g.out[c]) + i, static_cast<uint8_t>(v[k])); break;
+        case 2: gstore(static_cast<uint16_t*>(g.out[c]) + i, static_cast<uint16_t>(v[k])); break;
+        case 4: gstore(static_cast<uint32_t*>(g.out[c]) + i, static_cast<uint32_t>(v[k])); break;
+        default: gstore(static_cast<uint64_t*>(g.out[c]) + i, v[k]);
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_row_hash(device_table t, uint32_t seed, uint32_t* out)
 {
   int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -371,19 +414,31 @@ std::unique_ptr<table> gather(table_view const& source_table, column_view const&
   for (auto const& col : source_table) {
     auto const w = size_of(col.type());
     CUDF_EXPECTS(w <= 8, "gather: only fixed-width columns of at most 8 bytes.");
-    auto out = std::make_unique<column>(col.type(), static_cast<size_type>(n),
-                                        rmm::device_buffer{static_cast<size_t>(n) * w, stream.value(), mr}, rmm::device_buffer{}, 0);
-    if (n > 0) {
-      auto dc = make_device_column(col);
-      hipLaunchKernelGGL(k_gather_data, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream.value(), dc, col.size(), map,
-                         n, out->mutable_view().head());
+    out_cols.push_back(std::make_unique<column>(col.type(), static_cast<size_type>(n),
+                                                rmm::device_buffer{static_cast<size_t>(n) * w, stream.value(), mr}, rmm::device_buffer{}, 0));
+  }
+  if (n > 0) {
+    // data: columns in groups of GATHER_COLS per launch
+    for (size_type first = 0; first < source_table.num_columns(); first += GATHER_COLS) {
+      gather_cols g{};
+      g.ncols    = std::min<int32_t>(GATHER_COLS, source_table.num_columns() - first);
+      g.src_rows = source_table.num_rows();
+      for (int c = 0; c < g.ncols; ++c) {
+        g.src[c] = make_device_column(source_table.column(first + c));
+        g.out[c] = out_cols[static_cast<size_t>(first + c)]->mutable_view().head();
+      }
+      cudf::detail::prof::scope p_{"gather", stream.value()};
+      hipLaunchKernelGGL(k_gather_multi, dim3(static_cast<unsigned>((n + 1023) / 1024)), dim3(256), 0, stream.value(), g, map, n);
       CUDF_HIP_TRY(hipGetLastError());
+    }
+    // validity
+    for (size_type c = 0; c < source_table.num_columns(); ++c) {
+      auto const& col = source_table.column(c);
       if (col.nullable() || nullify) {
         auto [mask, nulls] = gather_mask(col, map, n, nullify, stream, mr);
-        if (col.nullable() || nulls > 0) out->set_null_mask(std::move(mask), nulls);
+        if (col.nullable() || nulls > 0) out_cols[static_cast<size_t>(c)]->set_null_mask(std::move(mask), nulls);
       }
     }
-    out_cols.push_back(std::move(out));
   }
   return std::make_unique<table>(std::move(out_cols));
 }
