@@ -166,8 +166,6 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
   constexpr bool STATIC_SIG = SIG != 0;
   int const KU = EXACT ? KUT : p.KU, NACC = STATIC_SIG ? sig_n(SIG) : p.NACC;
   uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);                 // [KU][cap]
-  uint64_t* accs = keys + static_cast<size_t>(KU) * cap;                   // [NACC][cap]
-  uint32_t* st   = reinterpret_cast<uint32_t*>(accs + static_cast<size_t>(NACC) * cap);  // [cap]
   __shared__ uint32_t s_nfilled, s_dump;
   __shared__ int32_t s_overflow;
 
@@ -176,16 +174,15 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     s_dump     = 0;
     s_overflow = 0;
   }
-  for (int s = threadIdx.x; s < cap; s += blockDim.x) st[s] = ST_EMPTY;
-  for (int q = 0; q < NACC; ++q) {
-    uint64_t const id = acc_identity(p.acc[q].op);
-    for (int s = threadIdx.x; s < cap; s += blockDim.x) accs[static_cast<size_t>(q) * cap + s] = id;
-  }
   uint64_t kmask[KUT];
 #pragma unroll
   for (int u = 0; u < KUT; ++u) kmask[u] = u < KU ? p.key_mask[u] : 0;
   // accumulator descriptors live in (scalar) registers for the whole kernel: no memory access per row
   int acc_op[NACCT], acc_src[NACCT], acc_pay[NACCT], acc_vbit[NACCT];
+  // LDS layout: keys [KU][cap] u64 | accumulator q [cap] u64, or u32 for a COUNT | state words [cap] u32
+  uint32_t acc_off[NACCT];
+  bool acc_narrow[NACCT];
+  uint32_t lds_off = static_cast<uint32_t>(KU) * static_cast<uint32_t>(cap) * 8u;
 #pragma unroll
   for (int j = 0; j < NACCT; ++j) {
     uint32_t const w = j < NACC ? reinterpret_cast<uint32_t const*>(p.acc)[j] : 0u;
@@ -193,6 +190,30 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     acc_src[j]       = STATIC_SIG ? sig_src(SIG, j) : static_cast<int8_t>(w >> 8);
     acc_pay[j]       = STATIC_SIG ? sig_pay(SIG, j) : static_cast<int8_t>(w >> 16);
     acc_vbit[j]      = STATIC_SIG ? sig_vbit(SIG, j) : static_cast<int8_t>(w >> 24);
+    acc_narrow[j]    = j < NACC && acc_is_narrow(acc_op[j], acc_src[j]);
+    acc_off[j]       = lds_off;
+    if (j < NACC) lds_off += static_cast<uint32_t>(cap) * (acc_narrow[j] ? 4u : 8u);
+  }
+  uint32_t* st = reinterpret_cast<uint32_t*>(lds_raw + lds_off);  // [cap], 16-byte aligned (cap is a multiple of 4)
+  auto acc_off_rt = [&](int q) {  // offset of accumulator q for a run-time q (ARGMIN / ARGMAX sweep)
+    uint32_t o = 0;
+#pragma unroll
+    for (int j = 0; j < NACCT; ++j)
+      if (j == q) o = acc_off[j];
+    return o;
+  };
+  auto acc64 = [&](int q) { return reinterpret_cast<uint64_t*>(lds_raw + acc_off[q]); };
+  auto acc32 = [&](int q) { return reinterpret_cast<uint32_t*>(lds_raw + acc_off[q]); };
+  for (int s = threadIdx.x; s < cap; s += blockDim.x) st[s] = ST_EMPTY;
+#pragma unroll
+  for (int q = 0; q < NACCT; ++q) {
+    if (q >= NACC) break;
+    if (acc_narrow[q]) {
+      for (int s = threadIdx.x; s < cap; s += blockDim.x) acc32(q)[s] = 0;
+    } else {
+      uint64_t const id = acc_identity(acc_op[q]);
+      for (int s = threadIdx.x; s < cap; s += blockDim.x) acc64(q)[s] = id;
+    }
   }
   __syncthreads();
 
@@ -211,22 +232,23 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
 #pragma unroll
     for (int q = 0; q < NACCT; ++q) {
       if (q >= NACC) break;
-      uint64_t* tgt = accs + (static_cast<uint32_t>(q) * static_cast<uint32_t>(cap) + static_cast<uint32_t>(slot));
+      uint64_t* tgt = acc64(q) + slot;  // (COUNT accumulators: acc32(q) + slot)
       if (acc_src[q] >= SRC_ARG_IDX) continue;  // filled by the second sweep
       if constexpr (INPUT == IN_PARTIAL_RECORDS) {
         uint64_t v;
         if constexpr (PAYT > 0) v = q < PAYT ? pay[q < PAYT ? q : 0] : 0;
         else v = gload(records + r * U + KU + q);
-        lds_merge(tgt, acc_op[q], v);
+        if (acc_narrow[q]) atomicAdd(acc32(q) + slot, static_cast<uint32_t>(v));
+        else lds_merge(tgt, acc_op[q], v);
       } else {
         if (acc_src[q] == SRC_ONE) {
-          lds_merge(tgt, ADD_I64, 1);
+          atomicAdd(acc32(q) + slot, 1u);
           continue;
         }
         bool const valid = acc_vbit[q] < 0 || ((valvalid >> acc_vbit[q]) & 1u);
         if (!valid) continue;
         if (acc_src[q] == SRC_ONE_IF_VALID) {
-          lds_merge(tgt, ADD_I64, 1);
+          atomicAdd(acc32(q) + slot, 1u);
           continue;
         }
         if (acc_pay[q] != last_pay) {
@@ -534,13 +556,12 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
               rowid = gload(records + r * U + p.rowid_unit) & 0xffffffffull;
             }
           }
-          uint64_t const best = accs[static_cast<uint32_t>(qv) * static_cast<uint32_t>(cap) + static_cast<uint32_t>(slot)];
+          uint64_t const best = reinterpret_cast<uint64_t const*>(lds_raw + acc_off_rt(qv))[slot];
           bool const same     = p.arg[i].is_float
                                   ? __longlong_as_double(static_cast<long long>(v)) == __longlong_as_double(static_cast<long long>(best))
                                   : v == best;
           if (same)
-            atomicMin(reinterpret_cast<long long*>(accs + (static_cast<uint32_t>(qi) * static_cast<uint32_t>(cap) + static_cast<uint32_t>(slot))),
-                      static_cast<long long>(rowid));
+            atomicMin(reinterpret_cast<long long*>(lds_raw + acc_off_rt(qi)) + slot, static_cast<long long>(rowid));
         }
       }
     }
@@ -553,7 +574,11 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
       uint32_t const pos = atomicAdd(&s_dump, 1u);
       uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
       for (int u = 0; u < KU; ++u) gstore(o + u, keys[static_cast<size_t>(u) * cap + s]);
-      for (int q = 0; q < NACC; ++q) gstore(o + KU + q, accs[static_cast<size_t>(q) * cap + s]);
+#pragma unroll
+      for (int q = 0; q < NACCT; ++q) {
+        if (q >= NACC) break;
+        gstore(o + KU + q, acc_narrow[q] ? static_cast<uint64_t>(acc32(q)[s]) : acc64(q)[s]);
+      }
     }
   }
   __syncthreads();
@@ -689,9 +714,15 @@ __global__ void __launch_bounds__(256) k_popcount(uint32_t const* bitmap, int64_
 
 }  // namespace
 
+int aggregate_slot_bytes(plan_dev const& plan)
+{
+  int b = 8 * plan.KU + 4;
+  for (int q = 0; q < plan.NACC; ++q) b += acc_is_narrow(plan.acc[q].op, plan.acc[q].src) ? 4 : 8;
+  return b;
+}
 std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g)
 {
-  return static_cast<std::size_t>(g.cap) * (8u * (plan.KU + plan.NACC) + 4u);
+  return static_cast<std::size_t>(g.cap) * static_cast<std::size_t>(aggregate_slot_bytes(plan));
 }
 
 template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT, uint64_t SIG = 0>

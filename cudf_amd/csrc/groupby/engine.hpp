@@ -54,6 +54,10 @@ enum acc_src : int8_t { SRC_VALUE = 0, SRC_ONE_IF_VALID, SRC_ONE, SRC_SQUARE, SR
 // SRC_ARG_IDX (of a minimum) / SRC_ARG_IDX_OF_MAX: the row-index half of an ARGMIN / ARGMAX pair (arg_desc): untouched by the first sweep, filled by a second
 // sweep over the same rows once the extreme value of every group is final.
 
+// COUNT accumulators (adding 1 per row, or partial counts of at most 2^31 - 1 rows) take 4 bytes in the LDS table; the
+// partial records still carry them as 8-byte units.
+constexpr bool acc_is_narrow(int op, int src) { return op == ADD_I64 && (src == SRC_ONE || src == SRC_ONE_IF_VALID); }
+
 struct acc_desc {
   int8_t op;
   int8_t src;
@@ -227,6 +231,8 @@ void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int6
                      int32_t bitmap_bits_log2, uint32_t* d_bits_set, hipStream_t stream);
 
 std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g);
+// LDS bytes of one table slot: key units, accumulators (4 bytes for counts), state word
+int aggregate_slot_bytes(plan_dev const& plan);
 std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g);
 // write-combining scatter: can records of U units be partitioned P ways with granules of G records?
 bool partition_wc_fits(int U, int P, int G);

@@ -529,7 +529,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   // ---- geometry
   agg_geom ag{};
   int64_t const lds_budget = env_i64("CUDF_AMD_GB_LDS_KB", 159) * 1024;  // 160 KiB minus the kernels' static words
-  int const slot_bytes     = 8 * PU + 4;
+  int const slot_bytes     = aggregate_slot_bytes(p);  // key units + accumulators (COUNTs take 4 bytes) + state word
   // a multiple of 4: the table is probed in aligned buckets of four slots (one ds_read_b128 of state words)
   ag.cap                   = static_cast<int32_t>(std::min<int64_t>(lds_budget / slot_bytes, 16384)) & ~3;
   ag.block                 = static_cast<int32_t>(env_i64("CUDF_AMD_GB_AGG_BLOCK", 1024));
