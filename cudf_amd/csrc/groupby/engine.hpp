@@ -7,8 +7,9 @@
 //   partial record = [KU key units | NACC accumulator units]   (one per (group, work item))
 // and aggregated ONLY in LDS hash tables (ds_add_f64 / ds_add_u64 / ds_min/max) — scattered global atomics
 // run at ~24 G ops/s on gfx950 (profiles/microbench_r1.txt) and cannot carry 1B rows. When the groups do
-// not fit one LDS table the records are first radix-partitioned on the top bits of a 64-bit key hash
-// (LDS-staged multi-split with exact offsets), so each partition's groups fit one table.
+// not fit one LDS table the records are first radix-partitioned on the top bits of a 64-bit key hash (one or two
+// levels; optimistic write-combining scatter into per-workgroup regions, or histogram / scan / scatter with exact
+// offsets as the fallback), so each partition's groups fit one table.
 // Replaces the reference's cuco::static_set + global-atomic design
 // (cpp/src/groupby/hash/compute_groupby.cu:51-155, compute_global_memory_aggs.cuh:74-187,
 // single_pass_functors.cuh:86-157) and its LDS path (compute_mapping_indices.cuh:92-151,
@@ -209,7 +210,7 @@ struct part_args {
   unsigned long long* stamps;
 };
 
-// Launchers (kernels.hip). All asynchronous on `stream`. Kernel arguments live in DEVICE memory (`d_args`,
+// Launchers (partition_kernels.hip, aggregate_kernels.hip). All asynchronous on `stream`. Kernel arguments live in DEVICE memory (`d_args`,
 // one slot per launch family, written by a one-thread kernel on the same stream): passed by value, the
 // dynamically indexed column descriptors were copied to scratch by the compiler (792 B/lane) and every
 // descriptor access became a vector memory load.
