@@ -85,6 +85,11 @@ def _timeit(fn):
 
 def main():
     args = parse()
+    # Libraries print banners on the C-level stdout (RCCL: "RCCL version : ...", "Hostname : ..."): everything but the
+    # one JSON line goes to stderr; the line itself is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -153,29 +158,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    # N > 1: also time the other form of the exchange (raw-row shuffle by default); reported next to `value`.
-    pre, pre_error = None, None
-    if world > 1 or force_dist:
-        from cudf_amd import distributed as D2
-
-        def pre_step():
-            return D2.distributed_groupby_sum_count(keys, vals, stream=stream, mode=other_mode)
-
-        try:  # the secondary form must never cost the primary number its JSON line
-            pre_step()
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                pre_step()
-            barrier()
-            tp = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-            pre = float(tp.item())
-        except Exception as e:  # noqa: BLE001 - reported in the JSON line
-            pre_error = repr(e)
-
-    if rank == 0:
+    def build_line(pre, pre_error):
         ms_per_step = dt / args.steps * 1e3
         total_rows = n * world
         value = total_rows * args.steps / dt
@@ -226,7 +209,55 @@ def main():
             line["raw_row_shuffle_variant" if other_mode == "shuffle" else "preaggregated_variant"] = {"error": pre_error}
         if world == 1 and not force_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(groups, args.cpu_sample_rows)
-        print(json.dumps(line), flush=True)
+        return line
+
+
+    # N > 1: also time the other form of the exchange (raw-row shuffle by default); reported next to `value`. The
+    # secondary form must never cost the primary number its JSON line: an exception is reported in the line, and a
+    # watchdog prints the line without it if the secondary form has not finished in time (a collective that never
+    # returns cannot be interrupted from Python).
+    import threading
+    state = {"pre": None, "pre_error": None, "printed": False}
+    emit_lock = threading.Lock()
+
+    def emit_and_maybe_exit(timed_out):
+        with emit_lock:
+            if state["printed"]:
+                return
+            state["printed"] = True
+            if timed_out:
+                state["pre_error"] = f"not finished after {watchdog_s} s"
+            if rank == 0:
+                os.write(json_fd, (json.dumps(build_line(state["pre"], state["pre_error"])) + "\n").encode())
+        if timed_out:
+            os._exit(0)
+
+    watchdog_s = int(os.environ.get("BENCH_VARIANT_TIMEOUT_S", "300"))
+    if world > 1 or force_dist:
+        from cudf_amd import distributed as D2
+
+        def pre_step():
+            return D2.distributed_groupby_sum_count(keys, vals, stream=stream, mode=other_mode)
+
+        watchdog = threading.Timer(watchdog_s, emit_and_maybe_exit, args=(True,))
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            pre_step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pre_step()
+            barrier()
+            tp = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            state["pre"] = float(tp.item())
+        except Exception as e:  # noqa: BLE001 - reported in the JSON line
+            state["pre_error"] = repr(e)
+        watchdog.cancel()
+
+    emit_and_maybe_exit(False)
     if world > 1 or force_dist:
         dist.destroy_process_group()
 
