@@ -542,7 +542,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   // ---- distinct-count estimate on a strided sample (skipped when n already fits one table)
   double est_groups = static_cast<double>(n);
   if (n > ag.fill_limit) {
-    int64_t const sample = std::min<int64_t>(n, int64_t{1} << 20);
+    // 1M sampled rows for big inputs; small inputs sample 1/16 of their rows (at least 64K): the estimate only picks the
+    // strategy, and a 1M-row sample costs more than the aggregation of a 1M-row input
+    int64_t const sample = std::min<int64_t>(n, std::clamp<int64_t>(n / 16, int64_t{1} << 16, int64_t{1} << 20));
     int const bits_log2  = 24;
     uint32_t* bitmap     = sc.alloc<uint32_t>((size_t{1} << bits_log2) / 32);
     uint32_t* d_set      = sc.alloc<uint32_t>(1);
@@ -665,7 +667,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       // optimistic: one persistent workgroup per CU (longer regions for the aggregate); exact: 2 per CU (the
       // histogram pass wants the parallelism: 1.6 ms at 512 slices vs 2.7 ms at 256)
       bool const will_try_optimistic = allow_optimistic && P2 == 1 && !forced_exact && n >= (int64_t{1} << 22);
-      pa.geom.slices  = static_cast<int32_t>(env_i64("CUDF_AMD_GB_SLICES", will_try_optimistic ? 256 : 512));
+      // (small inputs: one slice per 16K rows - the single-workgroup scan walks slices x P counters)
+      pa.geom.slices  = static_cast<int32_t>(env_i64("CUDF_AMD_GB_SLICES", will_try_optimistic ? 256 : std::clamp<int64_t>(n / 16384, 16, 512)));
       pa.geom.P       = static_cast<int32_t>(P1);
       pa.geom.shift   = 64 - log2P1;
       pa.geom.block   = 1024;
