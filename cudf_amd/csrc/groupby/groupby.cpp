@@ -579,6 +579,16 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   int32_t nitems     = 0;
   double safety      = 1.3;
 
+  // one stream synchronisation returns both the overflow flag and the per-item group counts of an attempt
+  std::vector<int32_t> h_count;
+  auto overflow_and_counts = [&]() -> int32_t {
+    int32_t h_ov = 0;
+    h_count.assign(static_cast<std::size_t>(nitems), 0);
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_ov, d_overflow, 4, hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(h_count.data(), d_count, sizeof(int32_t) * static_cast<std::size_t>(nitems), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    return h_ov;
+  };
   for (int attempt = 0;; ++attempt) {
     CUDF_EXPECTS(attempt < 4, "hash groupby: could not fit the groups into LDS tables (pathological key distribution).");
     CUDF_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, s));
@@ -728,9 +738,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         launch_aggregate(aa, sc.alloc<agg_args>(1), s);
         if (env_i64("CUDF_AMD_DEBUG", 0)) { CUDF_HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[cudf_amd] optimistic aggregate done\n"); }
 
-        int32_t h_ov = 0;
-        CUDF_HIP_TRY(hipMemcpyAsync(&h_ov, d_overflow, 4, hipMemcpyDeviceToHost, s));
-        CUDF_HIP_TRY(hipStreamSynchronize(s));
+        int32_t const h_ov = overflow_and_counts();
         if (env_i64("CUDF_AMD_DEBUG", 0)) fprintf(stderr, "[cudf_amd] optimistic overflow flag = %d\n", h_ov);
         if (h_ov == 0) break;
         // a region overflowed (skewed keys) or a table did: redo with exact offsets; a table overflow is then
@@ -805,9 +813,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           aa.out_count   = d_count;
           aa.nitems      = nitems;
           launch_aggregate(aa, sc.alloc<agg_args>(1), s);
-          int32_t h_ov = 0;
-          CUDF_HIP_TRY(hipMemcpyAsync(&h_ov, d_overflow, 4, hipMemcpyDeviceToHost, s));
-          CUDF_HIP_TRY(hipStreamSynchronize(s));
+          int32_t const h_ov = overflow_and_counts();
           if (env_i64("CUDF_AMD_DEBUG", 0))
             fprintf(stderr, "[cudf_amd] two-level optimistic P1=%ld P2=%ld slices2=%ld cap1=%ld cap2=%ld RU=%d wc=%d/%d overflow=%d\n",
                     (long)P1, (long)P2, (long)slices2, (long)cap1, (long)cap2, RU, pa.wc_granule, pb.wc_granule, h_ov);
@@ -869,10 +875,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       aa.nitems      = nitems;
       launch_aggregate(aa, sc.alloc<agg_args>(1), s);
     }
-    int32_t h_overflow = 0;
-    CUDF_HIP_TRY(hipMemcpyAsync(&h_overflow, d_overflow, 4, hipMemcpyDeviceToHost, s));
-    CUDF_HIP_TRY(hipStreamSynchronize(s));
-    if (h_overflow == 0) break;
+    if (overflow_and_counts() == 0) break;
     // The estimate was too low (skewed sample): ask for 8x more tables and redo.
     est_groups = std::min<double>(static_cast<double>(n), std::max(est_groups, static_cast<double>(ag.fill_limit)) * 8);
     sc.bufs.clear();
@@ -880,9 +883,6 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   }
 
   // ---- group counts -> prefix
-  std::vector<int32_t> h_count(nitems);
-  CUDF_HIP_TRY(hipMemcpyAsync(h_count.data(), d_count, sizeof(int32_t) * nitems, hipMemcpyDeviceToHost, s));
-  CUDF_HIP_TRY(hipStreamSynchronize(s));
   std::vector<int64_t> h_prefix(nitems + 1, 0);
   for (int i = 0; i < nitems; ++i) h_prefix[i + 1] = h_prefix[i] + h_count[i];
   int64_t const G = h_prefix[nitems];
