@@ -488,6 +488,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   std::vector<aggregation_request> const& requests, stream_ref stream, rmm::device_async_resource_ref mr)
 {
   using namespace detail;
+  // keys_are_sorted is a hint with which the reference picks its sort-based path (groupby.cu:64-69); group order is
+  // unspecified either way, so the hash path serves both
+  (void)_keys_are_sorted;
   // reference groupby.cu:225-229
   CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
                            [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
