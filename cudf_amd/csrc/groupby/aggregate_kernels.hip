@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(256) k_finalize(finalize_args const* __restric
 
 // ------------------------------------------------------------------ K_estimate (linear counting on a sample)
 __global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
-                                                  uint32_t* bitmap, int32_t bits_log2)
+                                                  uint32_t* bitmap, int32_t bits_log2, uint32_t* hot_buckets)
 {
   plan_dev const& p = *pp;
   int64_t const i   = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
@@ -702,6 +702,42 @@ __global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ p
   uint64_t const h   = hash_key_units<MAX_KU>(p, key);
   uint32_t const bit = static_cast<uint32_t>(h >> (64 - bits_log2));
   atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+  // heavy-hitter search: rows per hash bucket over every fourth sampled row (scattered global atomics run at 24 G/s:
+  // a quarter of the sample keeps this at ~10 us)
+  if (hot_buckets != nullptr && (i & 3) == 0) atomicAdd(&hot_buckets[h >> 48], 1u);
+}
+// ---- heavy hitters in the sample (plain 8-byte key): bucket counts, exact counts of the keys of crowded buckets, selection
+constexpr uint64_t HOT_SENTINEL = ~uint64_t{0};
+__device__ __forceinline__ bool hot_sample_key(plan_dev const& p, int64_t nrows, int64_t sample, uint64_t& key, uint64_t& h)
+{
+  int64_t const i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) * 4;  // the rows k_estimate counted
+  if (i >= sample) return false;
+  int64_t const row = sample >= nrows ? i : static_cast<int64_t>((static_cast<__int128>(i) * nrows) / sample);
+  key = gload(p.simple_base[0] + row) & p.key_mask[0];
+  h   = mix64(0x9e3779b97f4a7c15ull ^ key);
+  return true;
+}
+__global__ void __launch_bounds__(256) k_hot_any(uint32_t const* buckets, uint32_t min_count, uint32_t* crowded)
+{
+  int const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < HOT_BUCKETS && buckets[i] >= min_count) *crowded = 1;
+}
+__global__ void __launch_bounds__(256) k_hot_collect(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
+                                                     uint32_t const* buckets, uint32_t const* crowded, uint32_t min_count,
+                                                     uint64_t* tkeys, uint32_t* tcounts)
+{
+  if (*crowded == 0) return;  // no bucket reached the threshold: nothing to collect
+  uint64_t key, h;
+  if (!hot_sample_key(*pp, nrows, sample, key, h) || buckets[h >> 48] < min_count || key == HOT_SENTINEL) return;
+  uint32_t slot = static_cast<uint32_t>(h >> 20) & (HOT_TABLE - 1);
+  for (int probe = 0; probe < 64; ++probe) {
+    unsigned long long const cur = atomicCAS(reinterpret_cast<unsigned long long*>(tkeys + slot), HOT_SENTINEL, key);
+    if (cur == HOT_SENTINEL || cur == key) {
+      atomicAdd(&tcounts[slot], 1u);
+      return;
+    }
+    slot = (slot + 1) & (HOT_TABLE - 1);
+  }
 }
 __global__ void __launch_bounds__(256) k_popcount(uint32_t const* bitmap, int64_t nwords, uint32_t* out)
 {
@@ -870,9 +906,27 @@ void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t con
   CUDF_HIP_TRY(hipGetLastError());
 }
 
-void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
-                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, hipStream_t stream)
+void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint32_t min_count, uint32_t* buckets,
+                     uint64_t* table_keys, uint32_t* table_counts, hipStream_t stream)
 {
+  // table_counts holds HOT_TABLE counters followed by the one-word "some bucket is crowded" flag
+  CUDF_HIP_TRY(hipMemsetAsync(table_counts, 0, (HOT_TABLE + 1) * sizeof(uint32_t), stream));
+  CUDF_HIP_TRY(hipMemsetAsync(table_keys, 0xff, HOT_TABLE * sizeof(uint64_t), stream));
+  uint32_t* crowded   = table_counts + HOT_TABLE;
+  unsigned const grid = static_cast<unsigned>(((sample + 3) / 4 + 255) / 256);
+  cudf::detail::prof::scope prof_{"estimate", stream};
+  hipLaunchKernelGGL(k_hot_any, dim3(HOT_BUCKETS / 256), dim3(256), 0, stream, buckets, min_count, crowded);
+  // a bucket holds sample / 4 / 65536 counted keys on average (4 of a 1M-row sample): only crowded ones can hide a
+  // heavy hitter, and their keys are counted exactly
+  hipLaunchKernelGGL(k_hot_collect, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, buckets, crowded, min_count, table_keys,
+                     table_counts);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
+                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream)
+{
+  if (hot_buckets != nullptr) CUDF_HIP_TRY(hipMemsetAsync(hot_buckets, 0, HOT_BUCKETS * sizeof(uint32_t), stream));
   int64_t const nwords = (int64_t{1} << bitmap_bits_log2) / 32;
   CUDF_HIP_TRY(hipMemsetAsync(bitmap, 0, nwords * 4, stream));
   CUDF_HIP_TRY(hipMemsetAsync(d_bits_set, 0, 4, stream));
@@ -880,7 +934,7 @@ void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int6
   hipLaunchKernelGGL(k_store_args<plan_dev>, dim3(1), dim3(1), 0, stream, plan, d_plan);
   cudf::detail::prof::scope prof_{"estimate", stream};
   hipLaunchKernelGGL(k_estimate, dim3(static_cast<unsigned>((sample + block - 1) / block)), dim3(block), 0, stream, d_plan,
-                     nrows, sample, bitmap, bitmap_bits_log2);
+                     nrows, sample, bitmap, bitmap_bits_log2, hot_buckets);
   hipLaunchKernelGGL(k_popcount, dim3(256), dim3(block), 0, stream, bitmap, nwords, d_bits_set);
   CUDF_HIP_TRY(hipGetLastError());
 }

@@ -206,6 +206,15 @@ struct part_args {
   // Write-combining scatter (optimistic, 16-byte records): records per output granule (4 = 64 B, 8 = 128 B); every
   // global store of the tile loop is a whole, aligned granule; 0 = classic run-per-tile scatter.
   int32_t wc_granule;
+  // Heavy hitters (write-combining scatter of plain 16-byte records only): rows whose key is one of hot_keys[0..hot_n)
+  // are aggregated (SUM of the value, row COUNT) in an LDS table of HOT_SLOTS entries placed hot_lds_offset bytes into
+  // the workgroup's LDS instead of being scattered; workgroup w writes its non-empty entries as partial records to
+  // hot_out[w * HOT_SLOTS ...] and their number to hot_count[w].
+  int32_t hot_n;
+  int32_t hot_lds_offset;
+  uint64_t const* hot_keys;
+  uint64_t* hot_out;
+  int32_t* hot_count;
   // diagnostics (CUDF_AMD_GB_STAMPS=1): per-workgroup cycle totals of the tile phases, 8 x u64 per workgroup
   unsigned long long* stamps;
 };
@@ -229,7 +238,14 @@ void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t con
                      int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream);
 // Distinct-count estimate on a strided sample (linear counting into a bitmap); result written to *d_bits.
 void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
-                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, hipStream_t stream);
+                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream);
+
+// Heavy hitters of a plain 8-byte key column, from the same strided sample as the estimate: sample counts per hash bucket
+// (HOT_BUCKETS counters, filled by launch_estimate's pass over the sample), then exact sample counts of the keys of the buckets with at least `min_count` rows, in an
+// open-addressing table of HOT_TABLE (key, count) entries (empty key = all ones) that the host reads back and sorts.
+constexpr int HOT_BUCKETS = 65536, HOT_TABLE = 4096, HOT_MAX_KEYS = 256, HOT_SLOTS = 512;
+void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint32_t min_count, uint32_t* buckets,
+                     uint64_t* table_keys, uint32_t* table_counts, hipStream_t stream);
 
 std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g);
 // LDS bytes of one table slot: key units, accumulators (4 bytes for counts), state word
@@ -237,5 +253,7 @@ int aggregate_slot_bytes(plan_dev const& plan);
 std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g);
 // write-combining scatter: can records of U units be partitioned P ways with granules of G records?
 bool partition_wc_fits(int U, int P, int G);
+// LDS bytes of the heavy-hitter table; byte offset of it behind the write-combining scatter's own LDS
+std::size_t partition_hot_lds_bytes();
 
 }  // namespace cudf::groupby::detail

@@ -5,6 +5,7 @@
 // cpp/src/groupby/hash/groupby.cu:33-147 (hash dispatch), extract_single_pass_aggs.cpp:26-177 (flattening),
 // output_utils.cu:49-224 (result columns), hash_compound_agg_finalizer.cu:92-133 (MEAN).
 #include "engine.hpp"
+#include "../common/wc_scatter.hpp"
 
 #include <cudf/groupby.hpp>
 #include <cudf/null_mask.hpp>
@@ -461,6 +462,19 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
   return hp;
 }
 
+// Heavy-hitter handling covers plans whose accumulators are SUMs of the single value column and row COUNTs (no nulls).
+bool hot_plan_ok(plan_dev const& p)
+{
+  if (p.NACC < 1 || p.NACC > 2 || p.narg != 0) return false;
+  for (int q = 0; q < p.NACC; ++q) {
+    auto const& a = p.acc[q];
+    bool const sum = (a.op == ADD_F64 || a.op == ADD_I64) && a.src == SRC_VALUE && a.pay == 0 && a.valid_bit < 0;
+    bool const cnt = a.op == ADD_I64 && a.src == SRC_ONE;
+    if (!sum && !cnt) return false;
+  }
+  return true;
+}
+
 struct scratch {  // stream-ordered temporaries from the current device resource
   hipStream_t stream;
   rmm::device_async_resource_ref mr;
@@ -542,6 +556,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   scratch sc{s, tmp_mr, {}};
   int32_t* d_overflow = sc.alloc<int32_t>(1);
 
+  std::vector<uint64_t> hot_keys;  // heavy hitters found in the sample (aggregated inside the scatter workgroups)
   // ---- distinct-count estimate on a strided sample (skipped when n already fits one table)
   double est_groups = static_cast<double>(n);
   if (n > ag.fill_limit) {
@@ -551,10 +566,42 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     int const bits_log2  = 24;
     uint32_t* bitmap     = sc.alloc<uint32_t>((size_t{1} << bits_log2) / 32);
     uint32_t* d_set      = sc.alloc<uint32_t>(1);
-    launch_estimate(p, sc.alloc<plan_dev>(1), n, sample, bitmap, bits_log2, d_set, s);
+    plan_dev* d_plan = sc.alloc<plan_dev>(1);
+    bool const hot_eligible = p.simple && RU == 2 && p.KU == 1 && hot_plan_ok(p) && n >= (int64_t{1} << 22) &&
+                              env_i64("CUDF_AMD_GB_HOT", 1) != 0;
+    uint32_t* hot_buckets = hot_eligible ? sc.alloc<uint32_t>(HOT_BUCKETS) : nullptr;
+    launch_estimate(p, d_plan, n, sample, bitmap, bits_log2, d_set, hot_buckets, s);
+    // Heavy hitters (plain int64 key + one plain value, SUM / COUNT): a key above ~0.05 % of the rows overflows its
+    // regions of the optimistic partition, and a key with percents of the rows leaves one workgroup aggregating its
+    // partition alone. Keys seen min_count times in the sample are aggregated inside the scatter workgroups instead.
+    std::vector<uint64_t> h_tkeys;
+    std::vector<uint32_t> h_tcounts;
+    // (a key overflows its regions from about 0.24 / P of the rows: 0.023 % at P = 1024; the threshold is half of that)
+    uint32_t const hot_min_count = static_cast<uint32_t>(std::max<int64_t>(16, sample / 4 / 8192));  // of every 4th sampled row
+    if (hot_eligible) {
+      uint32_t* buckets = hot_buckets;
+      uint64_t* tkeys   = sc.alloc<uint64_t>(HOT_TABLE);
+      uint32_t* tcounts = sc.alloc<uint32_t>(HOT_TABLE + 1);
+      launch_hot_keys(d_plan, n, sample, hot_min_count, buckets, tkeys, tcounts, s);
+      h_tkeys.resize(HOT_TABLE);
+      h_tcounts.resize(HOT_TABLE);
+      CUDF_HIP_TRY(hipMemcpyAsync(h_tkeys.data(), tkeys, HOT_TABLE * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipMemcpyAsync(h_tcounts.data(), tcounts, HOT_TABLE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
     uint32_t h_set = 0;
     CUDF_HIP_TRY(hipMemcpyAsync(&h_set, d_set, 4, hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipStreamSynchronize(s));
+    if (hot_eligible) {  // the most frequent keys first, at most HOT_MAX_KEYS of them
+      std::vector<std::pair<uint32_t, uint64_t>> cand;
+      for (int i = 0; i < HOT_TABLE; ++i)
+        if (h_tkeys[i] != ~uint64_t{0} && h_tcounts[i] >= hot_min_count) cand.emplace_back(h_tcounts[i], h_tkeys[i]);
+      std::sort(cand.begin(), cand.end(), [](auto const& a, auto const& b) { return a.first > b.first; });
+      if (cand.size() > HOT_MAX_KEYS) cand.resize(HOT_MAX_KEYS);
+      for (auto const& c : cand) hot_keys.push_back(c.second);
+      if (env_i64("CUDF_AMD_DEBUG", 0))
+        fprintf(stderr, "[cudf_amd] heavy hitters: %zu keys (most frequent: %u of %ld counted rows)\n", hot_keys.size(),
+                cand.empty() ? 0u : cand[0].first, (long)(sample / 4));
+    }
     double const m  = std::ldexp(1.0, bits_log2);
     double const ds = h_set >= m ? m * 20 : -m * std::log(1.0 - h_set / m);  // distinct keys in the sample
     // population estimate under uniform frequencies: solve G (1 - exp(-S/G)) = ds
@@ -711,6 +758,19 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         // 16-byte records: write-combining scatter (whole aligned granules only); 64-byte granules at P = 1024
         // (the carry area of 128-byte granules would not leave room for a tile), 128-byte granules at P <= 512
         pa.wc_granule = wc_granule_for(P1);
+        // heavy hitters stay in the scatter workgroups (one more work item, P1, holds their merged partials)
+        bool const hot = !hot_keys.empty() && pa.wc_granule != 0 && p.simple && RU == 2 &&
+                         cudf::detail::wc_scatter_lds_bytes(5 * 1024, static_cast<std::size_t>(P1), pa.wc_granule, 2) +
+                             partition_hot_lds_bytes() + 1200 <= 160 * 1024;  // (the LDS table needs room next to the tile)
+        if (hot) {
+          uint64_t* d_hot = sc.alloc<uint64_t>(HOT_MAX_KEYS);
+          CUDF_HIP_TRY(hipMemcpyAsync(d_hot, hot_keys.data(), hot_keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+          pa.hot_n          = static_cast<int32_t>(hot_keys.size());
+          pa.hot_keys       = d_hot;
+          pa.hot_lds_offset = static_cast<int32_t>(cudf::detail::wc_scatter_lds_bytes(5 * 1024, static_cast<std::size_t>(P1), pa.wc_granule, 2));
+          pa.hot_out        = sc.alloc<uint64_t>(items1 * HOT_SLOTS * PU);
+          pa.hot_count      = sc.alloc<int32_t>(items1);
+        }
         if (env_i64("CUDF_AMD_GB_STAMPS", 0)) pa.stamps = sc.alloc<unsigned long long>(items1 * 8);
         store_args(pa, d_pa, s);
         launch_partition_scatter(pa, d_pa, s);
@@ -726,8 +786,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         }
         if (env_i64("CUDF_AMD_DEBUG", 0)) { CUDF_HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[cudf_amd] optimistic scatter done capR=%ld P=%ld slices=%zu\n", (long)capR, (long)P1, items1); }
         nitems         = static_cast<int32_t>(P1);
-        partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);
-        d_count        = sc.alloc<int32_t>(nitems);
+        partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems + 1) * ag.cap * PU);
+        d_count        = sc.alloc<int32_t>(nitems + 1);
         aa.input       = IN_RAW_RECORDS;
         aa.seg         = SEG_STRIDED;
         aa.records     = recA;
@@ -739,6 +799,20 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         aa.out_count   = d_count;
         aa.nitems      = nitems;
         launch_aggregate(aa, sc.alloc<agg_args>(1), s);
+        if (hot) {  // merge the workgroups' heavy-hitter partials into work item P1
+          agg_args hm    = aa;
+          hm.input       = IN_PARTIAL_RECORDS;
+          hm.records     = pa.hot_out;
+          hm.src_count   = pa.hot_count;
+          hm.src_stride  = HOT_SLOTS;
+          hm.fan         = static_cast<int32_t>(items1);
+          hm.nsrc        = static_cast<int32_t>(items1);
+          hm.out_records = partial + static_cast<size_t>(nitems) * ag.cap * PU;
+          hm.out_count   = d_count + nitems;
+          hm.nitems      = 1;
+          launch_aggregate(hm, sc.alloc<agg_args>(1), s);
+          nitems += 1;
+        }
         if (env_i64("CUDF_AMD_DEBUG", 0)) { CUDF_HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[cudf_amd] optimistic aggregate done\n"); }
 
         int32_t const h_ov = overflow_and_counts();

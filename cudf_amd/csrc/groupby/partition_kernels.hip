@@ -386,13 +386,37 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
 constexpr int WC_SRC_SIMPLE = 0;   // plain 8-byte columns
 constexpr int WC_SRC_COLUMNS = 1;  // any fixed-width columns, nulls (records built column-at-a-time)
 constexpr int WC_SRC_RECORDS = 2;  // records: one contiguous range, or a strided list of level-1 regions
-template <int UT, int RPT, int G, int SRC>
+// HOT: heavy-hitter keys (part_args::hot_*) are aggregated in a small LDS table and never scattered.
+template <int UT, int RPT, int G, int SRC, bool HOT = false>
 __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   part_args const& a = *ap;
   plan_dev const& p  = a.plan;
   int const shift = a.geom.shift, B = blockDim.x;
+  static_assert(!HOT || (UT == 2 && SRC == WC_SRC_SIMPLE), "heavy hitters: plain 16-byte records");
+  constexpr uint64_t HOT_EMPTY = ~uint64_t{0};
+  uint64_t* hkeys = reinterpret_cast<uint64_t*>(lds_raw + (HOT ? a.hot_lds_offset : 0));  // [HOT_SLOTS]
+  uint64_t* hsum  = hkeys + HOT_SLOTS;
+  uint32_t* hcnt  = reinterpret_cast<uint32_t*>(hsum + HOT_SLOTS);
+  __shared__ uint32_t s_hot_dumped;
+  bool hot_float = false;
+  if constexpr (HOT) {
+    for (int q = 0; q < p.NACC; ++q) hot_float = hot_float || p.acc[q].op == ADD_F64;
+    for (int t = threadIdx.x; t < HOT_SLOTS; t += B) {
+      hkeys[t] = HOT_EMPTY;
+      hsum[t]  = 0;
+      hcnt[t]  = 0;
+    }
+    if (threadIdx.x == 0) s_hot_dumped = 0;
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < a.hot_n) {
+      uint64_t const key = a.hot_keys[threadIdx.x];
+      uint32_t slot      = static_cast<uint32_t>(mix64(0x9e3779b97f4a7c15ull ^ key) >> 20) & (HOT_SLOTS - 1);
+      while (atomicCAS(reinterpret_cast<unsigned long long*>(hkeys + slot), HOT_EMPTY, key) != HOT_EMPTY) slot = (slot + 1) & (HOT_SLOTS - 1);
+    }
+    __syncthreads();
+  }
   __shared__ int32_t s_pre[MAX_REGION_LIST + 1];
   constexpr bool SIMPLE = SRC == WC_SRC_SIMPLE;
   region_input rin{};
@@ -438,6 +462,22 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
         if constexpr (SIMPLE) {
 #pragma unroll
           for (int u = 0; u < UT; ++u) rec[k][u] = gload(sbase[u] + r);
+          if constexpr (HOT) {  // a heavy hitter is accumulated here and leaves the scatter
+            uint64_t const key = rec[k][0] & kmask[0];
+            uint32_t slot      = static_cast<uint32_t>(mix64(0x9e3779b97f4a7c15ull ^ key) >> 20) & (HOT_SLOTS - 1);
+            for (;;) {
+              uint64_t const kk = hkeys[slot];
+              if (kk == key) {
+                if (hot_float) atomicAdd(reinterpret_cast<double*>(hsum + slot), __longlong_as_double(static_cast<long long>(rec[k][1])));
+                else atomicAdd(reinterpret_cast<unsigned long long*>(hsum + slot), static_cast<unsigned long long>(rec[k][1]));
+                atomicAdd(hcnt + slot, 1u);
+                keep[k] = false;
+                break;
+              }
+              if (kk == HOT_EMPTY) break;
+              slot = (slot + 1) & (HOT_SLOTS - 1);
+            }
+          }
         } else {
           int64_t const ri = from_regions ? rin.record_of(r) : r;
           if constexpr (UT == 2) {
@@ -474,6 +514,20 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   g.overflow     = a.overflow;
   g.out          = a.out_records + region0 * a.region_cap * UT;
   cudf::detail::wc_scatter_slice<RPT, G, UT, SRC != WC_SRC_COLUMNS>(lds_raw, g, load_tile, digit_of);
+  if constexpr (HOT) {  // this workgroup's heavy-hitter partials: [key | accumulators in plan order]
+    __syncthreads();
+    int const PU   = p.KU + p.NACC;
+    uint64_t* out  = a.hot_out + static_cast<int64_t>(blockIdx.x) * HOT_SLOTS * PU;
+    for (int t = threadIdx.x; t < HOT_SLOTS; t += B) {
+      if (hcnt[t] == 0) continue;
+      uint32_t const pos = atomicAdd(&s_hot_dumped, 1u);
+      gstore(out + static_cast<int64_t>(pos) * PU, hkeys[t]);
+      for (int q = 0; q < p.NACC; ++q)
+        gstore(out + static_cast<int64_t>(pos) * PU + 1 + q, p.acc[q].src == SRC_VALUE ? hsum[t] : static_cast<uint64_t>(hcnt[t]));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.hot_count[blockIdx.x] = static_cast<int32_t>(s_hot_dumped);
+  }
 }
 
 }  // namespace
@@ -541,20 +595,22 @@ bool partition_wc_fits(int U, int P, int G)
   return cudf::detail::wc_scatter_lds_bytes(static_cast<std::size_t>(1024) * rpt, P, G, U) + 1200 <= 160 * 1024;
 }
 
-template <int UT, int RPT, int G, int SRC>
+std::size_t partition_hot_lds_bytes() { return static_cast<std::size_t>(HOT_SLOTS) * (8 + 8 + 4); }
+
+template <int UT, int RPT, int G, int SRC, bool HOT = false>
 static void launch_scatter_wc_src(part_args const& a, part_args const* d_args, hipStream_t stream)
 {
   part_geom g  = a.geom;
   g.tile_rows  = g.block * RPT;
-  auto const lds = cudf::detail::wc_scatter_lds_bytes(g.tile_rows, g.P, G, UT);
+  auto const lds = cudf::detail::wc_scatter_lds_bytes(g.tile_rows, g.P, G, UT) + (HOT ? partition_hot_lds_bytes() : 0);
   CUDF_EXPECTS(lds + 1200 <= 160 * 1024, "write-combining partition kernel: LDS budget exceeded");
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SRC>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SRC, HOT>));
     attr_set = true;
   }
   cudf::detail::prof::scope prof_{"partition_scatter", stream};
-  hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SRC>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args);
+  hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SRC, HOT>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
@@ -562,6 +618,9 @@ template <int UT, int RPT, int G>
 static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hipStream_t stream)
 {
   if (!a.from_columns) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_RECORDS>(a, d_args, stream);
+  if constexpr (UT == 2) {
+    if (a.plan.simple && a.hot_n > 0) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE, true>(a, d_args, stream);
+  }
   if (a.plan.simple) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE>(a, d_args, stream);
   return launch_scatter_wc_src<UT, RPT, G, WC_SRC_COLUMNS>(a, d_args, stream);
 }

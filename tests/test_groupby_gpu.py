@@ -417,3 +417,20 @@ def test_fuzz_against_oracle(G, oracle, seed, monkeypatch):
             # results and the cancelling M2/variance/std formulas carry rounding
             loose = kind in ("variance", "std", "m2", "product", "mean") or (is_f and vals.data.dtype == np.float32)
             kat.compare_columns(a, e, f"{kind}({vals.type_name if hasattr(vals, 'type_name') else ''})", atol=1e-6 * max(1, n) if loose else 0.0)
+
+
+@pytest.mark.parametrize("vt", ["float64", "int64"])
+@pytest.mark.parametrize("hot_fraction", [0.01, 0.3, 0.9])
+def test_heavy_hitters(G, oracle, vt, hot_fraction):
+    """A few keys carry a large share of the rows: they are found in the sample and aggregated inside the scatter
+    workgroups (an LDS table) instead of overflowing their regions / being aggregated by one workgroup. SUM, COUNT and
+    MEAN must still be exact (integers) or within the usual float bound; the remaining keys are untouched."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(51)
+    n = 6_000_000
+    k = rng.integers(0, 900_000, n, dtype=np.int64) * 31 + 7
+    hot = rng.random(n) < hot_fraction
+    k[hot] = rng.integers(0, 12, int(hot.sum())) * 1_000_003 - 5  # 12 hot keys outside the cold range, one negative
+    npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
+    v = rng.random(n).astype(npt) if vt == "float64" else rng.integers(-1000, 1000, n).astype(npt)
+    _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), ["sum", "count_valid", "mean"])], expect_path="PARTITIONED_LDS")
