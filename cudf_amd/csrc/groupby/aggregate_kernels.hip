@@ -701,10 +701,23 @@ __global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ p
   if (!build_key_units<MAX_KU, false>(p, row, key, vv)) return;
   uint64_t const h   = hash_key_units<MAX_KU>(p, key);
   uint32_t const bit = static_cast<uint32_t>(h >> (64 - bits_log2));
-  atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+  // (same-address global atomics serialise - a constant key column made this pass take 16 ms: set a bit only if it is
+  // not seen set, and add to a bucket counter once per distinct bucket of the wave)
+  if (!((gload(bitmap + (bit >> 5)) >> (bit & 31)) & 1u)) atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
   // heavy-hitter search: rows per hash bucket over every fourth sampled row (scattered global atomics run at 24 G/s:
   // a quarter of the sample keeps this at ~10 us)
-  if (hot_buckets != nullptr && (i & 3) == 0) atomicAdd(&hot_buckets[h >> 48], 1u);
+  bool pending = hot_buckets != nullptr && (i & 3) == 0;
+  uint32_t const bucket = static_cast<uint32_t>(h >> 48);
+  for (int round = 0; round < 8; ++round) {  // wave-aggregated: one atomic per distinct bucket, for the first 8 of them
+    unsigned long long const todo = __ballot(pending);
+    if (todo == 0) break;
+    int const lead            = __ffsll(static_cast<long long>(todo)) - 1;
+    uint32_t const lead_bkt   = __shfl(bucket, lead);
+    unsigned long long const same = __ballot(pending && bucket == lead_bkt);
+    if ((threadIdx.x & 63) == lead) atomicAdd(&hot_buckets[lead_bkt], static_cast<uint32_t>(__popcll(same)));
+    if (bucket == lead_bkt) pending = false;
+  }
+  if (pending) atomicAdd(&hot_buckets[bucket], 1u);
 }
 // ---- heavy hitters in the sample (plain 8-byte key): bucket counts, exact counts of the keys of crowded buckets, selection
 constexpr uint64_t HOT_SENTINEL = ~uint64_t{0};
@@ -727,18 +740,33 @@ __global__ void __launch_bounds__(256) k_hot_collect(plan_dev const* __restrict_
                                                      uint64_t* tkeys, uint32_t* tcounts)
 {
   if (*crowded == 0) return;  // no bucket reached the threshold: nothing to collect
-  uint64_t key, h;
-  if (!hot_sample_key(*pp, nrows, sample, key, h) || buckets[h >> 48] < min_count || key == HOT_SENTINEL) return;
-  uint32_t slot = static_cast<uint32_t>(h >> 20) & (HOT_TABLE - 1);
+  uint64_t key = 0, h = 0;
+  bool pending = hot_sample_key(*pp, nrows, sample, key, h) && buckets[h >> 48] >= min_count && key != HOT_SENTINEL;
+  uint32_t mine = 1;  // rows this lane inserts for (wave-aggregated: the first lane of each distinct key of the wave)
+  for (int round = 0; round < 8; ++round) {
+    unsigned long long const todo = __ballot(pending && mine == 1);
+    if (todo == 0) break;
+    int const lead          = __ffsll(static_cast<long long>(todo)) - 1;
+    uint64_t const lead_key = __shfl(static_cast<unsigned long long>(key), lead);
+    unsigned long long const same = __ballot(pending && mine == 1 && key == lead_key);
+    if (pending && mine == 1 && key == lead_key) {
+      if (static_cast<int>(threadIdx.x & 63) == lead) mine = static_cast<uint32_t>(__popcll(same)) + 1;  // +1: marks "leader"
+      else pending = false;
+    }
+  }
+  if (!pending) return;
+  uint32_t const add = mine > 1 ? mine - 1 : 1;
+  uint32_t slot      = static_cast<uint32_t>(h >> 20) & (HOT_TABLE - 1);
   for (int probe = 0; probe < 64; ++probe) {
     unsigned long long const cur = atomicCAS(reinterpret_cast<unsigned long long*>(tkeys + slot), HOT_SENTINEL, key);
     if (cur == HOT_SENTINEL || cur == key) {
-      atomicAdd(&tcounts[slot], 1u);
+      atomicAdd(&tcounts[slot], add);
       return;
     }
     slot = (slot + 1) & (HOT_TABLE - 1);
   }
 }
+
 __global__ void __launch_bounds__(256) k_popcount(uint32_t const* bitmap, int64_t nwords, uint32_t* out)
 {
   int64_t i     = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
