@@ -35,7 +35,8 @@ struct wc_scatter_geom {
   int P;                  // partitions (<= 2 * blockDim.x)
   int slices;             // workgroups sharing the output (region index = d * slices + item)
   int item;               // this workgroup
-  int64_t begin, end;     // input rows of this workgroup
+  int64_t begin, end;     // input rows of this workgroup: tiles at begin, begin + step, ... below end
+  int64_t step;           // 0 = consecutive tiles (a contiguous slice); else the distance between this workgroup's tiles
   int64_t region_cap;     // records per region (multiple of 8)
   int32_t* region_count;  // [P * slices]
   int32_t* overflow;
@@ -89,7 +90,8 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
   if constexpr (PEEL) {
     if (g.begin < g.end) load_tile(g.begin, rec, keep);
   }
-  for (int64_t tile = PEEL ? g.begin : g.begin - T; tile < g.end; tile += T) {
+  int64_t const step = g.step > 0 ? g.step : T;
+  for (int64_t tile = PEEL ? g.begin : g.begin - step; tile < g.end; tile += step) {
     bool const cur = PEEL || tile >= g.begin;  // a tile sits in the registers
     uint32_t tot[MAXE], wr[MAXE], sofs[MAXE], total_gr = 0;
     if (cur) {
@@ -168,7 +170,7 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
     }
     }
     // the registers are free: the next tile's loads fly under the write-out
-    if (tile + T < g.end) load_tile(tile + T, rec, keep);
+    if (tile + step < g.end) load_tile(tile + step, rec, keep);
     if (!cur) continue;
     wc_lds_barrier();
     // write-out in 16-byte chunks; sequence index q < carry count comes from the carry area, the rest from the stage

@@ -56,6 +56,27 @@ __device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
   }
 }
 
+// a (op) b on accumulator bit patterns - the wave-level counterpart of lds_merge (float min / max: a NaN never beats a
+// number, as ds_min_f64 / ds_max_f64)
+__device__ __forceinline__ uint64_t combine_values(int op, uint64_t a, uint64_t b)
+{
+  auto f = [](uint64_t x) { return __longlong_as_double(static_cast<long long>(x)); };
+  auto u = [](double x) { return static_cast<uint64_t>(__double_as_longlong(x)); };
+  switch (op) {
+    case ADD_I64: return a + b;
+    case ADD_F64: return u(f(a) + f(b));
+    case MIN_I64: return static_cast<uint64_t>(min(static_cast<long long>(a), static_cast<long long>(b)));
+    case MIN_U64: return min(a, b);
+    case MAX_I64: return static_cast<uint64_t>(max(static_cast<long long>(a), static_cast<long long>(b)));
+    case MAX_U64: return max(a, b);
+    case MIN_F64: return u(fmin(f(a), f(b)));
+    case MAX_F64: return u(fmax(f(a), f(b)));
+    case MUL_I64: return a * b;
+    case MUL_F64: return u(f(a) * f(b));
+    default: return a;  // ANY_U64
+  }
+}
+
 // The LDS table is an open-addressing table probed in aligned BUCKETS of four slots: the four state words of a
 // bucket are one ds_read_b128, a tag match names the one slot whose key words are worth reading, and slots of a
 // bucket are claimed in order (occupied slots form a prefix; a key moves on to the next bucket only when its bucket
@@ -106,6 +127,8 @@ __device__ __forceinline__ int lds_find_or_insert(int KU, uint64_t const (&kmask
       if (eq) return slot;
     }
     slot = slot + 1 == cap ? 0 : slot + 1;
+    // the attempt is void once the table has overflowed: do not walk a saturated table to its end for every row
+    if ((probes & 31) == 31 && __hip_atomic_load(overflow_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return -1;
   }
   *overflow_flag = 1;
   return -1;
@@ -225,6 +248,28 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
   int const flags_unit = p.flags_unit, flags_hi = p.flags_hi;
   uint64_t const* records = a.records;
 
+  // payload unit of accumulator q for row r (prefetched record units, a plain / generic column, or the record in HBM)
+  auto payload_of = [&](int q, int64_t r, uint64_t const (&pay)[PAYT > 0 ? PAYT : 1]) -> uint64_t {
+    uint64_t value = 0;
+    if constexpr (PAYT > 0) {
+#pragma unroll
+      for (int w = 0; w < PAYT; ++w)
+        if (acc_pay[q] == w) value = pay[w];
+    } else if constexpr (INPUT == IN_COLUMNS) {
+      if constexpr (SIMPLE) value = gload(p.simple_base[KU + acc_pay[q]] + r);
+      else value = col_load_acc_bits(p.cols[p.nkeycols + acc_pay[q]], r);
+    } else {
+      value = gload(records + r * U + KU + acc_pay[q]);
+    }
+    return value;
+  };
+  auto squared = [](int op, uint64_t v) -> uint64_t {
+    if (op == ADD_F64) {
+      double const x = __longlong_as_double(static_cast<long long>(v));
+      return static_cast<uint64_t>(__double_as_longlong(x * x));
+    }
+    return v * v;
+  };
   // accumulators of one row whose LDS slot is known
   auto accumulate = [&](int64_t r, int slot, uint64_t const (&pay)[PAYT > 0 ? PAYT : 1], uint32_t valvalid) {
     int last_pay   = -1;
@@ -252,29 +297,41 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
           continue;
         }
         if (acc_pay[q] != last_pay) {
-          if constexpr (PAYT > 0) {
-#pragma unroll
-            for (int w = 0; w < PAYT; ++w)
-              if (acc_pay[q] == w) value = pay[w];
-          } else if constexpr (INPUT == IN_COLUMNS) {
-            if constexpr (SIMPLE) value = gload(p.simple_base[KU + acc_pay[q]] + r);
-            else value = col_load_acc_bits(p.cols[p.nkeycols + acc_pay[q]], r);
-          } else {
-            value = gload(records + r * U + KU + acc_pay[q]);
-          }
+          value    = payload_of(q, r, pay);
           last_pay = acc_pay[q];
         }
-        uint64_t v = value;
-        if (acc_src[q] == SRC_SQUARE) {
-          if (acc_op[q] == ADD_F64) {
-            double const x = __longlong_as_double(static_cast<long long>(v));
-            v              = static_cast<uint64_t>(__double_as_longlong(x * x));
-          } else {
-            v = v * v;
-          }
-        }
-        lds_merge(tgt, acc_op[q], v);
+        lds_merge(tgt, acc_op[q], acc_src[q] == SRC_SQUARE ? squared(acc_op[q], value) : value);
       }
+    }
+  };
+  // Wave-combined accumulate (raw rows): the lanes in `mine` all found the SAME slot. Same-address LDS atomics serialise
+  // (a key with percents of the rows kept one workgroup busy for 17 ms per 12M rows); here each accumulator is reduced
+  // across the wave (6 exchange steps) and lane `leader` issues one atomic.
+  auto accumulate_wave = [&](int64_t r, int slot, bool mine, bool leader, uint64_t const (&pay)[PAYT > 0 ? PAYT : 1], uint32_t valvalid) {
+#pragma unroll
+    for (int q = 0; q < NACCT; ++q) {
+      if (q >= NACC) break;
+      if (acc_src[q] >= SRC_ARG_IDX) continue;
+      bool const valid = mine && (acc_src[q] == SRC_ONE || acc_vbit[q] < 0 || ((valvalid >> acc_vbit[q]) & 1u));
+      unsigned long long const vm = __ballot(valid);
+      if (vm == 0) continue;  // (wave-uniform)
+      if (acc_narrow[q]) {
+        if (leader) atomicAdd(acc32(q) + slot, static_cast<uint32_t>(__popcll(vm)));
+        continue;
+      }
+      uint64_t v = acc_identity(acc_op[q]);
+      if (valid) {
+        uint64_t const value = payload_of(q, r, pay);
+        v                    = acc_src[q] == SRC_SQUARE ? squared(acc_op[q], value) : value;
+      }
+      if (acc_op[q] == ANY_U64) {  // any contributing row will do: the first valid lane's
+        v = static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(v), __ffsll(static_cast<long long>(vm)) - 1));
+      } else {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+          v = combine_values(acc_op[q], v, static_cast<uint64_t>(__shfl_xor(static_cast<unsigned long long>(v), off)));
+      }
+      if (leader) lds_merge(acc64(q) + slot, acc_op[q], v);
     }
   };
   auto hash_of = [&](uint64_t const (&key)[KUT]) {
@@ -354,9 +411,10 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   // Bucketed probe of R rows per lane together: per round, the four state words of each pending row's bucket (one
   // ds_read_b128 each, issued back to back), then the key words of the slot whose tag matches, then the verdict.
+  bool dead = false;  // this workgroup's table overflowed: the call will be redone, stop working on it
   auto probe_batch = [&](uint64_t const (&key)[R][KUT], uint64_t const (&h)[R], int (&bkt)[R], int (&sl)[R], uint32_t pend) {
     int const nbkt = cap >> 2;
-      int guard = 0;
+    int guard      = 0;
     while (pend != 0) {
       asm volatile("" ::: "memory");  // the state words change under us: read them again every round
       u32x4 sw[R];
@@ -410,15 +468,24 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
         }
         // lost the race (possibly to an earlier row of this lane): read the bucket again
       }
-      if (++guard > cap + 64) {  // saturated table
-        s_overflow = 1;
-        pend       = 0;
+      // A saturated table would cost every batch `cap` rounds (seconds per call when a skewed sample under-sized the
+      // tables): once the overflow flag is up the attempt is void, so the workgroup stops probing altogether.
+      if (++guard > 24) {
+        if (__hip_atomic_load(&s_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+          pend = 0;
+          dead = true;
+        } else if (guard > cap + 64) {  // saturated table
+          s_overflow = 1;
+          pend       = 0;
+          dead       = true;
+        }
       }
     }
   };
   // few long sources (the regions of a second partition level): every wave works on every source
   bool const multi = a.seg == SEG_STRIDED && nsrc >= nwaves;
   for (int sidx = multi ? wave : 0; sidx < nsrc; sidx += multi ? nwaves : 1) {
+    if (dead || __hip_atomic_load(&s_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;
     int64_t begin, end;
     if (a.seg == SEG_ROW_CHUNKS) {
       begin = static_cast<int64_t>(item) * a.chunk;
@@ -502,10 +569,36 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
         if (keep[k]) pend |= 1u << k;
       }
       probe_batch(key, h, bkt, sl, pend);
+      if (dead) break;
+      // Most of the wave on ONE slot (a heavy key, sorted or clustered rows, very few groups): reduce across the wave
+      // and issue one atomic per accumulator. Ordinary data pays one readfirstlane + ballot per 256 rows: the batch's
+      // first row set decides whether the other sets are looked at.
+      bool crowded = false;
+      if constexpr (INPUT != IN_PARTIAL_RECORDS) {
+        int const first = __builtin_amdgcn_readfirstlane(sl[0]);
+        crowded         = __popcll(__ballot(keep[0] && sl[0] == first && first >= 0)) >= 32;
+      }
+      if (!crowded) {
 #pragma unroll
-      for (int k = 0; k < R; ++k)
-        if (keep[k] && sl[k] >= 0) accumulate(base + k * 64 + lane, sl[k], pay[k], valvalid[k]);
+        for (int k = 0; k < R; ++k)
+          if (keep[k] && sl[k] >= 0) accumulate(base + k * 64 + lane, sl[k], pay[k], valvalid[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          bool const act                = keep[k] && sl[k] >= 0;
+          unsigned long long const am   = __ballot(act);
+          if (am == 0) continue;
+          int const lead_slot           = __shfl(sl[k], __ffsll(static_cast<long long>(am)) - 1);
+          bool const mine               = act && sl[k] == lead_slot;
+          unsigned long long const same = __ballot(mine);
+          bool const wave_path          = __popcll(same) >= 16;
+          if (wave_path)
+            accumulate_wave(base + k * 64 + lane, lead_slot, mine, lane == __ffsll(static_cast<long long>(same)) - 1, pay[k], valvalid[k]);
+          if (act && !(wave_path && mine)) accumulate(base + k * 64 + lane, sl[k], pay[k], valvalid[k]);
+        }
+      }
     }
+    if (dead) break;
     // tail: the < W records after the last full batch (a masked partial batch instead measured 25-30 % slower)
     int64_t const tail_begin = begin + nbatches * W;
     for (int64_t r = tail_begin + (multi ? lane : static_cast<int>(threadIdx.x)); r < end; r += multi ? 64 : B) {
@@ -584,7 +677,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
   __syncthreads();
   if (threadIdx.x == 0) {
     a.out_count[item] = static_cast<int32_t>(s_dump);
-    if (s_overflow) *a.overflow = 1;
+    if (s_overflow) atomicOr(a.overflow, 2);  // bit 1: a table overflowed (bit 0: a region of an optimistic partition)
   }
 }
 
@@ -689,13 +782,24 @@ __global__ void __launch_bounds__(256) k_finalize(finalize_args const* __restric
 }
 
 // ------------------------------------------------------------------ K_estimate (linear counting on a sample)
+// Row of sample i: one row out of each of `sample` equal strata, at a pseudo-random offset inside its stratum. (A fixed
+// stride aliases with periodic keys: `row % 10M` sampled every 200th row shows 50,000 distinct keys, the tables were
+// planned 200x too small and the call took seconds.)
+__device__ __forceinline__ int64_t sample_row(int64_t i, int64_t nrows, int64_t sample)
+{
+  if (sample >= nrows) return i;
+  int64_t const lo = static_cast<int64_t>((static_cast<__int128>(i) * nrows) / sample);
+  int64_t const hi = static_cast<int64_t>((static_cast<__int128>(i + 1) * nrows) / sample);
+  uint64_t const span = static_cast<uint64_t>(hi - lo);
+  return span <= 1 ? lo : lo + static_cast<int64_t>(mix64(static_cast<uint64_t>(i) + 0x51ed270b35a3c1ull) % span);
+}
 __global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
                                                   uint32_t* bitmap, int32_t bits_log2, uint32_t* hot_buckets)
 {
   plan_dev const& p = *pp;
   int64_t const i   = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= sample) return;
-  int64_t const row = sample >= nrows ? i : static_cast<int64_t>((static_cast<__int128>(i) * nrows) / sample);
+  int64_t const row = sample_row(i, nrows, sample);
   uint64_t key[MAX_KU];
   uint32_t vv;
   if (!build_key_units<MAX_KU, false>(p, row, key, vv)) return;
@@ -719,13 +823,44 @@ __global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ p
   }
   if (pending) atomicAdd(&hot_buckets[bucket], 1u);
 }
+// ------------------------------------------------------------------ K_distinct (HyperLogLog over ALL rows)
+// Run after a table overflowed, i.e. when the sample misjudged the group count (skewed key frequencies: a sample of a
+// Zipf-distributed column shows a twentieth of its keys). 2^14 registers in LDS per workgroup (ds_max_u32), merged into
+// the global registers at the end: the pass streams the key columns once (1.3 ms per 1B int64 keys), standard error 0.8 %.
+static_assert(HLL_REGISTERS == (1 << 14));
+constexpr int HLL_LOG2 = 14;
+__global__ void __launch_bounds__(1024) k_distinct(plan_dev const* __restrict__ pp, int64_t nrows, uint32_t* regs)
+{
+  __shared__ uint32_t s_regs[1 << HLL_LOG2];
+  plan_dev const& p = *pp;
+  for (int i = threadIdx.x; i < (1 << HLL_LOG2); i += blockDim.x) s_regs[i] = 0;
+  __syncthreads();
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t row = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; row < nrows; row += stride) {
+    uint64_t key[MAX_KU];
+    uint32_t vv;
+    if (!build_key_units<MAX_KU, false>(p, row, key, vv)) continue;
+    // (a second mix: the partition and table index bits of the engine's hash stay independent of the register choice)
+    uint64_t const h   = mix64(hash_key_units<MAX_KU>(p, key) ^ 0xa0761d6478bd642full);
+    uint32_t const idx = static_cast<uint32_t>(h >> (64 - HLL_LOG2));
+    uint64_t const w   = (h << HLL_LOG2) | (uint64_t{1} << (HLL_LOG2 - 1));  // rank is at most 64 - HLL_LOG2 + 1
+    uint32_t const rho = static_cast<uint32_t>(__clzll(static_cast<long long>(w))) + 1;
+    if (s_regs[idx] < rho) atomicMax(&s_regs[idx], rho);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 << HLL_LOG2); i += blockDim.x) {
+    uint32_t const r = s_regs[i];
+    if (r != 0 && gload(regs + i) < r) atomicMax(&regs[i], r);
+  }
+}
+
 // ---- heavy hitters in the sample (plain 8-byte key): bucket counts, exact counts of the keys of crowded buckets, selection
 constexpr uint64_t HOT_SENTINEL = ~uint64_t{0};
 __device__ __forceinline__ bool hot_sample_key(plan_dev const& p, int64_t nrows, int64_t sample, uint64_t& key, uint64_t& h)
 {
   int64_t const i = (blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x) * 4;  // the rows k_estimate counted
   if (i >= sample) return false;
-  int64_t const row = sample >= nrows ? i : static_cast<int64_t>((static_cast<__int128>(i) * nrows) / sample);
+  int64_t const row = sample_row(i, nrows, sample);
   key = gload(p.simple_base[0] + row) & p.key_mask[0];
   h   = mix64(0x9e3779b97f4a7c15ull ^ key);
   return true;
@@ -948,6 +1083,16 @@ void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint
   // heavy hitter, and their keys are counted exactly
   hipLaunchKernelGGL(k_hot_collect, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, buckets, crowded, min_count, table_keys,
                      table_counts);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_distinct_count(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, uint32_t* regs, hipStream_t stream)
+{
+  CUDF_HIP_TRY(hipMemsetAsync(regs, 0, HLL_REGISTERS * sizeof(uint32_t), stream));
+  hipLaunchKernelGGL(k_store_args<plan_dev>, dim3(1), dim3(1), 0, stream, plan, d_plan);
+  cudf::detail::prof::scope prof_{"distinct_count", stream};
+  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((nrows + 4095) / 4096, 1, 512));
+  hipLaunchKernelGGL(k_distinct, dim3(grid), dim3(1024), 0, stream, d_plan, nrows, regs);
   CUDF_HIP_TRY(hipGetLastError());
 }
 

@@ -206,6 +206,9 @@ struct part_args {
   // Write-combining scatter (optimistic, 16-byte records): records per output granule (4 = 64 B, 8 = 128 B); every
   // global store of the tile loop is a whole, aligned granule; 0 = classic run-per-tile scatter.
   int32_t wc_granule;
+  // Write-combining scatter of the input columns: workgroup w takes row tiles w, w + slices, ... instead of one contiguous
+  // chunk, so that sorted / clustered keys spread over every workgroup's regions as uniform ones do.
+  int32_t cyclic_tiles;
   // Heavy hitters (write-combining scatter of plain 16-byte records only): rows whose key is one of hot_keys[0..hot_n)
   // are aggregated (SUM of the value, row COUNT) in an LDS table of HOT_SLOTS entries placed hot_lds_offset bytes into
   // the workgroup's LDS instead of being scattered; workgroup w writes its non-empty entries as partial records to
@@ -239,6 +242,11 @@ void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t con
 // Distinct-count estimate on a strided sample (linear counting into a bitmap); result written to *d_bits.
 void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
                      int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream);
+
+// Distinct-count of the key rows over ALL rows (HyperLogLog, HLL_REGISTERS 32-bit registers holding ranks): the planner
+// runs it after a table overflowed, i.e. when the sample misjudged the group count (skewed key frequencies).
+constexpr int HLL_REGISTERS = 1 << 14;
+void launch_distinct_count(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, uint32_t* regs, hipStream_t stream);
 
 // Heavy hitters of a plain 8-byte key column, from the same strided sample as the estimate: sample counts per hash bucket
 // (HOT_BUCKETS counters, filled by launch_estimate's pass over the sample), then exact sample counts of the keys of the buckets with at least `min_count` rows, in an

@@ -168,6 +168,22 @@ int64_t env_i64(char const* name, int64_t dflt)
   return (e != nullptr && *e != 0) ? std::strtoll(e, nullptr, 10) : dflt;
 }
 
+// HyperLogLog estimate (Flajolet et al. 2007) from m registers of ranks, with the small-range (linear counting)
+// correction; a 64-bit hash needs no large-range correction.
+double hyperloglog_estimate(std::vector<uint32_t> const& regs)
+{
+  double const m = static_cast<double>(regs.size());
+  double z       = 0;
+  int64_t zeros  = 0;
+  for (uint32_t r : regs) {
+    z += std::ldexp(1.0, -static_cast<int>(r));
+    zeros += r == 0;
+  }
+  double const alpha = 0.7213 / (1.0 + 1.079 / m);
+  double const e     = alpha * m * m / z;
+  return (e <= 2.5 * m && zeros > 0) ? m * std::log(m / static_cast<double>(zeros)) : e;
+}
+
 // Kinds the hash engine computes (reference groupby/common/utils.hpp:66-85 lists the hashable set; the
 // remaining ones need the sort path, which is out of scope — SURVEY.md §8f rank 4).
 bool is_engine_kind(aggregation::Kind k)
@@ -628,6 +644,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   int32_t* d_count   = nullptr;
   int32_t nitems     = 0;
   double safety      = 1.3;
+  bool counted_all   = false;  // the HyperLogLog pass over all rows has run (after a table overflow)
 
   // one stream synchronisation returns both the overflow flag and the per-item group counts of an attempt
   std::vector<int32_t> h_count;
@@ -638,6 +655,61 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     CUDF_HIP_TRY(hipMemcpyAsync(h_count.data(), d_count, sizeof(int32_t) * static_cast<std::size_t>(nitems), hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipStreamSynchronize(s));
     return h_ov;
+  };
+  // Heavy hitters stay in the (first-level) scatter workgroups: `pa` gets the key list and the per-workgroup partial
+  // buffers; merge_hot() folds those partials into one more work item behind the tables' items.
+  auto setup_hot = [&](part_args& pa, int64_t P) -> bool {
+    auto const wc_lds = cudf::detail::wc_scatter_lds_bytes(5 * 1024, static_cast<std::size_t>(P), pa.wc_granule, 2);
+    bool const hot = !hot_keys.empty() && pa.wc_granule != 0 && p.simple && RU == 2 &&
+                     wc_lds + partition_hot_lds_bytes() + 1200 <= 160 * 1024;  // (the LDS table needs room next to the tile)
+    if (!hot) return false;
+    size_t const wgs = static_cast<size_t>(pa.geom.slices);
+    uint64_t* d_hot  = sc.alloc<uint64_t>(HOT_MAX_KEYS);
+    CUDF_HIP_TRY(hipMemcpyAsync(d_hot, hot_keys.data(), hot_keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    pa.hot_n          = static_cast<int32_t>(hot_keys.size());
+    pa.hot_keys       = d_hot;
+    pa.hot_lds_offset = static_cast<int32_t>(wc_lds);
+    pa.hot_out        = sc.alloc<uint64_t>(wgs * HOT_SLOTS * PU);
+    pa.hot_count      = sc.alloc<int32_t>(wgs);
+    return true;
+  };
+  auto merge_hot = [&](part_args const& pa, agg_args const& aa) {  // partial / d_count hold room for item `nitems`
+    agg_args hm    = aa;
+    hm.input       = IN_PARTIAL_RECORDS;
+    hm.seg         = SEG_STRIDED;
+    hm.records     = pa.hot_out;
+    hm.src_count   = pa.hot_count;
+    hm.src_stride  = HOT_SLOTS;
+    hm.fan         = pa.geom.slices;
+    hm.nsrc        = pa.geom.slices;
+    hm.out_records = partial + static_cast<size_t>(nitems) * ag.cap * PU;
+    hm.out_count   = d_count + nitems;
+    hm.nitems      = 1;
+    launch_aggregate(hm, sc.alloc<agg_args>(1), s);
+    nitems += 1;
+  };
+  auto escalate = [&]() {
+    // A table overflowed: the estimate was too low (skewed sample). First time: count the distinct key rows over ALL rows (HyperLogLog, one
+    // streaming pass over the key columns) and plan from that; after that, ask for 8x more tables and redo.
+    sc.bufs.clear();
+    if (!counted_all) {
+      counted_all       = true;
+      uint32_t* regs    = sc.alloc<uint32_t>(HLL_REGISTERS);
+      plan_dev* d_plan2 = sc.alloc<plan_dev>(1);
+      launch_distinct_count(p, d_plan2, n, regs, s);
+      std::vector<uint32_t> h_regs(HLL_REGISTERS);
+      CUDF_HIP_TRY(hipMemcpyAsync(h_regs.data(), regs, HLL_REGISTERS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipStreamSynchronize(s));
+      double const counted = hyperloglog_estimate(h_regs);
+      if (env_i64("CUDF_AMD_DEBUG", 0))
+        fprintf(stderr, "[cudf_amd] table overflow: sample estimate %.0f groups, HyperLogLog over all rows %.0f\n", est_groups, counted);
+      // (1.05: three standard errors of the 2^14-register estimate; never plan for fewer groups than the failed attempt)
+      est_groups = std::min<double>(static_cast<double>(n), std::max(est_groups * 1.5, counted * 1.05));
+      sc.bufs.clear();
+    } else {
+      est_groups = std::min<double>(static_cast<double>(n), std::max(est_groups, static_cast<double>(ag.fill_limit)) * 8);
+    }
+    d_overflow = sc.alloc<int32_t>(1);
   };
   for (int attempt = 0;; ++attempt) {
     CUDF_EXPECTS(attempt < 4, "hash groupby: could not fit the groups into LDS tables (pathological key distribution).");
@@ -758,19 +830,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         // 16-byte records: write-combining scatter (whole aligned granules only); 64-byte granules at P = 1024
         // (the carry area of 128-byte granules would not leave room for a tile), 128-byte granules at P <= 512
         pa.wc_granule = wc_granule_for(P1);
-        // heavy hitters stay in the scatter workgroups (one more work item, P1, holds their merged partials)
-        bool const hot = !hot_keys.empty() && pa.wc_granule != 0 && p.simple && RU == 2 &&
-                         cudf::detail::wc_scatter_lds_bytes(5 * 1024, static_cast<std::size_t>(P1), pa.wc_granule, 2) +
-                             partition_hot_lds_bytes() + 1200 <= 160 * 1024;  // (the LDS table needs room next to the tile)
-        if (hot) {
-          uint64_t* d_hot = sc.alloc<uint64_t>(HOT_MAX_KEYS);
-          CUDF_HIP_TRY(hipMemcpyAsync(d_hot, hot_keys.data(), hot_keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-          pa.hot_n          = static_cast<int32_t>(hot_keys.size());
-          pa.hot_keys       = d_hot;
-          pa.hot_lds_offset = static_cast<int32_t>(cudf::detail::wc_scatter_lds_bytes(5 * 1024, static_cast<std::size_t>(P1), pa.wc_granule, 2));
-          pa.hot_out        = sc.alloc<uint64_t>(items1 * HOT_SLOTS * PU);
-          pa.hot_count      = sc.alloc<int32_t>(items1);
-        }
+        pa.cyclic_tiles = pa.wc_granule != 0 && env_i64("CUDF_AMD_GB_CYCLIC", 1) != 0;
+        bool const hot = setup_hot(pa, P1);
         if (env_i64("CUDF_AMD_GB_STAMPS", 0)) pa.stamps = sc.alloc<unsigned long long>(items1 * 8);
         store_args(pa, d_pa, s);
         launch_partition_scatter(pa, d_pa, s);
@@ -799,27 +860,17 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         aa.out_count   = d_count;
         aa.nitems      = nitems;
         launch_aggregate(aa, sc.alloc<agg_args>(1), s);
-        if (hot) {  // merge the workgroups' heavy-hitter partials into work item P1
-          agg_args hm    = aa;
-          hm.input       = IN_PARTIAL_RECORDS;
-          hm.records     = pa.hot_out;
-          hm.src_count   = pa.hot_count;
-          hm.src_stride  = HOT_SLOTS;
-          hm.fan         = static_cast<int32_t>(items1);
-          hm.nsrc        = static_cast<int32_t>(items1);
-          hm.out_records = partial + static_cast<size_t>(nitems) * ag.cap * PU;
-          hm.out_count   = d_count + nitems;
-          hm.nitems      = 1;
-          launch_aggregate(hm, sc.alloc<agg_args>(1), s);
-          nitems += 1;
-        }
+        if (hot) merge_hot(pa, aa);
         if (env_i64("CUDF_AMD_DEBUG", 0)) { CUDF_HIP_TRY(hipStreamSynchronize(s)); fprintf(stderr, "[cudf_amd] optimistic aggregate done\n"); }
 
         int32_t const h_ov = overflow_and_counts();
         if (env_i64("CUDF_AMD_DEBUG", 0)) fprintf(stderr, "[cudf_amd] optimistic overflow flag = %d\n", h_ov);
         if (h_ov == 0) break;
-        // a region overflowed (skewed keys) or a table did: redo with exact offsets; a table overflow is then
-        // detected again below and handled by the usual escalation
+        if ((h_ov & 1) == 0) {  // the regions held, a table overflowed: more tables, still without a histogram pass
+          escalate();
+          continue;
+        }
+        // a region overflowed (skewed keys): redo with exact offsets
         allow_optimistic = false;
         sc.bufs.clear();
         d_overflow = sc.alloc<int32_t>(1);
@@ -849,6 +900,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           recA               = sc.alloc<uint64_t>(static_cast<size_t>(S1 * P1) * static_cast<size_t>(cap1) * RU);
           pa.out_records     = recA;
           pa.wc_granule      = wc_granule_for(P1);
+          pa.cyclic_tiles    = pa.wc_granule != 0 && env_i64("CUDF_AMD_GB_CYCLIC", 1) != 0;
+          bool const hot     = setup_hot(pa, P1);  // (a key with percents of the rows would leave one table's workgroup alone with them)
           store_args(pa, d_pa, s);
           launch_partition_scatter(pa, d_pa, s);
           part_args pb{};
@@ -877,8 +930,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           store_args(pb, d_pb, s);
           launch_partition_scatter(pb, d_pb, s);
           nitems         = static_cast<int32_t>(P1 * P2);
-          partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);
-          d_count        = sc.alloc<int32_t>(nitems);
+          partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems + 1) * ag.cap * PU);
+          d_count        = sc.alloc<int32_t>(nitems + 1);
           aa.input       = IN_RAW_RECORDS;
           aa.seg         = SEG_STRIDED;
           aa.records     = recB;
@@ -890,12 +943,17 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           aa.out_count   = d_count;
           aa.nitems      = nitems;
           launch_aggregate(aa, sc.alloc<agg_args>(1), s);
+          if (hot) merge_hot(pa, aa);
           int32_t const h_ov = overflow_and_counts();
           if (env_i64("CUDF_AMD_DEBUG", 0))
             fprintf(stderr, "[cudf_amd] two-level optimistic P1=%ld P2=%ld slices2=%ld cap1=%ld cap2=%ld RU=%d wc=%d/%d overflow=%d\n",
                     (long)P1, (long)P2, (long)slices2, (long)cap1, (long)cap2, RU, pa.wc_granule, pb.wc_granule, h_ov);
           if (h_ov == 0) break;
-          allow_optimistic = false;  // a region or a table overflowed: redo with exact offsets
+          if ((h_ov & 1) == 0) {  // the regions held, a table overflowed
+            escalate();
+            continue;
+          }
+          allow_optimistic = false;  // a region overflowed: redo with exact offsets
           sc.bufs.clear();
           d_overflow = sc.alloc<int32_t>(1);
           --attempt;
@@ -953,10 +1011,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       launch_aggregate(aa, sc.alloc<agg_args>(1), s);
     }
     if (overflow_and_counts() == 0) break;
-    // The estimate was too low (skewed sample): ask for 8x more tables and redo.
-    est_groups = std::min<double>(static_cast<double>(n), std::max(est_groups, static_cast<double>(ag.fill_limit)) * 8);
-    sc.bufs.clear();
-    d_overflow = sc.alloc<int32_t>(1);
+    escalate();
   }
 
   // ---- group counts -> prefix

@@ -429,6 +429,13 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
     sr.end       = rin.total();
   } else {
     sr = slice_of(a, blockIdx.x);
+    // Tile-cyclic rows (optimistic partition of the input columns): workgroup w takes tiles w, w + slices, ... so that
+    // every workgroup sees the whole row range. With a contiguous chunk per workgroup, sorted or clustered keys put a
+    // chunk's rows into a few partitions and overflowed their regions.
+    if (a.cyclic_tiles) {
+      sr.begin = min(a.nrows, static_cast<int64_t>(blockIdx.x) * (RPT * B));
+      sr.end   = a.nrows;
+    }
   }
   uint64_t const* in_records = a.in_records;
   constexpr int KUM = UT < MAX_KU ? UT : MAX_KU;
@@ -509,6 +516,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   g.item         = from_regions ? blockIdx.x % a.geom.slices : blockIdx.x;
   g.begin        = sr.begin;
   g.end          = sr.end;
+  g.step         = (!from_regions && a.cyclic_tiles) ? static_cast<int64_t>(a.geom.slices) * (RPT * B) : 0;
   g.region_cap   = a.region_cap;
   g.region_count = a.region_count + region0;
   g.overflow     = a.overflow;

@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(1024) k_probe_partition(join_args const* __res
   g.item         = blockIdx.x;
   g.begin        = min(n, static_cast<int64_t>(blockIdx.x) * per);
   g.end          = min(n, g.begin + per);
+  g.step         = 0;
   g.region_cap   = a.region_cap;
   g.region_count = a.region_count;
   g.overflow     = a.overflow;

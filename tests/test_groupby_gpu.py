@@ -233,6 +233,28 @@ def test_skewed_keys_retry(G, oracle):
     _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all"])])
 
 
+@pytest.mark.parametrize("kind", ["periodic", "zipf"])
+def test_misjudged_cardinality_is_repaired_quickly(G, oracle, kind):
+    """Key distributions whose sample misjudges the group count: `row % 2M` (a fixed sampling stride aliases with the
+    period) and a log-uniform (Zipf-like) column whose tail the sample barely sees. The tables of the first attempt
+    overflow; the workgroups must stop probing their saturated tables (this took seconds) and the planner must recount
+    over all rows (HyperLogLog) instead of escalating blindly. Results checked against the oracle; bounded time."""
+    import time
+    rng = np.random.default_rng(23)
+    n, groups = 8_000_000, 2_000_000
+    if kind == "periodic":
+        k = np.arange(n, dtype=np.int64) % groups
+    else:
+        k = np.clip((float(groups) ** rng.random(n)).astype(np.int64) - 1, 0, groups - 1)
+    v = rng.random(n)
+    G.groupby([k], [(v, ["sum"])])  # warm-up (allocator, module load)
+    t0 = time.perf_counter()
+    G.groupby([k], [(v, ["sum", "count_all"])])
+    dt = time.perf_counter() - t0
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all"])], expect_path="PARTITIONED_LDS")
+    assert dt < 1.0, f"{kind}: {dt:.3f} s for {n} rows (host copies included) - a saturated-table walk is back"
+
+
 def test_optimistic_partition_and_its_fallback(G, oracle):
     """n >= 4M rows takes the optimistic single-pass partition (no histogram pass). Uniform keys must stay on it;
     a heavy-hitter key overflows its fixed-capacity region and must be repaired by the exact pipeline."""
