@@ -381,6 +381,11 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
       u64x2 const v = gload(reinterpret_cast<u64x2 const*>(records) + r);
       key[0]        = v.x;
       pay[0]        = v.y;
+      // (a key of at most 4 bytes carries the validity flags of a nullable value in its spare half)
+      if (INPUT == IN_RAW_RECORDS && flags_unit >= 0) {
+        uint64_t const w = flags_unit == 0 ? v.x : v.y;
+        valvalid         = static_cast<uint32_t>(flags_hi ? (w >> 32) : w);
+      }
       return true;
     } else {
 #pragma unroll

@@ -121,6 +121,9 @@ class hash_join_impl {
     CUDF_HIP_TRY(hipMemsetAsync(_table.data(), 0xff, capacity * sizeof(uint64_t) * _slot_words, stream.value()));
     join_args a = base_args(right, 0);
     rmm::device_buffer d_args{sizeof(join_args), stream.value(), cudf::get_current_device_resource_ref()};
+    rmm::device_buffer skip{sizeof(uint64_t) * join::BUILD_SKIP_ENTRIES, stream.value(), cudf::get_current_device_resource_ref()};
+    CUDF_HIP_TRY(hipMemsetAsync(skip.data(), 0xff, skip.size(), stream.value()));  // no home slot is 2^40 - 1
+    a.build_skip = static_cast<uint64_t*>(skip.data());
     join::launch_build(a, static_cast<join_args*>(d_args.data()), stream.value());
     CUDF_HIP_TRY(hipStreamSynchronize(stream.value()));  // d_args goes out of scope; build is done for probes on any stream
   }

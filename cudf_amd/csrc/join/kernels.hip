@@ -72,13 +72,37 @@ __global__ void __launch_bounds__(256) k_build(join_args const* __restrict__ ap)
       h = join_row_hash(a.build, i, a.check_nulls);
     }
     uint64_t const entry = make_entry(h, i);
-    uint64_t slot        = home_slot(h, a);
+    uint64_t const home  = home_slot(h, a);
+    uint64_t slot        = home;
     int const sw         = a.slot_words;
+    // The home slot is tried with the compare-and-swap itself (empty three times out of four); further slots are read
+    // first and only an empty one is claimed: a walk over occupied slots costs loads, not atomics.
+    uint64_t dist = 0;  // slots [home, home + dist) are known to be occupied
+    uint64_t* const hint = a.build_skip + ((h >> 20) & (BUILD_SKIP_ENTRIES - 1));
     for (;;) {
-      unsigned long long const old =
-        atomicCAS(reinterpret_cast<unsigned long long*>(a.table + slot * sw), EMPTY_SLOT, static_cast<unsigned long long>(entry));
-      if (old == EMPTY_SLOT) break;
+      if (dist == 0 || __hip_atomic_load(a.table + slot * sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == EMPTY_SLOT) {
+        unsigned long long const old =
+          atomicCAS(reinterpret_cast<unsigned long long*>(a.table + slot * sw), EMPTY_SLOT, static_cast<unsigned long long>(entry));
+        if (old == EMPTY_SLOT) break;
+      }
+      ++dist;
       slot = slot + 1 == cap ? 0 : slot + 1;
+      if ((dist & (BUILD_SKIP_AFTER - 1)) == 0 && dist < cap) {  // a long run (many equal keys): is a longer one known?
+        uint64_t const e = __hip_atomic_load(hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t const d = e & 0xffffffull;
+        if ((e >> 24) == home && d > dist && d < cap) {
+          dist = d;
+          slot = home + d;
+          if (slot >= cap) slot -= cap;
+        }
+      }
+    }
+    if (dist >= BUILD_SKIP_AFTER && dist < 0xffffffull) {
+      // [home, home + dist] is occupied. Hints are advisory: any value ever stored is a true statement (slots are never
+      // emptied during the build), so a racing store can only lose some of the shortcut.
+      uint64_t const e = __hip_atomic_load(hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((e >> 24) != home || (e & 0xffffffull) < dist + 1)
+        __hip_atomic_store(hint, (home << 24) | (dist + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (SINGLE64) {
       if (sw == 2) gstore(a.table + slot * 2 + 1, gload(keys + i));

@@ -110,7 +110,10 @@ def compare_columns(actual, expected, what="", atol=0.0):
     assert len(a_data) == len(e_data), f"{what}: size {len(a_data)} != {len(e_data)}"
     av = np.ones(len(a_data), bool) if a_valid is None else a_valid
     ev = np.ones(len(e_data), bool) if e_valid is None else e_valid
-    assert np.array_equal(av, ev), f"{what}: validity differs {av} vs {ev}"
+    if not np.array_equal(av, ev):
+        bad = np.flatnonzero(av != ev)
+        raise AssertionError(f"{what}: validity differs at rows {bad[:8]} (of {len(bad)}): actual valid {av[bad[:8]]} data "
+                             f"{a_data[bad[:8]]}, expected valid {ev[bad[:8]]} data {e_data[bad[:8]]}")
     is_float = np.dtype(NP_OF_TYPE_ID[a_tid]).kind == "f"
     a = a_data[av]
     e = e_data[ev]
