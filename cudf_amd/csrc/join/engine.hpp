@@ -21,10 +21,9 @@ struct join_args {
   device_table build;
   device_table probe;
   uint64_t* table;         // capacity slots of slot_words 64-bit words
-  // Build only: BUILD_SKIP_ENTRIES hints {home slot << 24 | d}, indexed by hash bits: "the d slots from this home slot on
-  // are occupied". An insert that has walked BUILD_SKIP_AFTER slots looks its hint up and jumps ahead; an insert that
-  // ended further than that from its home slot leaves one. (100,000 equal build keys: every insert walked the run of its
-  // predecessors, 5e9 slot visits, 2.1 s.)
+  // Build only: BUILD_SKIP_ENTRIES advisory hints {44 hash bits | n}: "the first n steps of this hash's probe sequence are
+  // full" (kernels.hip k_build, seq_next). An insert that has walked BUILD_SKIP_AFTER steps looks its hint up and jumps
+  // ahead; an insert that ended further than that along its sequence leaves one.
   uint64_t* build_skip;
   uint64_t capacity;
   // slot_words == 2: the build side is one 8-byte integer key column whose NULLs (if any) are never inserted; the

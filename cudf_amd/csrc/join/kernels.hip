@@ -50,6 +50,55 @@ __device__ __forceinline__ uint64_t make_entry(uint64_t h, int64_t row)
   return ((h >> 32) << 32) | static_cast<uint32_t>(row);
 }
 
+// Probe sequence of a row hash, in STEPS of 16 bytes (two 8-byte slots, or one inline-key slot): SEQ_LINEAR consecutive
+// steps from the home step, then hops of a key-dependent stride coprime to the number of steps (the hops reach every
+// step). Plain linear probing lets ONE heavily duplicated build key poison its neighbourhood: 100,000 equal keys form a
+// 100,000-slot run that every probe with a home slot inside it walks to the end (0.25 % of 100M probes: 1 s). With the
+// hops, the duplicates beyond the window sit on their key's own trail. Build, count and retrieve passes walk the same
+// sequence; an entry always takes the first empty slot of its sequence, so a walk may stop at the first empty slot.
+constexpr uint32_t SEQ_LINEAR = 16;
+__device__ __noinline__ uint64_t seq_stride(uint64_t h, uint64_t nsteps)
+{
+  if (nsteps <= 2) return 1;
+  uint64_t s = 1 + mix64(h ^ 0x2545f4914f6cdd1dull) % (nsteps - 1);
+  for (;;) {
+    uint64_t x = s, y = nsteps;
+    while (y != 0) {
+      uint64_t const t = x % y;
+      x                = y;
+      y                = t;
+    }
+    if (x == 1) return s;
+    s = s + 1 >= nsteps ? 1 : s + 1;
+  }
+}
+// Advances from step number n (the home step st0 is number 0) and updates n; `stride` caches seq_stride (0 = not computed
+// yet). Hop positions that fall back into the linear window were visited already: they keep their number but are
+// passed over (a probe that walked them twice counted their matches twice). Tiny tables stay linear.
+__device__ __forceinline__ uint64_t seq_next(uint64_t st, uint32_t& n, uint64_t h, uint64_t nsteps, uint64_t& stride, uint64_t st0)
+{
+  if (n + 1 < SEQ_LINEAR || nsteps <= 4 * SEQ_LINEAR) {
+    ++n;
+    return st + 1 == nsteps ? 0 : st + 1;
+  }
+  if (stride == 0) stride = seq_stride(h, nsteps);
+  for (;;) {
+    st += stride;
+    if (st >= nsteps) st -= nsteps;
+    ++n;
+    uint64_t const d = st >= st0 ? st - st0 : st + nsteps - st0;
+    if (d >= SEQ_LINEAR) return st;
+  }
+}
+// position number n of the sequence that starts at step st0 (n: a number seq_next stopped at)
+__device__ __forceinline__ uint64_t seq_at(uint64_t st0, uint32_t n, uint64_t h, uint64_t nsteps, uint64_t& stride)
+{
+  if (n < SEQ_LINEAR || nsteps <= 4 * SEQ_LINEAR) return (st0 + n) % nsteps;
+  if (stride == 0) stride = seq_stride(h, nsteps);
+  // n < 2^20, stride < 2^32: no overflow
+  return (static_cast<uint64_t>(n - (SEQ_LINEAR - 1)) * stride + (st0 + SEQ_LINEAR - 1) % nsteps) % nsteps;
+}
+
 // ------------------------------------------------------------------ build
 template <bool SINGLE64>
 __global__ void __launch_bounds__(256) k_build(join_args const* __restrict__ ap)
@@ -73,36 +122,49 @@ __global__ void __launch_bounds__(256) k_build(join_args const* __restrict__ ap)
     }
     uint64_t const entry = make_entry(h, i);
     uint64_t const home  = home_slot(h, a);
-    uint64_t slot        = home;
     int const sw         = a.slot_words;
+    bool const pairs     = sw == 1;                      // 8-byte slots: a step is an aligned pair of slots
+    uint64_t const nsteps = pairs ? cap >> 1 : cap;      // (capacity is even)
+    uint64_t const st0   = pairs ? home >> 1 : home;
+    uint64_t st = st0, stride = 0, slot = home;
+    uint32_t n  = 0;                                     // step number; the slots of steps [0, n) are known to be occupied
     // The home slot is tried with the compare-and-swap itself (empty three times out of four); further slots are read
     // first and only an empty one is claimed: a walk over occupied slots costs loads, not atomics.
-    uint64_t dist = 0;  // slots [home, home + dist) are known to be occupied
-    uint64_t* const hint = a.build_skip + ((h >> 20) & (BUILD_SKIP_ENTRIES - 1));
+    bool blind = true;
+    // Hints {44 hash bits | n}: "the first n steps of this hash's sequence are full". An insert that has walked
+    // BUILD_SKIP_AFTER steps looks its hint up and jumps ahead; one that ended beyond that leaves a hint. Hints are
+    // advisory: any value ever stored is true (slots are never emptied during the build), a racing store can only lose
+    // some of the shortcut. (Two different heavy keys that agree in 44 hash bits would share hints: 2^-44 per pair.)
+    uint64_t* const hint    = a.build_skip + ((h >> 12) & (BUILD_SKIP_ENTRIES - 1));
+    uint64_t const hint_tag = (h >> 20) << 20;
     for (;;) {
-      if (dist == 0 || __hip_atomic_load(a.table + slot * sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == EMPTY_SLOT) {
-        unsigned long long const old =
-          atomicCAS(reinterpret_cast<unsigned long long*>(a.table + slot * sw), EMPTY_SLOT, static_cast<unsigned long long>(entry));
-        if (old == EMPTY_SLOT) break;
+      bool done = false;
+      for (int q = (pairs && n == 0) ? static_cast<int>(home & 1) : 0; q < (pairs ? 2 : 1); ++q) {
+        slot                  = pairs ? st * 2 + q : st;
+        uint64_t* const where = a.table + slot * sw;
+        if (blind || __hip_atomic_load(where, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == EMPTY_SLOT) {
+          blind = false;
+          if (atomicCAS(reinterpret_cast<unsigned long long*>(where), EMPTY_SLOT, static_cast<unsigned long long>(entry)) == EMPTY_SLOT) {
+            done = true;
+            break;
+          }
+        }
       }
-      ++dist;
-      slot = slot + 1 == cap ? 0 : slot + 1;
-      if ((dist & (BUILD_SKIP_AFTER - 1)) == 0 && dist < cap) {  // a long run (many equal keys): is a longer one known?
+      if (done) break;
+      uint32_t const before = n;
+      st = seq_next(st, n, h, nsteps, stride, st0);
+      if ((before / BUILD_SKIP_AFTER) != (n / BUILD_SKIP_AFTER)) {  // a long walk (many equal keys): is a longer full prefix known?
         uint64_t const e = __hip_atomic_load(hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t const d = e & 0xffffffull;
-        if ((e >> 24) == home && d > dist && d < cap) {
-          dist = d;
-          slot = home + d;
-          if (slot >= cap) slot -= cap;
+        uint32_t const d = static_cast<uint32_t>(e & 0xfffffull);
+        if ((e >> 20 << 20) == hint_tag && d > n) {
+          n  = d;
+          st = seq_at(st0, n, h, nsteps, stride);
         }
       }
     }
-    if (dist >= BUILD_SKIP_AFTER && dist < 0xffffffull) {
-      // [home, home + dist] is occupied. Hints are advisory: any value ever stored is a true statement (slots are never
-      // emptied during the build), so a racing store can only lose some of the shortcut.
+    if (n >= BUILD_SKIP_AFTER && n < 0xfffffu) {
       uint64_t const e = __hip_atomic_load(hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((e >> 24) != home || (e & 0xffffffull) < dist + 1)
-        __hip_atomic_store(hint, (home << 24) | (dist + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((e >> 20 << 20) != hint_tag || (e & 0xfffffull) < n) __hip_atomic_store(hint, hint_tag | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (SINGLE64) {
       if (sw == 2) gstore(a.table + slot * 2 + 1, gload(keys + i));
@@ -261,7 +323,8 @@ __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict
         };
         if (active[k]) {
           u64x2 v     = v0[k];
-          uint64_t st = pairs ? slot[k] >> 1 : slot[k];
+          uint64_t st = pairs ? slot[k] >> 1 : slot[k], stride = 0;
+          uint32_t ns = 0;                       // step number along the key's probe sequence (seq_next)
           bool skip   = pairs && (slot[k] & 1);  // the home slot is the second of its pair
           for (;;) {
             if (pairs) {
@@ -271,7 +334,7 @@ __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict
             } else {
               if (!visit(v.x, v.y)) break;
             }
-            st = st + 1 == nsteps ? 0 : st + 1;
+            st = seq_next(st, ns, h[k], nsteps, stride, pairs ? slot[k] >> 1 : slot[k]);
             v  = gload(table16 + st);
           }
         }
@@ -373,6 +436,11 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
       uint64_t slot      = multi ? home_slot(h, a) : 0;
       uint32_t const tag = static_cast<uint32_t>(h >> 32);
       bool walking       = multi;
+      bool const pairs   = sw == 1;  // the sequence advances in 16-byte steps: aligned pairs of 8-byte slots
+      uint64_t const nsteps = pairs ? cap >> 1 : cap;
+      uint64_t const st0 = pairs ? slot >> 1 : slot;
+      uint64_t stride    = 0;
+      uint32_t ns        = 0;
       while (__any(walking)) {
         bool match     = false;
         size_type brow = 0;
@@ -395,7 +463,12 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
               if constexpr (MODE == MODE_KEY64) match = gload(bkeys + brow) == pkey;
               else match = rows_equal(a.probe, j, a.build, brow, a.nulls_equal != 0);
             }
-            slot = slot + 1 == cap ? 0 : slot + 1;
+            if (pairs && (slot & 1) == 0) {
+              slot += 1;
+            } else {
+              uint64_t const st = seq_next(pairs ? slot >> 1 : slot, ns, h, nsteps, stride, st0);
+              slot = pairs ? st * 2 : st;
+            }
           }
         }
         emit(match, prow, brow);

@@ -114,6 +114,31 @@ def test_random_multi_column_mixed_types(G, oracle, nulls_equal):
         _check(G, oracle, left, right, nulls_equal, kind)
 
 
+@pytest.mark.parametrize("kind", ["inner", "left", "full"])
+@pytest.mark.parametrize("two_columns", [False, True])
+def test_heavily_duplicated_build_key(G, oracle, kind, two_columns):
+    """One build key with 40,000 duplicates among 120,000 build rows: its entries fill the linear window of its probe
+    sequence and continue on the key's own stride trail (kernels.hip seq_next); build, count and retrieve passes must
+    walk the same sequence, neighbours of the heavy key's home slot must still be found, and the inserts must share
+    their skip hints. Checked against the oracle, with a time bound (the quadratic walk took seconds)."""
+    import time
+    rng = np.random.default_rng(77)
+    nr, nl = 120_000, 90_000
+    rk = rng.permutation(400_000)[:nr].astype(np.int64)
+    rk[rng.permutation(nr)[:40_000]] = 31337
+    rk[rng.permutation(nr)[:3_000]] = 4242          # a second, lighter heavy key
+    lk = rng.integers(0, 400_000, nl, dtype=np.int64)
+    lk[:25] = 31337                                  # 25 x 40,000 pairs
+    lk[25:40] = 4242
+    left, right = [lk], [rk]
+    if two_columns:  # generic (multi-column) row path
+        left.append((lk % 7).astype(np.int32))
+        right.append((rk % 7).astype(np.int32))
+    t0 = time.perf_counter()
+    _check(G, oracle, left, right, True, kind)
+    assert time.perf_counter() - t0 < 30.0
+
+
 def test_empty_sides(G, oracle):
     e = np.zeros(0, np.int64)
     k = np.array([1, 2, 3], np.int64)
