@@ -880,7 +880,10 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       // two optimistic levels (more than 1024 partitions): level 1 as above into per-(slice, partition) regions; the
       // level-2 items read their level-1 partition as a strided list of those regions and write per-(item, final
       // partition) regions, which the aggregate walks. No histogram pass on either level.
-      if (allow_optimistic && P2 > 1 && !forced_exact && n >= (int64_t{1} << 22) && env_i64("CUDF_AMD_GB_OPTIMISTIC2", 1)) {
+      // (a full heavy-hitter list means many more warm keys behind it: each overflows a level-2 region, whose share of the
+      // rows is 1 / (P1 * slices2 * P2) - the attempt would be wasted, go to exact offsets at once)
+      bool const warm_tail = hot_keys.size() >= static_cast<std::size_t>(HOT_MAX_KEYS);
+      if (allow_optimistic && P2 > 1 && !forced_exact && !warm_tail && n >= (int64_t{1} << 22) && env_i64("CUDF_AMD_GB_OPTIMISTIC2", 1)) {
         int64_t const S1      = 256;
         int64_t const slices2 = std::max<int64_t>(1, 512 / P1);
         double const mean1    = static_cast<double>(n) / static_cast<double>(S1 * P1);
