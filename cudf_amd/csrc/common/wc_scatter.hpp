@@ -221,21 +221,37 @@ __device__ __forceinline__ void wc_scatter_slice(unsigned char* lds_raw, wc_scat
     // (no barrier: the next tile touches only hist and registers before its first barrier)
   }
   wc_lds_barrier();
-  // flush the carried records (the only partial granules of the region)
+  // flush the carried records (the only partial granules of the region): owners publish cursor and carry count, then G
+  // lanes per partition write its carried records side by side (16-byte stores; one thread storing a partition's units one
+  // by one cost the chunked pipeline, which flushes once per chunk, 4 % of its rows in 8-byte stores)
 #pragma unroll
   for (int k = 0; k < MAXE; ++k) {
     int const d = threadIdx.x + k * B;
     if (d < P) {
       if (cursor[k] + ccnt[k] > region_end[k]) {
         *g.overflow = 1;
-      } else {
-        for (uint32_t q = 0; q < ccnt[k]; ++q) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) gstore(out + (cursor[k] + q) * U + u, carry[(static_cast<uint32_t>(d) * CW + q) * U + u]);
-        }
-        cursor[k] += ccnt[k];
+        ccnt[k]     = 0;
       }
-      g.region_count[static_cast<int64_t>(d) * g.slices + item] = static_cast<int32_t>(cursor[k] - (region_end[k] - g.region_cap));
+      delta[d] = cursor[k];
+      hist[d]  = ccnt[k];
+      g.region_count[static_cast<int64_t>(d) * g.slices + item] = static_cast<int32_t>(cursor[k] + ccnt[k] - (region_end[k] - g.region_cap));
+    }
+  }
+  wc_lds_barrier();
+  if constexpr (U == 2) {
+    for (int idx = threadIdx.x; idx < P * G; idx += B) {
+      int const d = idx / G;
+      uint32_t const q = static_cast<uint32_t>(idx % G);
+      if (q < hist[d]) gstore(reinterpret_cast<u64x2*>(out) + delta[d] + q, reinterpret_cast<u64x2 const*>(carry)[static_cast<uint32_t>(d) * CW + q]);
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < P * G; idx += B) {
+      int const d = idx / G;
+      uint32_t const q = static_cast<uint32_t>(idx % G);
+      if (q < hist[d]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) gstore(out + (delta[d] + q) * U + u, carry[(static_cast<uint32_t>(d) * CW + q) * U + u]);
+      }
     }
   }
 }

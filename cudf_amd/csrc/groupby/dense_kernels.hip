@@ -1,0 +1,317 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 kernels of the DENSE-KEY hash-groupby path (engine.hpp dense_map / dense_agg_args): one plain 8-byte integer
+// key column whose values span a small range is aggregated by direct addressing - the perfect-hash special case of the
+// open-addressing tables of aggregate_kernels.hip: no hash, no probe, no key words, no state words; a row costs one
+// 16-byte load, one 32-bit multiply and its ds_add / ds_min / ds_max atomics.
+// Replaces, for such keys, the reference's cuco::static_set insert + global atomics
+// (cpp/src/groupby/hash/compute_global_memory_aggs.cuh:74-187, single_pass_functors.cuh:86-157).
+#include "device_common.hpp"
+
+namespace cudf::groupby::detail {
+namespace {
+
+// ------------------------------------------------------------------ K_key_range (sample minimum / maximum)
+__device__ __forceinline__ int64_t dense_sample_row(int64_t i, int64_t nrows, int64_t sample)
+{
+  // the strided sample of k_estimate (aggregate_kernels.hip sample_row): one row per stratum at a pseudo-random offset
+  if (sample >= nrows) return i;
+  int64_t const lo    = static_cast<int64_t>((static_cast<__int128>(i) * nrows) / sample);
+  int64_t const hi    = static_cast<int64_t>((static_cast<__int128>(i + 1) * nrows) / sample);
+  uint64_t const span = static_cast<uint64_t>(hi - lo);
+  return span <= 1 ? lo : lo + static_cast<int64_t>(mix64(static_cast<uint64_t>(i) + 0x51ed270b35a3c1ull) % span);
+}
+template <bool SIGNED>
+__global__ void __launch_bounds__(256) k_key_range(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample, uint64_t* out)
+{
+  plan_dev const& p = *pp;
+  using T           = std::conditional_t<SIGNED, long long, unsigned long long>;
+  __shared__ T s_lo[4], s_hi[4];
+  T lo = SIGNED ? static_cast<T>(INT64_MAX) : static_cast<T>(UINT64_MAX), hi = SIGNED ? static_cast<T>(INT64_MIN) : T{0};
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < sample; i += stride) {
+    T const k = static_cast<T>(gload(p.simple_base[0] + dense_sample_row(i, nrows, sample)));
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    T const l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  // (same-address global atomics serialise at ~12 ns each: one pair per workgroup, not per wave)
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
+    atomicMin(reinterpret_cast<T*>(out), lo);
+    atomicMax(reinterpret_cast<T*>(out) + 1, hi);
+  }
+}
+
+// ------------------------------------------------------------------ K_aggregate_dense
+// LDS image of a table: accumulator q as [slots] u64 (u32 for a COUNT), 8-byte arrays first; then the occupancy bitmap
+// [slots / 32] u32 if no accumulator counts every row. The image is copied verbatim from / to HBM between chunks.
+struct dense_layout {
+  uint32_t off[MAX_ACC];
+  uint32_t occ_off;
+  uint32_t bytes;
+};
+__host__ __device__ inline dense_layout make_dense_layout(plan_dev const& p, int slots, int occ_acc)
+{
+  dense_layout L{};
+  uint32_t o = 0;
+  for (int q = 0; q < p.NACC; ++q)
+    if (!acc_is_narrow(p.acc[q].op, p.acc[q].src)) {
+      L.off[q] = o;
+      o += static_cast<uint32_t>(slots) * 8u;
+    }
+  for (int q = 0; q < p.NACC; ++q)
+    if (acc_is_narrow(p.acc[q].op, p.acc[q].src)) {
+      L.off[q] = o;
+      o += static_cast<uint32_t>(slots) * 4u;
+    }
+  L.occ_off = o;
+  if (occ_acc < 0) o += static_cast<uint32_t>((slots + 31) / 32) * 4u;
+  L.bytes = (o + 15u) & ~15u;
+  return L;
+}
+
+// SIG: compile-time accumulator signature (device_common.hpp), 0 = descriptors read at run time.
+// One workgroup per partition; wave w walks the regions [w * g, (w + 1) * g) of its partition as ONE virtual record range
+// (a chunk's regions hold 50-400 records each: walked one by one they would be all tail).
+template <uint64_t SIG, int NACCT>
+__global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args const* __restrict__ ap, int first_chunk, int last_chunk)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ uint32_t s_dump;
+  dense_agg_args const& a = *ap;
+  plan_dev const& p       = a.plan;
+  constexpr bool STATIC_SIG = SIG != 0;
+  int const NACC  = STATIC_SIG ? sig_n(SIG) : p.NACC;
+  int const slots = a.slots, item = blockIdx.x, B = blockDim.x;
+  int const occ_acc = a.occ_acc;
+  int acc_op[NACCT], acc_src[NACCT];
+  uint32_t acc_off[NACCT];
+  bool acc_narrow[NACCT];
+  uint32_t off8 = 0, off4 = 0;
+#pragma unroll
+  for (int j = 0; j < NACCT; ++j) {
+    uint32_t const w = j < NACC ? reinterpret_cast<uint32_t const*>(p.acc)[j] : 0u;
+    acc_op[j]        = STATIC_SIG ? sig_op(SIG, j) : static_cast<int8_t>(w);
+    acc_src[j]       = STATIC_SIG ? sig_src(SIG, j) : static_cast<int8_t>(w >> 8);
+    acc_narrow[j]    = j < NACC && acc_is_narrow(acc_op[j], acc_src[j]);
+    if (j < NACC && !acc_narrow[j]) off4 += static_cast<uint32_t>(slots) * 8u;
+  }
+#pragma unroll
+  for (int j = 0; j < NACCT; ++j) {
+    if (j >= NACC) { acc_off[j] = 0; continue; }
+    if (acc_narrow[j]) { acc_off[j] = off4; off4 += static_cast<uint32_t>(slots) * 4u; }
+    else { acc_off[j] = off8; off8 += static_cast<uint32_t>(slots) * 8u; }
+  }
+  uint32_t* occ = reinterpret_cast<uint32_t*>(lds_raw + off4);  // (only if occ_acc < 0)
+  auto acc64 = [&](int q) { return reinterpret_cast<uint64_t*>(lds_raw + acc_off[q]); };
+  auto acc32 = [&](int q) { return reinterpret_cast<uint32_t*>(lds_raw + acc_off[q]); };
+
+  // ---- table: identities on the first chunk, the carried image afterwards
+  uint64_t* image = a.tables + static_cast<int64_t>(item) * (a.image_bytes / 8);
+  if (first_chunk) {
+#pragma unroll
+    for (int q = 0; q < NACCT; ++q) {
+      if (q >= NACC) break;
+      if (acc_narrow[q]) {
+        for (int s = threadIdx.x; s < slots; s += B) acc32(q)[s] = 0;
+      } else {
+        uint64_t const id = acc_identity(acc_op[q]);
+        for (int s = threadIdx.x; s < slots; s += B) acc64(q)[s] = id;
+      }
+    }
+    if (occ_acc < 0)
+      for (int s = threadIdx.x; s < (slots + 31) / 32; s += B) occ[s] = 0;
+  } else {
+    for (int i = threadIdx.x; i < a.image_bytes / 16; i += B)
+      reinterpret_cast<u64x2*>(lds_raw)[i] = gload(reinterpret_cast<u64x2 const*>(image) + i);
+  }
+  if (threadIdx.x == 0) s_dump = 0;
+  __syncthreads();
+
+  uint64_t const lo = a.map.lo;
+  uint32_t const mult = a.map.mult, smask = static_cast<uint32_t>(slots - 1);
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
+  // an upstream scatter gave up (region overflow / key outside the dense range): its counts are not valid
+  bool const upstream_ok = *a.overflow == 0;
+  // ---- this wave's regions as one virtual range
+  int const g      = (a.slices + nwaves - 1) / nwaves;  // <= 64 (slices <= 1024)
+  int const r_base = wave * g;
+  int32_t cnt      = 0;
+  if (upstream_ok && lane < g && r_base + lane < a.slices)
+    cnt = min(max(a.region_count[static_cast<int64_t>(item) * a.slices + r_base + lane], 0), static_cast<int32_t>(a.region_cap));
+  int32_t pend = cnt;  // inclusive prefix: end of region `lane` in the virtual range
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int32_t const t = __shfl_up(pend, o);
+    if (lane >= o) pend += t;
+  }
+  int32_t const total = __builtin_amdgcn_readlane(pend, 63);
+  u64x2 const* recs   = reinterpret_cast<u64x2 const*>(a.records) + (static_cast<int64_t>(item) * a.slices + r_base) * a.region_cap;
+  int64_t const cap   = a.region_cap;
+  int rcur            = 0;  // wave-uniform: first region that may hold the next virtual record
+  // record index (relative to `recs`) of virtual record v; v ascends from call to call
+  auto locate = [&](int32_t v, bool active) -> int64_t {
+    int32_t const v0 = __builtin_amdgcn_readfirstlane(v);
+    while (rcur < g - 1 && __builtin_amdgcn_readlane(pend, rcur) <= v0) ++rcur;
+    int reg       = rcur;
+    int32_t start = rcur == 0 ? 0 : __builtin_amdgcn_readlane(pend, rcur - 1);
+    for (int i = rcur; i < g - 1; ++i) {
+      int32_t const e = __builtin_amdgcn_readlane(pend, i);
+      bool const ge   = active && v >= e;
+      if (__ballot(ge) == 0) break;
+      reg += ge ? 1 : 0;
+      start = ge ? e : start;
+    }
+    return static_cast<int64_t>(reg) * cap + (v - start);
+  };
+  auto accumulate = [&](uint64_t key, uint64_t value) {
+    uint32_t const s = (static_cast<uint32_t>(key - lo) * mult) & smask;
+#pragma unroll
+    for (int q = 0; q < NACCT; ++q) {
+      if (q >= NACC) break;
+      if (acc_narrow[q]) {  // row counts (no nulls on this path: COUNT_VALID == COUNT_ALL)
+        atomicAdd(acc32(q) + s, 1u);
+        continue;
+      }
+      uint64_t v = value;
+      if (acc_src[q] == SRC_SQUARE) {
+        if (acc_op[q] == ADD_F64) {
+          double const x = __longlong_as_double(static_cast<long long>(value));
+          v              = static_cast<uint64_t>(__double_as_longlong(x * x));
+        } else {
+          v = value * value;
+        }
+      }
+      lds_merge(acc64(q) + s, acc_op[q], v);
+    }
+    if (occ_acc < 0) {
+      uint32_t const bit = 1u << (s & 31);
+      if (!(occ[s >> 5] & bit)) atomicOr(&occ[s >> 5], bit);
+    }
+  };
+  constexpr int R = 4;
+  for (int32_t v0 = 0; v0 < total; v0 += R * 64) {
+    u64x2 rec[R];
+    bool act[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      int32_t const v = v0 + k * 64 + lane;
+      act[k]          = v < total;
+      if (v0 + k * 64 < total) {  // (wave-uniform)
+        int64_t const ri = locate(v, act[k]);
+        if (act[k]) rec[k] = gload(recs + ri);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      if (act[k]) accumulate(rec[k].x, rec[k].y);
+  }
+  __syncthreads();
+  if (!last_chunk) {
+    for (int i = threadIdx.x; i < a.image_bytes / 16; i += B)
+      gstore(reinterpret_cast<u64x2*>(image) + i, reinterpret_cast<u64x2 const*>(lds_raw)[i]);
+    return;
+  }
+  // ---- last chunk: occupied slots -> partial records [key | accumulators] (k_finalize reads them)
+  int const PU       = 1 + NACC;
+  uint64_t* out      = a.out_records + static_cast<int64_t>(item) * slots * PU;
+  uint32_t const hi  = static_cast<uint32_t>(item) << (a.map.bits - a.map.log2P);
+  uint32_t const bmask = (1u << a.map.bits) - 1u;
+  for (int s = threadIdx.x; s < slots; s += B) {
+    bool occupied;
+    if (occ_acc >= 0) {
+      occupied = false;
+#pragma unroll
+      for (int q = 0; q < NACCT; ++q)
+        if (q == occ_acc) occupied = acc32(q)[s] != 0;
+    } else {
+      occupied = (occ[s >> 5] >> (s & 31)) & 1u;
+    }
+    if (!occupied) continue;
+    uint32_t const pos = atomicAdd(&s_dump, 1u);
+    uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
+    uint32_t const idx = ((hi | static_cast<uint32_t>(s)) * a.map.mult_inv) & bmask;
+    gstore(o, lo + idx);
+#pragma unroll
+    for (int q = 0; q < NACCT; ++q) {
+      if (q >= NACC) break;
+      gstore(o + 1 + q, acc_narrow[q] ? static_cast<uint64_t>(acc32(q)[s]) : acc64(q)[s]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.out_count[item] = static_cast<int32_t>(s_dump);
+}
+
+}  // namespace
+
+int dense_occ_acc(plan_dev const& plan)
+{
+  for (int q = 0; q < plan.NACC; ++q)
+    if (plan.acc[q].op == ADD_I64 && plan.acc[q].src == SRC_ONE) return q;
+  return -1;
+}
+std::size_t dense_table_bytes(plan_dev const& plan, int slots) { return make_dense_layout(plan, slots, dense_occ_acc(plan)).bytes; }
+
+void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<dense_agg_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+template <uint64_t SIG, int NACCT>
+static void launch_dense_n(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream)
+{
+  static bool attr_set = false;
+  if (!attr_set) {
+    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate_dense<SIG, NACCT>));
+    attr_set = true;
+  }
+  cudf::detail::prof::scope prof_{"aggregate", stream};
+  hipLaunchKernelGGL((k_aggregate_dense<SIG, NACCT>), dim3(a.nitems), dim3(a.block), a.image_bytes, stream, d_args,
+                     first_chunk ? 1 : 0, last_chunk ? 1 : 0);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_aggregate_dense(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1 && a.plan.narg == 0, "dense keys: one plain key column, one plain value column");
+  CUDF_EXPECTS(a.block == 1024 && a.slices <= 1024 && a.image_bytes <= 159 * 1024 && (a.slots & (a.slots - 1)) == 0 &&
+                 a.occ_acc == dense_occ_acc(a.plan) && a.image_bytes == static_cast<int32_t>(dense_table_bytes(a.plan, a.slots)),
+               "dense keys: table geometry");
+  uint64_t const sig = plan_sig(a.plan);
+  if (sig == SIG_SUMF_CNT) return launch_dense_n<SIG_SUMF_CNT, 2>(a, d_args, first_chunk, last_chunk, stream);
+  if (sig == SIG_SUMI_CNT) return launch_dense_n<SIG_SUMI_CNT, 2>(a, d_args, first_chunk, last_chunk, stream);
+  if (sig == SIG_SUMF) return launch_dense_n<SIG_SUMF, 2>(a, d_args, first_chunk, last_chunk, stream);
+  if (sig == SIG_SUMI) return launch_dense_n<SIG_SUMI, 2>(a, d_args, first_chunk, last_chunk, stream);
+  if (sig == SIG_CNT) return launch_dense_n<SIG_CNT, 2>(a, d_args, first_chunk, last_chunk, stream);
+  if (sig == SIG_MEAN_MIN_MAX_F) return launch_dense_n<SIG_MEAN_MIN_MAX_F, 4>(a, d_args, first_chunk, last_chunk, stream);
+  if (a.plan.NACC <= 4) return launch_dense_n<0, 4>(a, d_args, first_chunk, last_chunk, stream);
+  return launch_dense_n<0, MAX_ACC>(a, d_args, first_chunk, last_chunk, stream);
+}
+
+void launch_key_range(plan_dev const* d_plan, int64_t nrows, int64_t sample, int is_signed, uint64_t* out, hipStream_t stream)
+{
+  struct range_init { uint64_t lo, hi; };
+  range_init const init{is_signed ? static_cast<uint64_t>(INT64_MAX) : UINT64_MAX, is_signed ? static_cast<uint64_t>(INT64_MIN) : uint64_t{0}};
+  hipLaunchKernelGGL(k_store_args<range_init>, dim3(1), dim3(1), 0, stream, init, reinterpret_cast<range_init*>(out));
+  cudf::detail::prof::scope prof_{"estimate", stream};
+  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((sample + 255) / 256, 1, 256));
+  if (is_signed) hipLaunchKernelGGL(k_key_range<true>, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, out);
+  else hipLaunchKernelGGL(k_key_range<false>, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, out);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cudf::groupby::detail

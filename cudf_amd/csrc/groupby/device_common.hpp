@@ -41,6 +41,126 @@ __global__ void k_store_args(T v, T* dst)
   *dst = v;
 }
 
+// ------------------------------------------------------------------ accumulator primitives (LDS)
+__device__ __forceinline__ uint64_t acc_identity(int op)
+{
+  switch (op) {
+    case MIN_I64: return static_cast<uint64_t>(INT64_MAX);
+    case MIN_U64: return UINT64_MAX;
+    case MIN_F64: return 0x7ff0000000000000ull;  // +inf
+    case MAX_I64: return static_cast<uint64_t>(INT64_MIN);
+    case MAX_U64: return 0;
+    case MAX_F64: return 0xfff0000000000000ull;  // -inf
+    case MUL_I64: return 1;
+    case MUL_F64: return 0x3ff0000000000000ull;  // 1.0
+    default: return 0;                            // ADD_I64 / ADD_F64
+  }
+}
+
+__device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
+{
+  switch (op) {
+    case ADD_I64: atomicAdd(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case ADD_F64: atomicAdd(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v))); break;
+    case MIN_I64: atomicMin(reinterpret_cast<long long*>(slot), static_cast<long long>(v)); break;
+    case MIN_U64: atomicMin(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case MAX_I64: atomicMax(reinterpret_cast<long long*>(slot), static_cast<long long>(v)); break;
+    case MAX_U64: atomicMax(reinterpret_cast<unsigned long long*>(slot), static_cast<unsigned long long>(v)); break;
+    case MIN_F64:
+      __hip_atomic_fetch_min(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    case MAX_F64:
+      __hip_atomic_fetch_max(reinterpret_cast<double*>(slot), __longlong_as_double(static_cast<long long>(v)),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    case ANY_U64: *slot = v; break;  // any contributing row will do: a plain store
+    case MUL_I64:
+    case MUL_F64: {
+      // no multiply atomic: compare-and-swap loop (ds_cmpst_rtn_b64), as the reference's product (device_atomics.cuh:226-337)
+      unsigned long long* p = reinterpret_cast<unsigned long long*>(slot);
+      unsigned long long old = *p, seen;
+      do {
+        seen = old;
+        unsigned long long const next =
+          op == MUL_I64 ? seen * static_cast<unsigned long long>(v)
+                        : static_cast<unsigned long long>(__double_as_longlong(__longlong_as_double(static_cast<long long>(seen)) *
+                                                                                __longlong_as_double(static_cast<long long>(v))));
+        old = atomicCAS(p, seen, next);
+      } while (old != seen);
+      break;
+    }
+  }
+}
+
+// a (op) b on accumulator bit patterns - the wave-level counterpart of lds_merge (float min / max: a NaN never beats a
+// number, as ds_min_f64 / ds_max_f64)
+__device__ __forceinline__ uint64_t combine_values(int op, uint64_t a, uint64_t b)
+{
+  auto f = [](uint64_t x) { return __longlong_as_double(static_cast<long long>(x)); };
+  auto u = [](double x) { return static_cast<uint64_t>(__double_as_longlong(x)); };
+  switch (op) {
+    case ADD_I64: return a + b;
+    case ADD_F64: return u(f(a) + f(b));
+    case MIN_I64: return static_cast<uint64_t>(min(static_cast<long long>(a), static_cast<long long>(b)));
+    case MIN_U64: return min(a, b);
+    case MAX_I64: return static_cast<uint64_t>(max(static_cast<long long>(a), static_cast<long long>(b)));
+    case MAX_U64: return max(a, b);
+    case MIN_F64: return u(fmin(f(a), f(b)));
+    case MAX_F64: return u(fmax(f(a), f(b)));
+    case MUL_I64: return a * b;
+    case MUL_F64: return u(f(a) * f(b));
+    default: return a;  // ANY_U64
+  }
+}
+
+// 12 bits per accumulator: op(4) | src(2) | pay+1 (3) | vbit+1 (3); accumulator count in bits 60..63.
+constexpr uint64_t sig_acc(int op, int src, int pay, int vbit)
+{
+  return static_cast<uint64_t>(op) | (static_cast<uint64_t>(src) << 4) | (static_cast<uint64_t>(pay + 1) << 6) |
+         (static_cast<uint64_t>(vbit + 1) << 9);
+}
+constexpr uint64_t make_sig(int n, uint64_t a0 = 0, uint64_t a1 = 0, uint64_t a2 = 0, uint64_t a3 = 0)
+{
+  return (static_cast<uint64_t>(n) << 60) | a0 | (a1 << 12) | (a2 << 24) | (a3 << 36);
+}
+constexpr int sig_n(uint64_t s) { return static_cast<int>(s >> 60); }
+constexpr int sig_op(uint64_t s, int q) { return static_cast<int>((s >> (12 * q)) & 0xf); }
+constexpr int sig_src(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 4)) & 0x3); }
+constexpr int sig_pay(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 6)) & 0x7) - 1; }
+constexpr int sig_vbit(uint64_t s, int q) { return static_cast<int>((s >> (12 * q + 9)) & 0x7) - 1; }
+
+// Signature of a plan's accumulators (0 if it does not fit the static encoding).
+inline uint64_t plan_sig(plan_dev const& p)
+{
+  if (p.NACC < 1 || p.NACC > 4) return 0;
+  uint64_t a[4] = {0, 0, 0, 0};
+  for (int q = 0; q < p.NACC; ++q) {
+    auto const& d = p.acc[q];
+    if (d.pay > 5 || d.valid_bit > 5 || d.src > 3) return 0;
+    a[q] = sig_acc(d.op, d.src, d.pay, d.valid_bit);
+  }
+  return make_sig(p.NACC, a[0], a[1], a[2], a[3]);
+}
+// hot signatures with their own instantiation
+constexpr uint64_t SIG_SUMF_CNT = make_sig(2, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1));
+constexpr uint64_t SIG_SUMI_CNT = make_sig(2, sig_acc(ADD_I64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1));
+constexpr uint64_t SIG_SUMF     = make_sig(1, sig_acc(ADD_F64, SRC_VALUE, 0, -1));
+constexpr uint64_t SIG_SUMI     = make_sig(1, sig_acc(ADD_I64, SRC_VALUE, 0, -1));
+constexpr uint64_t SIG_CNT      = make_sig(1, sig_acc(ADD_I64, SRC_ONE, -1, -1));
+// SUM + COUNT_VALID (and MEAN) of a NULLABLE column: both accumulators test the row's validity bit
+constexpr uint64_t SIG_SUMF_CNT_NULLS = make_sig(2, sig_acc(ADD_F64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0));
+constexpr uint64_t SIG_SUMI_CNT_NULLS = make_sig(2, sig_acc(ADD_I64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0));
+// C4: MEAN + MIN + MAX of a nullable float64 column -> SUM, COUNT_VALID, MIN, MAX
+constexpr uint64_t SIG_MEAN_MIN_MAX_F_NULLS =
+  make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, 0), sig_acc(ADD_I64, SRC_ONE_IF_VALID, 0, 0), sig_acc(MIN_F64, SRC_VALUE, 0, 0),
+           sig_acc(MAX_F64, SRC_VALUE, 0, 0));
+
+// the same without nulls: SUM, COUNT_ALL (as the count of MEAN), MIN, MAX
+constexpr uint64_t SIG_MEAN_MIN_MAX_F =
+  make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1), sig_acc(MIN_F64, SRC_VALUE, 0, -1),
+           sig_acc(MAX_F64, SRC_VALUE, 0, -1));
+
 // ------------------------------------------------------------------ record building from columns
 // Validity words of one row: keynulls bit c = key column c NULL; valvalid bit v = value column v valid.
 __device__ __forceinline__ void row_validity(plan_dev const& p, int64_t row, uint32_t& keynulls, uint32_t& valvalid)

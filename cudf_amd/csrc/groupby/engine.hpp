@@ -176,6 +176,20 @@ struct agg_args {
   int32_t nitems;
 };
 
+// Dense integer keys (one plain 8-byte integer key column whose values span a small range): direct addressing instead of
+// hashing and probing. index = key - lo in [0, range); scrambled = (index * mult) mod 2^bits is a bijection on `bits`
+// bits (mult odd) that spreads runs and strides of keys over the partitions; partition = its top log2P bits, table
+// slot = the remaining low bits. A table holds no key words and no state words: slot s of partition d IS the key
+// lo + ((d << (bits - log2P) | s) * mult_inv mod 2^bits).
+struct dense_map {
+  uint64_t lo;
+  uint64_t range;
+  uint32_t mult;
+  uint32_t mult_inv;  // mult * mult_inv = 1 mod 2^32
+  int32_t bits;       // 2^bits >= range, bits <= 30
+  int32_t log2P;
+};
+
 struct part_args {
   plan_dev plan;
   part_geom geom;
@@ -220,7 +234,47 @@ struct part_args {
   int32_t* hot_count;
   // diagnostics (CUDF_AMD_GB_STAMPS=1): per-workgroup cycle totals of the tile phases, 8 x u64 per workgroup
   unsigned long long* stamps;
+  // Dense integer keys (write-combining scatter of plain 16-byte records): partition digit from the dense map; a key
+  // outside [lo, lo + range) raises bit 2 of *overflow (the sampled range was wrong: the caller redoes the call by hash).
+  int32_t use_dense;
+  dense_map dense;
 };
+
+// Chunked pipeline: the input rows are partitioned one CHUNK at a time into a reused ring of regions
+// that stays resident in the 256 MiB Infinity Cache, and each chunk is aggregated before the next one overwrites it.
+// A chunk's row range is a by-value kernel parameter (the device-resident part_args stay as they are).
+struct chunk_range {
+  int64_t begin, end;  // rows [begin, end) of the input columns; end == 0: all rows (no chunking)
+};
+
+// Aggregation of dense-key records into direct-address LDS tables (dense_kernels.hip). Work item d = partition d reads the
+// regions (d, w), w < slices, of an optimistic scatter. The table IMAGE (the accumulator arrays as they lie in LDS) of
+// every partition is carried across the chunks of a call in `tables`; the last chunk dumps partial records
+// [key | accumulators] for k_finalize: item d at out_records[d * slots * PU ...], count in out_count[d].
+struct dense_agg_args {
+  plan_dev plan;
+  dense_map map;
+  uint64_t const* records;
+  int32_t const* region_count;
+  int64_t region_cap;
+  int32_t slices;
+  int32_t slots;        // per table: 1 << (bits - log2P)
+  int32_t image_bytes;  // multiple of 16
+  int32_t occ_acc;      // accumulator that counts every row (SRC_ONE): a slot is occupied iff it is > 0; -1: occupancy bitmap
+  uint64_t* tables;     // [P][image_bytes / 8]
+  uint64_t* out_records;
+  int32_t* out_count;
+  int32_t* overflow;
+  int32_t nitems;
+  int32_t block;
+};
+std::size_t dense_table_bytes(plan_dev const& plan, int slots);  // LDS image of one table (multiple of 16)
+int dense_occ_acc(plan_dev const& plan);                          // dense_agg_args::occ_acc of a plan
+void launch_aggregate_dense(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream);
+void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t stream);
+// Minimum and maximum of a plain 8-byte integer key column over the strided sample of launch_estimate (signed compare
+// for signed keys): out[0] = min, out[1] = max as bit patterns. `out` must hold {max value, min value} of the ordering before.
+void launch_key_range(plan_dev const* d_plan, int64_t nrows, int64_t sample, int is_signed, uint64_t* out, hipStream_t stream);
 
 // Launchers (partition_kernels.hip, aggregate_kernels.hip). All asynchronous on `stream`. Kernel arguments live in DEVICE memory (`d_args`,
 // one slot per launch family, written by a one-thread kernel on the same stream): passed by value, the
@@ -229,7 +283,7 @@ struct part_args {
 void store_args(part_args const& a, part_args* d_args, hipStream_t stream);
 void launch_partition_hist(part_args const& a, part_args const* d_args, hipStream_t stream);
 void launch_partition_scan(part_args const& a, part_args const* d_args, hipStream_t stream);
-void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream);
+void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream, chunk_range chunk = {0, 0});
 void launch_aggregate(agg_args const& a, agg_args* d_args, hipStream_t stream);
 // Gathers `total` groups (items' partial records, prefix[] = exclusive scan of the item counts) into the
 // typed output columns.
@@ -260,7 +314,8 @@ std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g);
 int aggregate_slot_bytes(plan_dev const& plan);
 std::size_t partition_lds_bytes(plan_dev const& plan, part_geom const& g);
 // write-combining scatter: can records of U units be partitioned P ways with granules of G records?
-bool partition_wc_fits(int U, int P, int G);
+// (block = 512: two workgroups per CU, each within 80 KiB)
+bool partition_wc_fits(int U, int P, int G, int block = 1024);
 // LDS bytes of the heavy-hitter table; byte offset of it behind the write-combining scatter's own LDS
 std::size_t partition_hot_lds_bytes();
 

@@ -573,6 +573,13 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   int32_t* d_overflow = sc.alloc<int32_t>(1);
 
   std::vector<uint64_t> hot_keys;  // heavy hitters found in the sample (aggregated inside the scatter workgroups)
+  // Dense-key candidate: one plain 8-byte integer key column, one plain 8-byte value column, no ARGMIN / ARGMAX
+  bool const dense_signed    = p.cols[0].cls == cudf::detail::CLS_SINT;
+  bool const dense_candidate = p.simple && p.KU == 1 && p.NPAY == 1 && p.narg == 0 && n >= (int64_t{1} << 22) &&
+                               env_i64("CUDF_AMD_GB_DENSE", 1) != 0;
+  bool allow_dense   = dense_candidate;
+  uint64_t h_range[2] = {0, 0};  // sample minimum / maximum of the key column (bit patterns)
+  int64_t final_cap  = 0;        // records per work item in `partial` (0: ag.cap)
   // ---- distinct-count estimate on a strided sample (skipped when n already fits one table)
   double est_groups = static_cast<double>(n);
   if (n > ag.fill_limit) {
@@ -587,6 +594,13 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
                               env_i64("CUDF_AMD_GB_HOT", 1) != 0;
     uint32_t* hot_buckets = hot_eligible ? sc.alloc<uint32_t>(HOT_BUCKETS) : nullptr;
     launch_estimate(p, d_plan, n, sample, bitmap, bits_log2, d_set, hot_buckets, s);
+    // Dense integer keys ("Dense keys"): minimum and maximum of the key column over the same sample
+    uint64_t* d_range = nullptr;
+    if (dense_candidate) {
+      d_range = sc.alloc<uint64_t>(2);
+      launch_key_range(d_plan, n, sample, dense_signed ? 1 : 0, d_range, s);
+      CUDF_HIP_TRY(hipMemcpyAsync(h_range, d_range, 16, hipMemcpyDeviceToHost, s));
+    }
     // Heavy hitters (plain int64 key + one plain value, SUM / COUNT): a key above ~0.05 % of the rows overflows its
     // regions of the optimistic partition, and a key with percents of the rows leaves one workgroup aggregating its
     // partition alone. Keys seen min_count times in the sample are aggregated inside the scatter workgroups instead.
@@ -764,6 +778,124 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         nitems  = next;
       }
     } else {
+      // ---------------- path D: dense integer keys -> direct-address LDS tables, chunked through the Infinity Cache
+      final_cap = 0;
+      if (allow_dense && forced_p == 0 && hot_keys.empty() && !forced_exact) {
+        // key range from the sample, widened by a margin (the sample's extremes of a dense column miss the true ones by
+        // about range / sample); a key outside [lo, lo + range) voids the attempt (overflow bit 2) and the call is redone by hash
+        uint64_t const width  = h_range[1] - h_range[0];  // exact in two's complement for either ordering
+        uint64_t const margin = std::clamp<uint64_t>(width / 64, 4096, uint64_t{1} << 26);
+        uint64_t lo, hi;
+        if (dense_signed) {
+          int64_t const l = static_cast<int64_t>(h_range[0]), h = static_cast<int64_t>(h_range[1]);
+          lo = static_cast<uint64_t>(l < INT64_MIN + static_cast<int64_t>(margin) ? INT64_MIN : l - static_cast<int64_t>(margin));
+          hi = static_cast<uint64_t>(h > INT64_MAX - static_cast<int64_t>(margin) ? INT64_MAX : h + static_cast<int64_t>(margin));
+        } else {
+          lo = h_range[0] < margin ? 0 : h_range[0] - margin;
+          hi = h_range[1] > UINT64_MAX - margin ? UINT64_MAX : h_range[1] + margin;
+        }
+        uint64_t const range = hi - lo + 1;  // (0 if the keys span the whole type: fails the test below)
+        int bits = 14;
+        while (bits < 31 && (uint64_t{1} << bits) < range) ++bits;
+        double const unit_bytes = static_cast<double>(dense_table_bytes(p, 4096)) / 4096.0;  // LDS bytes per key of the range
+        // tables of ~32 KiB (two 1024-thread workgroups per CU), at least 256 and at most 1024 of them; the carried table
+        // images of all partitions stay below 32 MiB (they travel to LDS and back once per chunk)
+        int log2P = 8;
+        while (log2P < 10 && std::ldexp(unit_bytes, bits - log2P) > 32.0 * 1024) ++log2P;
+        if (env_i64("CUDF_AMD_GB_DENSE_LOG2P", 0) > 0) log2P = static_cast<int>(env_i64("CUDF_AMD_GB_DENSE_LOG2P", 0));
+        int const slots           = 1 << (bits - log2P);
+        std::size_t const image   = dense_table_bytes(p, slots);
+        bool const dense_ok = width <= (uint64_t{1} << 30) && range != 0 && range <= (uint64_t{1} << bits) && bits <= 30 &&
+                              image <= 150 * 1024 && static_cast<double>(image) * (1 << log2P) <= 32.0 * 1024 * 1024 &&
+                              static_cast<double>(range) <= 8.0 * std::max(est_groups, 4096.0);
+        int64_t const PD = int64_t{1} << log2P;
+        // scatter workgroups: one of 1024 threads per CU (128-byte granules up to 512 partitions), or - CUDF_AMD_GB_SCATTER_BLOCK=512 -
+        // two of 512 threads per CU with 64-byte granules, so that one's LDS phases overlap the other's memory phases
+        int const SB     = env_i64("CUDF_AMD_GB_SCATTER_BLOCK", 1024) == 512 ? 512 : 1024;
+        int const GD     = static_cast<int>(env_i64("CUDF_AMD_GB_WC_G", (PD > 512 || SB == 512) ? 4 : 8));
+        if (dense_ok && partition_wc_fits(RU, static_cast<int>(PD), GD, SB)) {
+          _last_path = hash_path::DENSE_DIRECT;
+          dense_map dm{};
+          dm.lo    = lo;
+          dm.range = range;
+          dm.mult  = 0x9E3779B1u;  // odd: index -> (index * mult) mod 2^bits is a bijection
+          uint32_t inv = dm.mult;  // Newton: inv = mult^-1 mod 2^32
+          for (int it = 0; it < 5; ++it) inv *= 2u - dm.mult * inv;
+          dm.mult_inv = inv;
+          dm.bits     = bits;
+          dm.log2P    = log2P;
+          // chunks: a multiple of one tile per workgroup; the ring of a chunk's regions stays in the Infinity Cache
+          int64_t const S        = 256 * (1024 / SB), tile_rows = 5 * SB;
+          int64_t const quantum  = S * tile_rows;
+          int64_t const want     = std::max<int64_t>(quantum, env_i64("CUDF_AMD_GB_CHUNK_ROWS", 8 * quantum));
+          int64_t const nchunks  = env_i64("CUDF_AMD_GB_CHUNKED", 0) != 0 ? std::max<int64_t>(1, (n + want - 1) / want) : 1;
+          int64_t const C        = ((n + nchunks - 1) / nchunks + quantum - 1) / quantum * quantum;
+          double const cell_mean = static_cast<double>(std::min(C, n)) / static_cast<double>(S * PD);
+          double const keys_per_p = std::max(1.0, 0.5 * est_groups / static_cast<double>(PD));
+          double const rel_sigma  = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, cell_mean));
+          int64_t const capR      = (static_cast<int64_t>(cell_mean * (1.0 + 6.0 * std::min(rel_sigma, 1.0)) + 16.0) + 7) / 8 * 8;
+          part_args pa{};
+          pa.plan          = p;
+          pa.geom.nseg     = 1;
+          pa.geom.slices   = static_cast<int32_t>(S);
+          pa.geom.P        = static_cast<int32_t>(PD);
+          pa.geom.shift    = 0;
+          pa.geom.block    = SB;
+          pa.geom.tile_rows = static_cast<int32_t>(tile_rows);
+          pa.from_columns  = 1;
+          pa.nrows         = n;
+          pa.optimistic    = 1;
+          pa.region_cap    = capR;
+          pa.region_count  = sc.alloc<int32_t>(static_cast<size_t>(S * PD));
+          pa.overflow      = d_overflow;
+          pa.out_records   = sc.alloc<uint64_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR) * RU);
+          pa.wc_granule    = GD;
+          pa.cyclic_tiles  = 1;
+          pa.use_dense     = 1;
+          pa.dense         = dm;
+          part_args* d_pa  = sc.alloc<part_args>(1);
+          store_args(pa, d_pa, s);
+          dense_agg_args da{};
+          da.plan         = p;
+          da.map          = dm;
+          da.records      = pa.out_records;
+          da.region_count = pa.region_count;
+          da.region_cap   = capR;
+          da.slices       = static_cast<int32_t>(S);
+          da.slots        = slots;
+          da.image_bytes  = static_cast<int32_t>(image);
+          da.occ_acc      = dense_occ_acc(p);
+          da.tables       = sc.alloc<uint64_t>(static_cast<size_t>(PD) * image / 8);
+          nitems          = static_cast<int32_t>(PD);
+          partial         = sc.alloc<uint64_t>(static_cast<size_t>(PD) * slots * PU);
+          d_count         = sc.alloc<int32_t>(nitems);
+          da.out_records  = partial;
+          da.out_count    = d_count;
+          da.overflow     = d_overflow;
+          da.nitems       = nitems;
+          da.block        = 1024;
+          dense_agg_args* d_da = sc.alloc<dense_agg_args>(1);
+          store_args(da, d_da, s);
+          for (int64_t c = 0; c < nchunks; ++c) {
+            chunk_range const cr{c * C, std::min(n, (c + 1) * C)};
+            launch_partition_scatter(pa, d_pa, s, cr);
+            launch_aggregate_dense(da, d_da, c == 0, c == nchunks - 1, s);
+          }
+          final_cap          = slots;
+          int32_t const h_ov = overflow_and_counts();
+          if (env_i64("CUDF_AMD_DEBUG", 0))
+            fprintf(stderr, "[cudf_amd] dense keys: lo=%lld range=%llu bits=%d P=%ld slots=%d image=%zu B chunks=%ld x %ld rows capR=%ld overflow=%d\n",
+                    (long long)lo, (unsigned long long)range, bits, (long)PD, slots, image, (long)nchunks, (long)C, (long)capR, h_ov);
+          if (h_ov == 0) break;
+          // a region overflowed (skewed or clustered keys) or a key lay outside the sampled range: redo by hash
+          allow_dense = false;
+          final_cap   = 0;
+          sc.bufs.clear();
+          d_overflow = sc.alloc<int32_t>(1);
+          --attempt;
+          continue;
+        }
+      }
       // ---------------- path P: radix-partition raw records on hash bits, then one LDS table per partition
       _last_path = hash_path::PARTITIONED_LDS;
       auto pow2_at_least = [](double x) {
@@ -1091,7 +1223,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     fin.out[fin.nout++] = d;
     res_cols.push_back(std::move(col));
   }
-  launch_finalize(fa, sc.alloc<finalize_args>(1), partial, ag.cap, d_prefix, nitems, G, s);
+  launch_finalize(fa, sc.alloc<finalize_args>(1), partial, final_cap > 0 ? final_cap : ag.cap, d_prefix, nitems, G, s);
   std::vector<int32_t> h_nulls(MAX_OUT, 0);
   CUDF_HIP_TRY(hipMemcpyAsync(h_nulls.data(), d_nulls, sizeof(int32_t) * MAX_OUT, hipMemcpyDeviceToHost, s));
   CUDF_HIP_TRY(hipStreamSynchronize(s));

@@ -387,8 +387,10 @@ constexpr int WC_SRC_SIMPLE = 0;   // plain 8-byte columns
 constexpr int WC_SRC_COLUMNS = 1;  // any fixed-width columns, nulls (records built column-at-a-time)
 constexpr int WC_SRC_RECORDS = 2;  // records: one contiguous range, or a strided list of level-1 regions
 // HOT: heavy-hitter keys (part_args::hot_*) are aggregated in a small LDS table and never scattered.
-template <int UT, int RPT, int G, int SRC, bool HOT = false>
-__global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* __restrict__ ap)
+// DENSE: the partition digit comes from the dense key map (part_args::dense) instead of the key hash.
+// `chunk`: rows [begin, end) of the input columns (end == 0: all rows) - the chunked pipeline partitions one chunk per launch.
+template <int UT, int RPT, int G, int SRC, bool HOT = false, bool DENSE = false>
+__global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* __restrict__ ap, chunk_range chunk)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   part_args const& a = *ap;
@@ -433,8 +435,9 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
     // every workgroup sees the whole row range. With a contiguous chunk per workgroup, sorted or clustered keys put a
     // chunk's rows into a few partitions and overflowed their regions.
     if (a.cyclic_tiles) {
-      sr.begin = min(a.nrows, static_cast<int64_t>(blockIdx.x) * (RPT * B));
-      sr.end   = a.nrows;
+      int64_t const cb = chunk.end > 0 ? chunk.begin : 0, ce = chunk.end > 0 ? chunk.end : a.nrows;
+      sr.begin = min(ce, cb + static_cast<int64_t>(blockIdx.x) * (RPT * B));
+      sr.end   = ce;
     }
   }
   uint64_t const* in_records = a.in_records;
@@ -500,7 +503,18 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
     }
     }
   };
+  [[maybe_unused]] uint64_t const dense_lo = a.dense.lo, dense_range = a.dense.range;
+  [[maybe_unused]] uint32_t const dense_mult = a.dense.mult, dense_mask = (1u << a.dense.bits) - 1u;
+  [[maybe_unused]] int const dense_shift = a.dense.bits - a.dense.log2P;
   auto digit_of = [&](uint64_t const (&rec)[UT]) {
+    if constexpr (DENSE) {
+      uint64_t idx = rec[0] - dense_lo;
+      if (idx >= dense_range) {  // the sampled key range was wrong: this call is void (redone by hash)
+        atomicOr(a.overflow, 4);
+        idx = 0;
+      }
+      return ((static_cast<uint32_t>(idx) * dense_mult) & dense_mask) >> dense_shift;
+    }
     uint64_t h = 0x9e3779b97f4a7c15ull;
 #pragma unroll
     for (int u = 0; u < KUM; ++u)
@@ -593,59 +607,63 @@ static void launch_scatter_t(part_args const& a, part_args const* d_args, hipStr
 
 // Tile rows per thread and granule of the write-combining kernel for a record width; 0 = no instantiation.
 int wc_rpt(int U) { return U == 2 ? 5 : U == 3 ? 4 : U == 4 ? 3 : 0; }
-bool partition_wc_fits(int U, int P, int G)
+bool partition_wc_fits(int U, int P, int G, int block)
 {
   int const rpt = wc_rpt(U);
   // 24-byte records: 192-byte granules (G = 8), or 96-byte ones (G = 4: whole 32-byte sectors) where the carry area of
   // G = 8 does not fit; 32-byte records: 128-byte granules
   if (rpt == 0 || (G != 4 && G != 8) || (U == 4 && G != 4)) return false;
   // static LDS of the kernel (region prefix list, abort flag) is ~1.1 KB
-  return cudf::detail::wc_scatter_lds_bytes(static_cast<std::size_t>(1024) * rpt, P, G, U) + 1200 <= 160 * 1024;
+  return P <= 2 * block && cudf::detail::wc_scatter_lds_bytes(static_cast<std::size_t>(block) * rpt, P, G, U) + 1200 <= (block == 1024 ? 160 : 80) * 1024;
 }
 
 std::size_t partition_hot_lds_bytes() { return static_cast<std::size_t>(HOT_SLOTS) * (8 + 8 + 4); }
 
-template <int UT, int RPT, int G, int SRC, bool HOT = false>
-static void launch_scatter_wc_src(part_args const& a, part_args const* d_args, hipStream_t stream)
+template <int UT, int RPT, int G, int SRC, bool HOT = false, bool DENSE = false>
+static void launch_scatter_wc_src(part_args const& a, part_args const* d_args, hipStream_t stream, chunk_range chunk)
 {
   part_geom g  = a.geom;
   g.tile_rows  = g.block * RPT;
   auto const lds = cudf::detail::wc_scatter_lds_bytes(g.tile_rows, g.P, G, UT) + (HOT ? partition_hot_lds_bytes() : 0);
   CUDF_EXPECTS(lds + 1200 <= 160 * 1024, "write-combining partition kernel: LDS budget exceeded");
+  CUDF_EXPECTS(!HOT || g.block == 1024, "heavy hitters: 1024-thread scatter workgroups");
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SRC, HOT>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SRC, HOT, DENSE>));
     attr_set = true;
   }
   cudf::detail::prof::scope prof_{"partition_scatter", stream};
-  hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SRC, HOT>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args);
+  hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SRC, HOT, DENSE>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args, chunk);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
 template <int UT, int RPT, int G>
-static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hipStream_t stream)
+static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hipStream_t stream, chunk_range chunk)
 {
-  if (!a.from_columns) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_RECORDS>(a, d_args, stream);
+  if (!a.from_columns) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_RECORDS>(a, d_args, stream, chunk);
   if constexpr (UT == 2) {
-    if (a.plan.simple && a.hot_n > 0) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE, true>(a, d_args, stream);
+    if (a.plan.simple && a.use_dense) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE, false, true>(a, d_args, stream, chunk);
+    if (a.plan.simple && a.hot_n > 0) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE, true>(a, d_args, stream, chunk);
   }
-  if (a.plan.simple) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE>(a, d_args, stream);
-  return launch_scatter_wc_src<UT, RPT, G, WC_SRC_COLUMNS>(a, d_args, stream);
+  if (a.plan.simple) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE>(a, d_args, stream, chunk);
+  return launch_scatter_wc_src<UT, RPT, G, WC_SRC_COLUMNS>(a, d_args, stream, chunk);
 }
 
-void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream)
+void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream, chunk_range chunk)
 {
+  CUDF_EXPECTS(chunk.end == 0 || (a.wc_granule != 0 && a.from_columns && a.cyclic_tiles), "chunked scatter: write-combining kernel over the input columns only");
+  CUDF_EXPECTS(!a.use_dense || (a.wc_granule != 0 && a.plan.simple && a.plan.KU + a.plan.NPAY == 2), "dense keys: plain 16-byte records only");
   CUDF_EXPECTS(a.geom.P <= 2 * a.geom.block, "partition fan-out exceeds 2x the block size");
   int const U       = a.plan.KU + a.plan.NPAY;
   bool const simple = a.plan.simple && a.from_columns;
   if (a.wc_granule != 0) {
-    CUDF_EXPECTS(a.optimistic && a.geom.block == 1024 && partition_wc_fits(U, a.geom.P, a.wc_granule),
+    CUDF_EXPECTS(a.optimistic && (a.geom.block == 1024 || a.geom.block == 512) && partition_wc_fits(U, a.geom.P, a.wc_granule, a.geom.block),
                  "write-combining scatter: optimistic regions, records of 2-4 units, carry area within the LDS");
-    if (U == 2 && a.wc_granule == 4) launch_scatter_wc_t<2, 5, 4>(a, d_args, stream);
-    else if (U == 2) launch_scatter_wc_t<2, 5, 8>(a, d_args, stream);
-    else if (U == 3 && a.wc_granule == 4) launch_scatter_wc_t<3, 4, 4>(a, d_args, stream);
-    else if (U == 3) launch_scatter_wc_t<3, 4, 8>(a, d_args, stream);
-    else launch_scatter_wc_t<4, 3, 4>(a, d_args, stream);
+    if (U == 2 && a.wc_granule == 4) launch_scatter_wc_t<2, 5, 4>(a, d_args, stream, chunk);
+    else if (U == 2) launch_scatter_wc_t<2, 5, 8>(a, d_args, stream, chunk);
+    else if (U == 3 && a.wc_granule == 4) launch_scatter_wc_t<3, 4, 4>(a, d_args, stream, chunk);
+    else if (U == 3) launch_scatter_wc_t<3, 4, 8>(a, d_args, stream, chunk);
+    else launch_scatter_wc_t<4, 3, 4>(a, d_args, stream, chunk);
     return;
   }
   switch (next_ut(U)) {

@@ -13,6 +13,7 @@ class HashPath(IntEnum):
     LDS_SINGLE_PASS = 1
     PARTITIONED_LDS = 2
     GLOBAL_TABLE = 3
+    DENSE_DIRECT = 4
 
 
 class GroupByRequest:

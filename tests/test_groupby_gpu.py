@@ -54,7 +54,9 @@ def test_groupby_errors(G):
 def _check_against_oracle(G, O, keys, requests, include=False, expect_path=None):
     got = kat.sort_groups(*G.groupby(keys, requests, include_null_keys=include))
     if expect_path is not None:
-        assert G.last_path.name == expect_path, G.last_path
+        # dense integer keys may take the direct-address tables (DENSE_DIRECT) wherever the partitioned path is expected
+        ok = (expect_path, "DENSE_DIRECT") if expect_path == "PARTITIONED_LDS" else (expect_path,)
+        assert G.last_path.name in ok, G.last_path
     exp = kat.sort_groups(*O.groupby(keys, requests, include_null_keys=include))
     assert len(got[0]) == len(exp[0])
     for a, e in zip(got[0], exp[0]):
@@ -284,6 +286,41 @@ def test_optimistic_partition_and_its_fallback(G, oracle):
     _check_against_oracle(G, oracle, [k2], [(v, ["sum", "count_all", "max"])], expect_path="PARTITIONED_LDS")
 
 
+@pytest.mark.parametrize("lo,groups,vt", [(0, 1_000_000, "float64"), (-5_000_000_000, 300_000, "int64"), (2**62, 60_000, "float64")])
+def test_dense_keys_direct_address(G, oracle, monkeypatch, lo, groups, vt):
+    """One plain int64 key column spanning a small range, n >= 4M: direct-address LDS tables (no hash, no probe, keys
+    rebuilt from the slot index). Same call with CUDF_AMD_GB_DENSE=0 must take the hash tables and agree."""
+    rng = np.random.default_rng(71)
+    n = 4_500_000
+    k = rng.integers(0, groups, n, dtype=np.int64) + lo
+    v = rng.random(n) if vt == "float64" else rng.integers(-10**6, 10**6, n, dtype=np.int64)
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_valid", "min", "max", "mean"])], expect_path="DENSE_DIRECT")
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE", "0")
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_valid"])], expect_path="PARTITIONED_LDS")
+    assert G.last_path.name == "PARTITIONED_LDS"
+
+
+def test_dense_keys_chunked_and_fallbacks(G, oracle, monkeypatch):
+    """The chunked form of the dense path (table images carried from chunk to chunk); a key outside the sampled range and a
+    sparse key column must fall back to the hash tables."""
+    rng = np.random.default_rng(72)
+    n = 6_000_000
+    k = rng.integers(0, 500_000, n, dtype=np.int64)
+    v = rng.random(n)
+    monkeypatch.setenv("CUDF_AMD_GB_CHUNKED", "1")
+    monkeypatch.setenv("CUDF_AMD_GB_CHUNK_ROWS", str(256 * 5120))  # 5 chunks
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all", "max"])], expect_path="DENSE_DIRECT")
+    monkeypatch.delenv("CUDF_AMD_GB_CHUNKED")
+    monkeypatch.delenv("CUDF_AMD_GB_CHUNK_ROWS")
+    k2 = k.copy()
+    k2[n // 2 + 12345] = 10**12  # one outlier the sample will not see: the attempt is void, the call is redone by hash
+    _check_against_oracle(G, oracle, [k2], [(v, ["sum", "count_all"])], expect_path="PARTITIONED_LDS")
+    assert G.last_path.name == "PARTITIONED_LDS"
+    k3 = k * 1_000_003  # sparse keys: never dense
+    _check_against_oracle(G, oracle, [k3], [(v, ["sum", "count_all"])], expect_path="PARTITIONED_LDS")
+    assert G.last_path.name == "PARTITIONED_LDS"
+
+
 def test_two_level_partition_forced(G, oracle, monkeypatch):
     """Forces the two-level radix partition (C4's regime) at a size the oracle can check."""
     rng = np.random.default_rng(13)
@@ -311,7 +348,7 @@ def test_large_properties(G):
     req = gb.GroupByRequest(cudf_amd.Column.from_torch(v), [agg.sum(), agg.count(NullPolicy.EXCLUDE), agg.min(), agg.max(), agg.mean()])
     grp = gb.GroupBy(cudf_amd.Table([cudf_amd.Column.from_torch(k)]))
     keys, res = grp.aggregate([req], stream=torch.cuda.current_stream())
-    assert grp.last_path.name == "PARTITIONED_LDS"
+    assert grp.last_path.name in ("PARTITIONED_LDS", "DENSE_DIRECT")
     kk = keys.columns()[0].to_numpy()[0]
     s, c, mn, mx, me = [x.to_numpy()[0] for x in res[0].columns()]
     assert len(kk) == len(np.unique(kk)) == int(torch.unique(k).numel())
