@@ -230,7 +230,9 @@ def main():
             if rank == 0:
                 os.write(json_fd, (json.dumps(build_line(state["pre"], state["pre_error"])) + "\n").encode())
         if timed_out:
-            os._exit(0)
+            # the primary line is out; a collective that never returned is still a failure of the run: exit non-zero so that
+            # drivers looking at the return code see it (no restart / re-exec of a process that has touched the GPU)
+            os._exit(3)
 
     watchdog_s = int(os.environ.get("BENCH_VARIANT_TIMEOUT_S", "300"))
     if world > 1 or force_dist:

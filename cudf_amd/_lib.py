@@ -13,7 +13,8 @@ class ColumnView(C.Structure):
 
 
 class AggregationRequest(C.Structure):
-    _fields_ = [("values", ColumnView), ("kinds", C.POINTER(C.c_int32)), ("num_kinds", C.c_int32)]
+    _fields_ = [("values", ColumnView), ("kinds", C.POINTER(C.c_int32)), ("num_kinds", C.c_int32),
+                ("params", C.POINTER(C.c_int32))]
 
 
 # Every symbol declared in include/cudf_amd_c.h: (restype, argtypes)
@@ -33,6 +34,8 @@ SYMBOLS = {
     "cudf_amd_table_num_columns": (C.c_int32, [_P]),
     "cudf_amd_table_num_rows": (C.c_int32, [_P]),
     "cudf_amd_table_column": (C.c_int, [_P, C.c_int32, C.POINTER(ColumnView)]),
+    "cudf_amd_table_column_num_children": (C.c_int32, [_P, C.c_int32]),
+    "cudf_amd_table_column_child": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(ColumnView)]),
     "cudf_amd_table_free": (None, [_P]),
     "cudf_amd_groupby_aggregate": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.c_int32, C.c_int32,
                                              C.POINTER(AggregationRequest), C.c_int32, _P, C.POINTER(_P),
@@ -93,6 +96,8 @@ def check(status):
         raise TypeError(msg)
     if status == 5:
         raise MemoryError(msg)
+    if status == 7:
+        raise IndexError(msg)
     raise CudfAmdError(msg)
 
 

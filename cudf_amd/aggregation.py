@@ -29,18 +29,27 @@ class Kind(IntEnum):
 
 
 class Aggregation:
-    def __init__(self, kind: Kind):
+    def __init__(self, kind: Kind, param: int = None):
         self._kind = Kind(kind)
+        self._param = param  # ddof of VARIANCE / STD, n of NTH_ELEMENT (cudf_amd_aggregation_request.params)
 
     def kind(self) -> Kind:
         return self._kind
 
+    def param(self, default: int = 0) -> int:
+        return default if self._param is None else int(self._param)
+
     def __repr__(self):
-        return f"Aggregation({self._kind.name})"
+        return f"Aggregation({self._kind.name})" if self._param is None else f"Aggregation({self._kind.name}, {self._param})"
 
 
 def sum():
     return Aggregation(Kind.SUM)
+
+
+def sum_with_overflow():
+    # pylibcudf.aggregation.sum_with_overflow: struct {sum, overflow} (aggregation.pyi; cudf::make_sum_overflow_aggregation)
+    return Aggregation(Kind.SUM_OVERFLOW)
 
 
 def product():
@@ -69,11 +78,11 @@ def mean():
 
 
 def variance(ddof: int = 1):
-    return Aggregation(Kind.VARIANCE)
+    return Aggregation(Kind.VARIANCE, int(ddof))
 
 
 def std(ddof: int = 1):
-    return Aggregation(Kind.STD)
+    return Aggregation(Kind.STD, int(ddof))
 
 
 def median():
@@ -89,7 +98,7 @@ def argmin():
 
 
 def nth_element(n: int, null_handling: NullPolicy = NullPolicy.INCLUDE):
-    return Aggregation(Kind.NTH_ELEMENT)
+    return Aggregation(Kind.NTH_ELEMENT, int(n))
 
 
 def m2():

@@ -50,7 +50,7 @@ class _TableHandle:
 
 class Column:
     def __init__(self, dtype: DataType, size: int, data_ptr, mask_ptr=None, null_count: int = 0, offset: int = 0,
-                 owner=None):
+                 owner=None, children=None):
         self._dtype = dtype
         self._size = int(size)
         self._data = int(data_ptr or 0)
@@ -58,6 +58,7 @@ class Column:
         self._null_count = int(null_count)
         self._offset = int(offset)
         self._owner = owner  # keeps the underlying memory alive
+        self._children = list(children or [])  # STRUCT columns (SUM_OVERFLOW: [sum, overflow])
 
     # ---- pylibcudf.Column accessors
     def type(self) -> DataType:
@@ -80,6 +81,15 @@ class Column:
 
     def nullable(self) -> bool:
         return self._mask != 0
+
+    def num_children(self) -> int:
+        return len(self._children)
+
+    def child(self, i: int) -> "Column":
+        return self._children[i]
+
+    def children(self):
+        return list(self._children)
 
     def _view(self) -> _lib.ColumnView:
         return _lib.ColumnView(int(self._dtype.id()), self._size, self._data or None, self._mask or None,
@@ -130,8 +140,14 @@ class Column:
 
     # ---- host transfer
     def to_numpy(self):
-        """Returns (data, valid_or_None) on the host."""
+        """Returns (data, valid_or_None) on the host. A STRUCT column returns the tuple of its children's data."""
         lib = _lib.load()
+        if self._children:
+            data = tuple(c.to_numpy()[0] for c in self._children)
+            valid = None
+            if self._mask:
+                valid = Column(DataType(TypeId.INT8), self._size, 0, self._mask, self._null_count, self._offset, self._owner)._valid_bits()
+            return data, valid
         npdt = self._dtype.numpy_dtype()
         raw_dt = np.uint8 if npdt == np.bool_ else npdt
         out = np.empty(self._size, dtype=raw_dt)
@@ -151,6 +167,16 @@ class Column:
         if npdt == np.bool_:
             out = out != 0
         return out, valid
+
+    def _valid_bits(self):
+        lib = _lib.load()
+        nwords = (self._offset + self._size + 31) // 32
+        words = np.empty(max(nwords, 1), dtype=np.uint32)
+        if nwords:
+            _lib.check(lib.cudf_amd_memcpy(words.ctypes.data, C.c_void_p(self._mask), nwords * 4, 1, None))
+        _lib.check(lib.cudf_amd_stream_synchronize(None))
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+        return bits[self._offset:self._offset + self._size].astype(bool)
 
     # ---- zero-copy interop (torch.as_tensor / cupy / numba read this protocol)
     @property
@@ -203,6 +229,12 @@ class Table:
         for i in range(lib.cudf_amd_table_num_columns(handle)):
             v = _lib.ColumnView()
             _lib.check(lib.cudf_amd_table_column(handle, i, C.byref(v)))
+            children = []
+            for j in range(lib.cudf_amd_table_column_num_children(handle, i)):
+                cv = _lib.ColumnView()
+                _lib.check(lib.cudf_amd_table_column_child(handle, i, j, C.byref(cv)))
+                children.append(Column(DataType(TypeId(cv.type_id), cv.scale), cv.size, cv.data, cv.null_mask, cv.null_count,
+                                       cv.offset, owner))
             cols.append(Column(DataType(TypeId(v.type_id), v.scale), v.size, v.data, v.null_mask, v.null_count,
-                               v.offset, owner))
+                               v.offset, owner, children))
         return Table(cols)

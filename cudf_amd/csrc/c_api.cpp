@@ -17,8 +17,10 @@
 #include <algorithm>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <optional>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 struct cudf_amd_table_s {
@@ -59,6 +61,9 @@ cudf_amd_status guarded(F&& f)
   } catch (std::invalid_argument const& e) {
     g_last_error = e.what();
     return CUDF_AMD_INVALID_ARGUMENT;
+  } catch (std::out_of_range const& e) {
+    g_last_error = e.what();
+    return CUDF_AMD_OUT_OF_RANGE;
   } catch (cudf::logic_error const& e) {
     g_last_error = e.what();
     return CUDF_AMD_LOGIC_ERROR;
@@ -92,11 +97,12 @@ cudf::table_view to_table(cudf_amd_column_view const* cols, int32_t n)
 }
 hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
-std::unique_ptr<cudf::groupby_aggregation> make_agg(int32_t kind)
+std::unique_ptr<cudf::groupby_aggregation> make_agg(int32_t kind, int32_t const* param)
 {
   using A = cudf::aggregation;
   switch (kind) {
     case A::SUM: return cudf::make_sum_aggregation<cudf::groupby_aggregation>();
+    case A::SUM_OVERFLOW: return cudf::make_sum_overflow_aggregation<cudf::groupby_aggregation>();
     case A::PRODUCT: return cudf::make_product_aggregation<cudf::groupby_aggregation>();
     case A::MIN: return cudf::make_min_aggregation<cudf::groupby_aggregation>();
     case A::MAX: return cudf::make_max_aggregation<cudf::groupby_aggregation>();
@@ -105,12 +111,12 @@ std::unique_ptr<cudf::groupby_aggregation> make_agg(int32_t kind)
     case A::SUM_OF_SQUARES: return cudf::make_sum_of_squares_aggregation<cudf::groupby_aggregation>();
     case A::MEAN: return cudf::make_mean_aggregation<cudf::groupby_aggregation>();
     case A::M2: return cudf::make_m2_aggregation<cudf::groupby_aggregation>();
-    case A::VARIANCE: return cudf::make_variance_aggregation<cudf::groupby_aggregation>();
-    case A::STD: return cudf::make_std_aggregation<cudf::groupby_aggregation>();
+    case A::VARIANCE: return cudf::make_variance_aggregation<cudf::groupby_aggregation>(param ? *param : 1);
+    case A::STD: return cudf::make_std_aggregation<cudf::groupby_aggregation>(param ? *param : 1);
     case A::ARGMAX: return cudf::make_argmax_aggregation<cudf::groupby_aggregation>();
     case A::ARGMIN: return cudf::make_argmin_aggregation<cudf::groupby_aggregation>();
     case A::MEDIAN: return cudf::make_median_aggregation<cudf::groupby_aggregation>();
-    case A::NTH_ELEMENT: return cudf::make_nth_element_aggregation<cudf::groupby_aggregation>(0);
+    case A::NTH_ELEMENT: return cudf::make_nth_element_aggregation<cudf::groupby_aggregation>(param ? *param : 0);
     default: CUDF_FAIL("Unsupported aggregation kind in the C ABI.", std::invalid_argument);
   }
 }
@@ -121,13 +127,31 @@ extern "C" {
 const char* cudf_amd_last_error(void) { return g_last_error.c_str(); }
 const char* cudf_amd_version(void) { return "cudf_amd 0.1.0 (gfx950; libcudf 26.10 API subset)"; }
 
+// sizes of the live cudf_amd_malloc allocations: the resource's deallocate takes the size, the C ABI's free does not
+static std::mutex g_alloc_mu;
+static std::unordered_map<void*, std::size_t> g_alloc_sizes;
 cudf_amd_status cudf_amd_malloc(void** ptr, size_t bytes, void* stream)
 {
-  return guarded([&] { *ptr = cudf::get_current_device_resource_ref().allocate_async(bytes, as_stream(stream)); });
+  return guarded([&] {
+    *ptr = cudf::get_current_device_resource_ref().allocate_async(bytes, as_stream(stream));
+    std::lock_guard<std::mutex> g{g_alloc_mu};
+    g_alloc_sizes[*ptr] = bytes;
+  });
 }
 cudf_amd_status cudf_amd_free(void* ptr, void* stream)
 {
-  return guarded([&] { cudf::get_current_device_resource_ref().deallocate_async(ptr, 0, as_stream(stream)); });
+  return guarded([&] {
+    if (ptr == nullptr) return;
+    std::size_t bytes = 0;
+    {
+      std::lock_guard<std::mutex> g{g_alloc_mu};
+      auto it = g_alloc_sizes.find(ptr);
+      CUDF_EXPECTS(it != g_alloc_sizes.end(), "cudf_amd_free: pointer was not allocated by cudf_amd_malloc", std::invalid_argument);
+      bytes = it->second;
+      g_alloc_sizes.erase(it);
+    }
+    cudf::get_current_device_resource_ref().deallocate_async(ptr, bytes, as_stream(stream));
+  });
 }
 cudf_amd_status cudf_amd_memcpy(void* dst, const void* src, size_t bytes, int32_t kind, void* stream)
 {
@@ -193,6 +217,29 @@ cudf_amd_status cudf_amd_table_column(cudf_amd_table_t t, int32_t i, cudf_amd_co
     out->scale      = v.type().scale();
   });
 }
+static void fill_view(cudf::column_view const& v, cudf_amd_column_view* out)
+{
+  out->type_id    = static_cast<int32_t>(v.type().id());
+  out->size       = v.size();
+  out->data       = v.head();
+  out->null_mask  = v.null_mask();
+  out->null_count = v.null_count();
+  out->offset     = v.offset();
+  out->scale      = v.type().scale();
+}
+int32_t cudf_amd_table_column_num_children(cudf_amd_table_t t, int32_t i)
+{
+  return (t && i >= 0 && i < static_cast<int32_t>(t->cols.size())) ? t->cols[i]->num_children() : 0;
+}
+cudf_amd_status cudf_amd_table_column_child(cudf_amd_table_t t, int32_t i, int32_t j, cudf_amd_column_view* out)
+{
+  return guarded([&] {
+    CUDF_EXPECTS(t != nullptr && i >= 0 && i < static_cast<int32_t>(t->cols.size()), "column index out of range", std::invalid_argument);
+    auto const v = t->cols[i]->view();
+    CUDF_EXPECTS(j >= 0 && j < v.num_children(), "child index out of range", std::invalid_argument);
+    fill_view(v.child(j), out);
+  });
+}
 void cudf_amd_table_free(cudf_amd_table_t t) { delete t; }
 
 cudf_amd_status cudf_amd_groupby_aggregate(const cudf_amd_column_view* keys, int32_t num_keys,
@@ -208,7 +255,8 @@ cudf_amd_status cudf_amd_groupby_aggregate(const cudf_amd_column_view* keys, int
     std::vector<cudf::groupby::aggregation_request> reqs(num_requests);
     for (int32_t r = 0; r < num_requests; ++r) {
       reqs[r].values = to_view(requests[r].values);
-      for (int32_t k = 0; k < requests[r].num_kinds; ++k) reqs[r].aggregations.push_back(make_agg(requests[r].kinds[k]));
+      for (int32_t k = 0; k < requests[r].num_kinds; ++k)
+        reqs[r].aggregations.push_back(make_agg(requests[r].kinds[k], requests[r].params ? requests[r].params + k : nullptr));
     }
     cudf::groupby::groupby gb{kt, include_null_keys ? cudf::null_policy::INCLUDE : cudf::null_policy::EXCLUDE,
                               keys_are_sorted ? cudf::sorted::YES : cudf::sorted::NO};
@@ -346,7 +394,7 @@ cudf_amd_status cudf_amd_hash_join_finalize_full(const int32_t* const* left_part
   return guarded([&] {
     *out_indices = nullptr;
     CUDF_EXPECTS(num_partials >= 0, "negative number of partial results", std::invalid_argument);
-    std::vector<std::pair<cudf::size_type const*, std::size_t>> lp, rp;
+    std::vector<cudf::device_span<cudf::size_type const>> lp, rp;
     for (int32_t i = 0; i < num_partials; ++i) {
       lp.emplace_back(left_partials[i], static_cast<std::size_t>(partial_sizes[i]));
       rp.emplace_back(right_partials[i], static_cast<std::size_t>(partial_sizes[i]));

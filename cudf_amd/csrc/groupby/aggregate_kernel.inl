@@ -180,13 +180,6 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     }
     return value;
   };
-  auto squared = [](int op, uint64_t v) -> uint64_t {
-    if (op == ADD_F64) {
-      double const x = __longlong_as_double(static_cast<long long>(v));
-      return static_cast<uint64_t>(__double_as_longlong(x * x));
-    }
-    return v * v;
-  };
   // accumulators of one row whose LDS slot is known
   auto accumulate = [&](int64_t r, int slot, uint64_t const (&pay)[PAYT > 0 ? PAYT : 1], uint32_t valvalid) {
     int last_pay   = -1;
@@ -195,7 +188,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     for (int q = 0; q < NACCT; ++q) {
       if (q >= NACC) break;
       uint64_t* tgt = acc64(q) + slot;  // (COUNT accumulators: acc32(q) + slot)
-      if (acc_src[q] >= SRC_ARG_IDX) continue;  // filled by the second sweep
+      if ((acc_src[q] == SRC_ARG_IDX || acc_src[q] == SRC_ARG_IDX_OF_MAX)) continue;  // filled by the second sweep
       if constexpr (INPUT == IN_PARTIAL_RECORDS) {
         uint64_t v;
         if constexpr (PAYT > 0) v = q < PAYT ? pay[q < PAYT ? q : 0] : 0;
@@ -217,7 +210,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
           value    = payload_of(q, r, pay);
           last_pay = acc_pay[q];
         }
-        lds_merge(tgt, acc_op[q], acc_src[q] == SRC_SQUARE ? squared(acc_op[q], value) : value);
+        lds_merge(tgt, acc_op[q], acc_contribution(acc_src[q], acc_op[q], value));
       }
     }
   };
@@ -228,7 +221,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
 #pragma unroll
     for (int q = 0; q < NACCT; ++q) {
       if (q >= NACC) break;
-      if (acc_src[q] >= SRC_ARG_IDX) continue;
+      if ((acc_src[q] == SRC_ARG_IDX || acc_src[q] == SRC_ARG_IDX_OF_MAX)) continue;
       bool const valid = mine && (acc_src[q] == SRC_ONE || acc_vbit[q] < 0 || ((valvalid >> acc_vbit[q]) & 1u));
       unsigned long long const vm = __ballot(valid);
       if (vm == 0) continue;  // (wave-uniform)
@@ -239,7 +232,7 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
       uint64_t v = acc_identity(acc_op[q]);
       if (valid) {
         uint64_t const value = payload_of(q, r, pay);
-        v                    = acc_src[q] == SRC_SQUARE ? squared(acc_op[q], value) : value;
+        v                    = acc_contribution(acc_src[q], acc_op[q], value);
       }
       if (acc_op[q] == ANY_U64) {  // any contributing row will do: the first valid lane's
         v = static_cast<uint64_t>(__shfl(static_cast<unsigned long long>(v), __ffsll(static_cast<long long>(vm)) - 1));

@@ -77,6 +77,27 @@ __global__ void __launch_bounds__(256) k_finalize(finalize_args const* __restric
             valid = true;
           }
           bits = static_cast<uint64_t>(__double_as_longlong(out));
+        } else if (d.kind == OUT_MEAN_INT) {
+          // MEAN of a duration / decimal column: the SUM in the source type (wrapped to its width, as the reference's
+          // accumulator is) divided by COUNT_VALID with C++ integer division (reference hash_compound_agg_finalizer.cu:92-133:
+          // binary DIV with the source type as output; KATs mean_tests.cpp:152-198)
+          int const sh      = 64 - 8 * d.width;
+          int64_t const sum = static_cast<int64_t>(a0 << sh) >> sh;
+          int64_t const n   = static_cast<int64_t>(rec[p.KU + d.a1]);
+          bits              = static_cast<uint64_t>(valid && n > 0 ? sum / n : 0);
+        } else if (d.kind == OUT_SUMOV_SUM || d.kind == OUT_SUMOV_FLAG) {
+          // SUM_OVERFLOW (reference device_aggregators.cuh:136-160): sum in the source type, overflow = the exact sum does not
+          // fit it. The reference's flag depends on the arrival order of its atomics; "every order overflows" is the part of it
+          // that does not, and it is what its tests pin (sum_overflow_tests.cpp:260-378).
+          int const w = d.key_unit;  // source width in bytes (field reused)
+          __int128 exact;
+          if (d.a2 >= 0) exact = (static_cast<__int128>(static_cast<int64_t>(a0)) << 32) + static_cast<__int128>(static_cast<int64_t>(rec[p.KU + d.a2]));
+          else exact = static_cast<__int128>(static_cast<int64_t>(a0));
+          int const sh        = 64 - 8 * w;
+          int64_t const wrap  = static_cast<int64_t>(static_cast<uint64_t>(exact) << sh) >> sh;
+          bool const overflow = exact != static_cast<__int128>(wrap);
+          bits                = d.kind == OUT_SUMOV_SUM ? static_cast<uint64_t>(wrap) : static_cast<uint64_t>(overflow);
+          if (!valid) bits = 0;
         } else if (d.kind == OUT_MEAN) {
           // MEAN = double(SUM) / COUNT_VALID as FLOAT64 (reference hash_compound_agg_finalizer.cu:92-133)
           double const s = d.cls == cudf::detail::CLS_F64 ? __longlong_as_double(static_cast<long long>(a0))

@@ -186,15 +186,7 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
         atomicAdd(acc32(q) + s, 1u);
         continue;
       }
-      uint64_t v = value;
-      if (acc_src[q] == SRC_SQUARE) {
-        if (acc_op[q] == ADD_F64) {
-          double const x = __longlong_as_double(static_cast<long long>(value));
-          v              = static_cast<uint64_t>(__double_as_longlong(x * x));
-        } else {
-          v = value * value;
-        }
-      }
+      uint64_t const v = acc_contribution(acc_src[q], acc_op[q], value);
       lds_merge(acc64(q) + s, acc_op[q], v);
     }
     if (occ_acc < 0) {
@@ -308,7 +300,8 @@ void launch_key_range(plan_dev const* d_plan, int64_t nrows, int64_t sample, int
   range_init const init{is_signed ? static_cast<uint64_t>(INT64_MAX) : UINT64_MAX, is_signed ? static_cast<uint64_t>(INT64_MIN) : uint64_t{0}};
   hipLaunchKernelGGL(k_store_args<range_init>, dim3(1), dim3(1), 0, stream, init, reinterpret_cast<range_init*>(out));
   cudf::detail::prof::scope prof_{"estimate", stream};
-  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((sample + 255) / 256, 1, 256));
+  // (four sampled rows per thread: the stratum arithmetic is 128-bit division; one atomic pair per workgroup)
+  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((sample + 1023) / 1024, 1, 1024));
   if (is_signed) hipLaunchKernelGGL(k_key_range<true>, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, out);
   else hipLaunchKernelGGL(k_key_range<false>, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, out);
   CUDF_HIP_TRY(hipGetLastError());

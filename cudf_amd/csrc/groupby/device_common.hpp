@@ -93,6 +93,21 @@ __device__ __forceinline__ void lds_merge(uint64_t* slot, int op, uint64_t v)
   }
 }
 
+// what a raw row contributes to an accumulator, from the row's value (acc_src; SRC_VALUE passes through)
+__device__ __forceinline__ uint64_t acc_contribution(int src, int op, uint64_t v)
+{
+  if (src == SRC_SQUARE) {
+    if (op == ADD_F64) {
+      double const x = __longlong_as_double(static_cast<long long>(v));
+      return static_cast<uint64_t>(__double_as_longlong(x * x));
+    }
+    return v * v;
+  }
+  if (src == SRC_LO32) return v & 0xffffffffull;
+  if (src == SRC_HI32) return static_cast<uint64_t>(static_cast<int64_t>(v) >> 32);
+  return v;
+}
+
 // a (op) b on accumulator bit patterns - the wave-level counterpart of lds_merge (float min / max: a NaN never beats a
 // number, as ds_min_f64 / ds_max_f64)
 __device__ __forceinline__ uint64_t combine_values(int op, uint64_t a, uint64_t b)

@@ -51,7 +51,9 @@ enum acc_op : int8_t { ADD_I64 = 0, ADD_F64, MIN_I64, MIN_U64, MIN_F64, MAX_I64,
 // +0.0 / canonical NaN the key units carry.
 // How a RAW row contributes (reference device_aggregators.cuh:24-112,428-446: null source elements are
 // skipped for everything except COUNT_ALL).
-enum acc_src : int8_t { SRC_VALUE = 0, SRC_ONE_IF_VALID, SRC_ONE, SRC_SQUARE, SRC_ARG_IDX, SRC_ARG_IDX_OF_MAX };
+enum acc_src : int8_t { SRC_VALUE = 0, SRC_ONE_IF_VALID, SRC_ONE, SRC_SQUARE, SRC_ARG_IDX, SRC_ARG_IDX_OF_MAX, SRC_LO32, SRC_HI32 };
+// SRC_LO32 / SRC_HI32: the low 32 bits (zero-extended) / the high 32 bits (sign-extended) of a 64-bit value: their two int64
+// sums give the EXACT sum of up to 2^31 int64 values (hi * 2^32 + lo), from which SUM_OVERFLOW takes its overflow flag.
 // SRC_ARG_IDX (of a minimum) / SRC_ARG_IDX_OF_MAX: the row-index half of an ARGMIN / ARGMAX pair (arg_desc): untouched by the first sweep, filled by a second
 // sweep over the same rows once the extreme value of every group is final.
 
@@ -108,7 +110,10 @@ enum out_kind : int8_t {
   OUT_COUNT,      // accumulator a0 as INT32
   OUT_M2,         // double(a0 = sum of squares) - double(a1 = sum)^2 / (a2 = count); 0 for an empty group
   OUT_VAR,        // M2 / (count - ddof); null when count - ddof <= 0
-  OUT_STD         // sqrt(VAR)
+  OUT_STD,        // sqrt(VAR)
+  OUT_MEAN_INT,   // MEAN of a duration / decimal column: (acc a0 truncated to the source width) / (count a1), integer division
+  OUT_SUMOV_SUM,  // SUM_OVERFLOW, sum child: the exact sum (a0, or a0 = hi and a2 = lo halves) wrapped to the source width
+  OUT_SUMOV_FLAG  // SUM_OVERFLOW, overflow child: the exact sum does not fit the source type
 };
 struct out_desc {
   void* data;

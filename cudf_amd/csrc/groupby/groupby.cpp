@@ -69,6 +69,11 @@ data_type target_type(data_type source, aggregation::Kind k)
       if (plain_numeric) return data_type{type_id::INT64};
       if (is_duration || is_decimal) return source;
       return invalid;
+    case aggregation::SUM_OVERFLOW:
+      // signed integers (not bool) and decimals: struct {sum: source type, overflow: bool}
+      // (reference detail/aggregation/aggregation.hpp:981-995)
+      if ((cls == CLS_SINT && plain_numeric) || is_decimal) return data_type{type_id::STRUCT};
+      return invalid;
     case aggregation::PRODUCT:
     case aggregation::SUM_OF_SQUARES:
       if (cls == CLS_F32 || cls == CLS_F64) return source;
@@ -110,6 +115,7 @@ device_table make_device_table(table_view const& t)
   template std::unique_ptr<aggregation> fn<aggregation>();                       \
   template std::unique_ptr<groupby_aggregation> fn<groupby_aggregation>();
 CUDF_AMD_FACTORY(make_sum_aggregation, SUM)
+CUDF_AMD_FACTORY(make_sum_overflow_aggregation, SUM_OVERFLOW)
 CUDF_AMD_FACTORY(make_product_aggregation, PRODUCT)
 CUDF_AMD_FACTORY(make_min_aggregation, MIN)
 CUDF_AMD_FACTORY(make_max_aggregation, MAX)
@@ -190,6 +196,7 @@ bool is_engine_kind(aggregation::Kind k)
 {
   switch (k) {
     case aggregation::SUM:
+    case aggregation::SUM_OVERFLOW:
     case aggregation::PRODUCT:
     case aggregation::MIN:
     case aggregation::MAX:
@@ -239,7 +246,7 @@ int find_or_add_acc(plan_dev& p, acc_desc const& d)
   return p.NACC++;
 }
 
-host_plan build_plan(table_view const& keys, null_policy policy, std::vector<aggregation_request> const& requests)
+host_plan build_plan(table_view const& keys, null_policy policy, std::span<aggregation_request const> requests)
 {
   host_plan hp;
   auto& p = hp.dev;
@@ -430,10 +437,19 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::vector<agg
           rs.nullable = false;
           break;
         case aggregation::MEAN:
-          CUDF_EXPECTS(rs.target.id() == type_id::FLOAT64,
-                       "MEAN of duration/decimal columns is not implemented on the hash path.");
+          // FLOAT64 for plain numerics; duration / decimal columns keep their type: integer division of the SUM in the
+          // source type by the count (reference hash_compound_agg_finalizer.cu:92-133)
           rs.a0 = sum_acc(SRC_VALUE);
           rs.a1 = count_valid_acc();
+          break;
+        case aggregation::SUM_OVERFLOW:
+          // exact sum: one int64 accumulator for sources of at most 4 bytes; hi / lo half sums for 8-byte sources
+          if (size_of(vtype) < 8) {
+            rs.a0 = sum_acc(SRC_VALUE);
+          } else {
+            rs.a0 = sum_acc(SRC_HI32);
+            rs.a2 = sum_acc(SRC_LO32);
+          }
           break;
         case aggregation::M2:
         case aggregation::VARIANCE:
@@ -515,7 +531,7 @@ groupby::groupby(table_view const& keys, null_policy null_handling, sorted keys_
 groupby::~groupby() = default;
 
 std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggregate(
-  std::vector<aggregation_request> const& requests, stream_ref stream, rmm::device_async_resource_ref mr)
+  std::span<aggregation_request const> requests, stream_ref stream, rmm::device_async_resource_ref mr)
 {
   using namespace detail;
   // keys_are_sorted is a hint with which the reference picks its sort-based path (groupby.cu:64-69); group order is
@@ -546,8 +562,16 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     std::vector<aggregation_result> res;
     for (auto const& r : requests) {
       aggregation_result ar;
-      for (auto const& a : r.aggregations)
+      for (auto const& a : r.aggregations) {
+        if (a->kind == aggregation::SUM_OVERFLOW) {
+          std::vector<std::unique_ptr<column>> children;
+          children.push_back(make_empty_column(r.values.type()));
+          children.push_back(make_empty_column(data_type{type_id::BOOL8}));
+          ar.results.push_back(std::make_unique<column>(data_type{type_id::STRUCT}, 0, rmm::device_buffer{}, rmm::device_buffer{}, 0, std::move(children)));
+          continue;
+        }
         ar.results.push_back(make_empty_column(cudf::detail::target_type(r.values.type(), a->kind)));
+      }
       res.push_back(std::move(ar));
     }
     _last_path = hash_path::NONE;
@@ -1165,6 +1189,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   std::vector<std::unique_ptr<column>> res_cols;
   int const nres = static_cast<int>(hp.results.size());
   CUDF_EXPECTS(p.nkeycols + nres <= MAX_OUT, "Too many output columns for one call (limit 40).");
+  (void)nres;
   int32_t* d_nulls = sc.alloc<int32_t>(MAX_OUT);
   CUDF_HIP_TRY(hipMemsetAsync(d_nulls, 0, sizeof(int32_t) * MAX_OUT, s));
   auto make_out = [&](data_type t, bool nullable) {
@@ -1197,7 +1222,43 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     fin.out[fin.nout++] = d;
     key_cols.push_back(std::move(col));
   }
+  std::vector<int> res_desc;  // result column -> the out_desc whose null count is the column's
   for (auto const& rs : hp.results) {
+    res_desc.push_back(fin.nout);
+    if (rs.kind == aggregation::SUM_OVERFLOW) {
+      // struct {sum: source type, overflow: BOOL8}; the children carry no masks, the struct's mask is the validity of the group's
+      // sum (reference groupby/hash/output_utils.cu:83-111)
+      auto const vtype = hp.value_cols[rs.value_idx].type();
+      auto sum_col     = make_out(vtype, false);
+      auto flag_col    = make_out(data_type{type_id::BOOL8}, false);
+      rmm::device_buffer smask = rs.nullable ? create_null_mask(static_cast<size_type>(G), mask_state::UNINITIALIZED, stream, mr) : rmm::device_buffer{};
+      CUDF_EXPECTS(fin.nout + 2 <= MAX_OUT, "Too many output columns for one call (limit 40).");
+      for (int part = 0; part < 2; ++part) {
+        out_desc d{};
+        auto mv       = (part == 0 ? sum_col : flag_col)->mutable_view();
+        d.data        = mv.head();
+        d.mask        = (part == 0 && rs.nullable) ? static_cast<bitmask_type*>(smask.data()) : nullptr;
+        d.null_count  = d_nulls + fin.nout;
+        d.kind        = part == 0 ? OUT_SUMOV_SUM : OUT_SUMOV_FLAG;
+        d.a0          = static_cast<int8_t>(rs.a0);
+        d.a1          = -1;
+        d.a2          = static_cast<int8_t>(rs.a2);
+        d.valid_acc   = static_cast<int8_t>(rs.valid_acc);
+        d.cls         = static_cast<int8_t>(CLS_SINT);
+        d.width       = static_cast<int8_t>(part == 0 ? size_of(vtype) : 1);
+        d.out_cls     = static_cast<int8_t>(part == 0 ? CLS_SINT : CLS_BOOL);
+        d.key_unit    = static_cast<int8_t>(size_of(vtype));  // (source width)
+        d.key_null_bit = -1;
+        d.key_acc      = -1;
+        fin.out[fin.nout++] = d;
+      }
+      std::vector<std::unique_ptr<column>> children;
+      children.push_back(std::move(sum_col));
+      children.push_back(std::move(flag_col));
+      res_cols.push_back(std::make_unique<column>(data_type{type_id::STRUCT}, static_cast<size_type>(G), rmm::device_buffer{}, std::move(smask), 0,
+                                                  std::move(children)));
+      continue;
+    }
     auto col = make_out(rs.target, rs.nullable);
     out_desc d{};
     auto mv      = col->mutable_view();
@@ -1205,7 +1266,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     d.mask       = rs.nullable ? mv.null_mask() : nullptr;
     d.null_count = d_nulls + fin.nout;
     d.kind       = (rs.kind == aggregation::COUNT_VALID || rs.kind == aggregation::COUNT_ALL) ? OUT_COUNT
-                   : rs.kind == aggregation::MEAN                                              ? OUT_MEAN
+                   : rs.kind == aggregation::MEAN ? (rs.target.id() == type_id::FLOAT64 ? OUT_MEAN : OUT_MEAN_INT)
                    : rs.kind == aggregation::M2                                                ? OUT_M2
                    : rs.kind == aggregation::VARIANCE                                          ? OUT_VAR
                    : rs.kind == aggregation::STD                                               ? OUT_STD
@@ -1229,7 +1290,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   CUDF_HIP_TRY(hipStreamSynchronize(s));
   int oc = 0;
   for (auto& k : key_cols) k->set_null_count(h_nulls[oc++]);
-  for (auto& r : res_cols) r->set_null_count(h_nulls[oc++]);
+  for (std::size_t r = 0; r < res_cols.size(); ++r) res_cols[r]->set_null_count(h_nulls[res_desc[r]]);
 
   // ---- hand results back in request order; every (column, aggregation) pair has its own column, so a
   // repeated pair needs no cache deep copy (reference groupby/common/utils.hpp:39-51 copies instead).

@@ -149,6 +149,12 @@ struct array_private {
   std::vector<const void*> buffer_ptrs;     // what ArrowArray::buffers points at
   std::vector<ArrowArray> child_storage;
   std::vector<ArrowArray*> child_ptrs;
+  // device export (to_arrow_device): buffers copied for the export, a column whose buffers the array owns, the sync event
+  std::vector<rmm::device_buffer> device_buffers;
+  std::unique_ptr<column> owned_column;
+  std::vector<const void*> const_buffers;
+  hipEvent_t event{};
+  bool has_event{false};
 };
 void release_array(ArrowArray* a)
 {
@@ -157,6 +163,7 @@ void release_array(ArrowArray* a)
     if (a->children[i]->release != nullptr) a->children[i]->release(a->children[i]);
   auto* p = static_cast<array_private*>(a->private_data);
   for (void* b : p->host_buffers) std::free(b);
+  if (p->has_event) (void)hipEventDestroy(p->event);
   delete p;
   a->release = nullptr;
 }
@@ -232,6 +239,123 @@ void export_column(column_view const& c, ArrowArray* out, hipStream_t s)
   out->dictionary  = nullptr;
   out->release     = release_array;
   out->private_data = p;
+}
+
+
+// ---- device export: the Arrow buffers ARE the column's device buffers wherever the layouts agree
+__global__ void __launch_bounds__(256) k_shift_bits(uint32_t const* words, int64_t bit_offset, int64_t n, uint32_t* out)
+{
+  int64_t const w = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;  // output word
+  if (w * 32 >= n) return;
+  int64_t const b   = bit_offset + w * 32, idx = b >> 5;
+  uint64_t const lo = words[idx], hi = (idx + 1) * 32 < bit_offset + n ? words[idx + 1] : 0;
+  uint32_t v        = static_cast<uint32_t>(((hi << 32) | lo) >> (b & 31));
+  if ((w + 1) * 32 > n) v &= (1u << (n & 31)) - 1u;  // clear the bits past the last row
+  out[w] = v;
+}
+
+// One column as a device ArrowArray: buffers {validity bitmap, data} in device memory. `owned` (may be null) is a column
+// whose buffers the array takes over; otherwise the array only views `c` (plus whatever had to be copied).
+void export_column_device(column_view const& c, std::unique_ptr<column> owned, ArrowArray* out, hipStream_t s,
+                          rmm::device_async_resource_ref mr)
+{
+  auto* p = new array_private{};
+  try {
+    size_type const n       = c.size();
+    std::size_t const width = size_of_id(c.type().id());
+    (void)format_of_type(c.type().id());
+    void const* valid = nullptr;
+    if (c.nullable() && c.null_count() > 0 && n > 0) {
+      if (c.offset() == 0) {
+        valid = c.null_mask();
+      } else {  // a sliced column: Arrow wants the bits of [offset, offset + n) - repacked to bit 0 on the device, offset = 0
+        std::size_t const nwords = (static_cast<std::size_t>(n) + 31) / 32;
+        p->device_buffers.emplace_back(nwords * 4 + 64, s, mr);
+        hipLaunchKernelGGL(k_shift_bits, dim3(static_cast<unsigned>((nwords + 255) / 256)), dim3(256), 0, s, c.null_mask(),
+                           static_cast<int64_t>(c.offset()), static_cast<int64_t>(n), static_cast<uint32_t*>(p->device_buffers.back().data()));
+        CUDF_HIP_TRY(hipGetLastError());
+        valid = p->device_buffers.back().data();
+      }
+    }
+    void const* data = nullptr;
+    uint8_t const* src = static_cast<uint8_t const*>(c.head()) + static_cast<std::size_t>(c.offset()) * width;
+    if (c.type().id() == type_id::BOOL8) {  // BOOL8 bytes -> Arrow bit-packed booleans (a copy, as in the reference)
+      std::size_t const nwords = (static_cast<std::size_t>(n) + 31) / 32 + 2;
+      p->device_buffers.emplace_back(nwords * 4, s, mr);
+      CUDF_HIP_TRY(hipMemsetAsync(p->device_buffers.back().data(), 0, nwords * 4, s));
+      if (n > 0) {
+        hipLaunchKernelGGL(k_bytes_to_bits, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, s, src, static_cast<int64_t>(n),
+                           static_cast<uint32_t*>(p->device_buffers.back().data()));
+        CUDF_HIP_TRY(hipGetLastError());
+      }
+      data = p->device_buffers.back().data();
+    } else {
+      data = n > 0 ? src : nullptr;
+    }
+    p->owned_column   = std::move(owned);
+    p->const_buffers  = {valid, data};
+    out->length       = n;
+    out->null_count   = valid != nullptr ? c.null_count() : 0;
+    out->offset       = 0;
+    out->n_buffers    = 2;
+    out->n_children   = 0;
+    out->buffers      = p->const_buffers.data();
+    out->children     = nullptr;
+    out->dictionary   = nullptr;
+    out->release      = release_array;
+    out->private_data = p;
+  } catch (...) {
+    delete p;
+    throw;
+  }
+}
+
+unique_device_array_t finish_device_array(array_private* p, int64_t length, hipStream_t s)
+{
+  unique_device_array_t out{new ArrowDeviceArray{}};
+  // the consumer orders its work behind the exporting stream through the event (Arrow C Device Data Interface: sync_event
+  // is a hipEvent_t* for ARROW_DEVICE_ROCM)
+  CUDF_HIP_TRY(hipEventCreateWithFlags(&p->event, hipEventDisableTiming));
+  p->has_event = true;
+  CUDF_HIP_TRY(hipEventRecord(p->event, s));
+  int dev = 0;
+  CUDF_HIP_TRY(hipGetDevice(&dev));
+  out->array.length       = length;
+  out->array.null_count   = 0;
+  out->array.offset       = 0;
+  out->array.n_buffers    = p->child_ptrs.empty() && !p->const_buffers.empty() ? 2 : 1;
+  out->array.n_children   = static_cast<int64_t>(p->child_ptrs.size());
+  out->array.buffers      = p->const_buffers.data();
+  out->array.children     = p->child_ptrs.empty() ? nullptr : p->child_ptrs.data();
+  out->array.dictionary   = nullptr;
+  out->array.release      = release_array;
+  out->array.private_data = p;
+  out->device_id          = dev;
+  out->device_type        = ARROW_DEVICE_ROCM;
+  out->sync_event         = &p->event;
+  return out;
+}
+
+unique_device_array_t table_to_device_array(table_view const& table, std::vector<std::unique_ptr<column>> owned, stream_ref stream,
+                                            rmm::device_async_resource_ref mr)
+{
+  auto* p = new array_private{};
+  p->child_storage.resize(static_cast<std::size_t>(table.num_columns()));
+  try {
+    for (size_type i = 0; i < table.num_columns(); ++i) {
+      auto& slot   = p->child_storage[static_cast<std::size_t>(i)];
+      slot.release = nullptr;
+      export_column_device(table.column(i), owned.empty() ? nullptr : std::move(owned[static_cast<std::size_t>(i)]), &slot, stream.value(), mr);
+      p->child_ptrs.push_back(&slot);
+    }
+    p->const_buffers = {nullptr};
+    return finish_device_array(p, table.num_rows(), stream.value());
+  } catch (...) {
+    for (auto& c : p->child_storage)
+      if (c.release != nullptr) c.release(&c);
+    delete p;
+    throw;
+  }
 }
 
 void export_schema(type_id t, std::string const& name, bool nullable, ArrowSchema* out)
@@ -375,6 +499,50 @@ unique_device_array_t to_arrow_host(table_view const& table, stream_ref stream, 
   out->device_type        = ARROW_DEVICE_CPU;
   out->sync_event         = nullptr;
   return out;
+}
+
+// ---- to_arrow_device (reference interop.hpp:500-610): the table's data stays on the device. The view forms wrap the
+// caller's buffers (which must outlive the array); the rvalue forms hand the buffers' ownership to the array.
+unique_device_array_t to_arrow_device(table_view const& table, stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  return table_to_device_array(table, {}, stream, mr);
+}
+unique_device_array_t to_arrow_device(column_view const& col, stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  ArrowArray tmp{};
+  export_column_device(col, nullptr, &tmp, stream.value(), mr);
+  auto* p = static_cast<array_private*>(tmp.private_data);
+  try {
+    auto out              = finish_device_array(p, col.size(), stream.value());
+    out->array.null_count = tmp.null_count;
+    out->array.n_buffers  = 2;
+    return out;
+  } catch (...) {
+    delete p;
+    throw;
+  }
+}
+unique_device_array_t to_arrow_device(table&& tbl, stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  auto const view = tbl.view();
+  return table_to_device_array(view, tbl.release(), stream, mr);
+}
+unique_device_array_t to_arrow_device(column&& col, stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  auto owned      = std::make_unique<column>(std::move(col));
+  auto const view = owned->view();
+  ArrowArray tmp{};
+  export_column_device(view, std::move(owned), &tmp, stream.value(), mr);
+  auto* p = static_cast<array_private*>(tmp.private_data);
+  try {
+    auto out              = finish_device_array(p, view.size(), stream.value());
+    out->array.null_count = tmp.null_count;
+    out->array.n_buffers  = 2;
+    return out;
+  } catch (...) {
+    delete p;
+    throw;
+  }
 }
 
 }  // namespace cudf

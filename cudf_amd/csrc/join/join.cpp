@@ -482,8 +482,8 @@ join_index_pair hash_join::partitioned_full_join(join_partition_context const& c
 // Concatenates the partial probe-side results and appends (JoinNoMatch, r) for every right row r that no partial
 // matched (reference hash_join.hpp:414-441, join_utils.cu:45-221).
 join_index_pair hash_join::finalize_partitioned_full_join(
-  std::vector<std::pair<size_type const*, std::size_t>> const& left_partials,
-  std::vector<std::pair<size_type const*, std::size_t>> const& right_partials, size_type left_table_num_rows,
+  cudf::host_span<cudf::device_span<size_type const> const> left_partials,
+  cudf::host_span<cudf::device_span<size_type const> const> right_partials, size_type left_table_num_rows,
   size_type right_table_num_rows, stream_ref stream, rmm::device_async_resource_ref mr)
 {
   CUDF_EXPECTS(left_partials.size() == right_partials.size(), "left and right partial results differ in number",
@@ -492,9 +492,9 @@ join_index_pair hash_join::finalize_partitioned_full_join(
   hipStream_t const s = stream.value();
   std::size_t probe_pairs = 0;
   for (std::size_t i = 0; i < left_partials.size(); ++i) {
-    CUDF_EXPECTS(left_partials[i].second == right_partials[i].second, "partial index vectors differ in size",
+    CUDF_EXPECTS(left_partials[i].size() == right_partials[i].size(), "partial index vectors differ in size",
                  std::invalid_argument);
-    probe_pairs += left_partials[i].second;
+    probe_pairs += left_partials[i].size();
   }
   std::size_t const room = probe_pairs + static_cast<std::size_t>(right_table_num_rows);
   CUDF_EXPECTS(room <= static_cast<std::size_t>(std::numeric_limits<size_type>::max()),
@@ -505,11 +505,11 @@ join_index_pair hash_join::finalize_partitioned_full_join(
   CUDF_HIP_TRY(hipMemsetAsync(matched.data(), 0, matched.size(), s));
   std::size_t pos = 0;
   for (std::size_t i = 0; i < left_partials.size(); ++i) {
-    std::size_t const m = left_partials[i].second;
+    std::size_t const m = left_partials[i].size();
     if (m == 0) continue;
-    CUDF_HIP_TRY(hipMemcpyAsync(l.data() + pos, left_partials[i].first, m * sizeof(size_type), hipMemcpyDeviceToDevice, s));
-    CUDF_HIP_TRY(hipMemcpyAsync(r.data() + pos, right_partials[i].first, m * sizeof(size_type), hipMemcpyDeviceToDevice, s));
-    detail::join::launch_mark_matched(right_partials[i].first, m, static_cast<uint8_t*>(matched.data()), s);
+    CUDF_HIP_TRY(hipMemcpyAsync(l.data() + pos, left_partials[i].data(), m * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(r.data() + pos, right_partials[i].data(), m * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+    detail::join::launch_mark_matched(right_partials[i].data(), m, static_cast<uint8_t*>(matched.data()), s);
     pos += m;
   }
   std::size_t total = probe_pairs;

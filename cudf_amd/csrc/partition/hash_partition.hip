@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(256) k_gather_mask(device_column src, int32_t 
   int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   bool valid      = false;
   if (i < n) {
-    int64_t const s = map[i];
+    int64_t s = map[i];
+    if (s < 0) s += src_rows;  // negative indices count from the end (reference copying/gather.cu:81-82)
     bool const in   = s >= 0 && s < src_rows;
     valid           = in ? col_is_valid(src, s) : !nullify;
   }
@@ -233,7 +234,8 @@ __global__ void __launch_bounds__(256) k_gather_data(device_column src, int32_t 
 {
   int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   if (i >= n) return;
-  int64_t const s = map[i];
+  int64_t s = map[i];
+  if (s < 0) s += src_rows;
   uint64_t const v = (s >= 0 && s < src_rows) ? col_load_bits(src, s) : 0;
   switch (src.width) {
     case 1: static_cast<uint8_t*>(out)[i] = static_cast<uint8_t>(v); break;
@@ -262,7 +264,8 @@ __global__ void __launch_bounds__(256) k_gather_multi(gather_cols g, size_type c
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     int64_t const i = base + static_cast<int64_t>(k) * blockDim.x;
-    s[k]            = i < n ? gload(map + i) : -1;
+    s[k]            = i < n ? gload(map + i) : INT32_MIN;
+    if (s[k] < 0) s[k] += g.src_rows;
     in[k]           = s[k] >= 0 && s[k] < g.src_rows;
   }
 #pragma unroll
@@ -317,12 +320,23 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_v
                                                                          int num_partitions, hash_id hash_function, uint32_t seed,
                                                                          stream_ref stream, rmm::device_async_resource_ref mr)
 {
+  // (an index outside the table: std::out_of_range from select, as in the reference - hash_partition_test.cpp:48-58)
+  return hash_partition(input, input.select(columns_to_hash), num_partitions, hash_function, seed, stream, mr);
+}
+
+std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_view const& input, table_view const& table_to_hash,
+                                                                         int num_partitions, hash_id hash_function, uint32_t seed,
+                                                                         stream_ref stream, rmm::device_async_resource_ref mr)
+{
   using namespace detail;
+  // reference partitioning.cu:925-947
+  CUDF_EXPECTS(table_to_hash.num_columns() == 0 || input.num_rows() == table_to_hash.num_rows(),
+               "Input table and key table must have same number of rows, or key table should have no columns.", std::invalid_argument);
   CUDF_EXPECTS(hash_function == hash_id::HASH_MURMUR3, "Only HASH_MURMUR3 is implemented on this path.");
-  auto const table_to_hash = input.select(columns_to_hash);
-  // Return empty result if there are no partitions or nothing to hash (reference partitioning.cu:925-947)
+  // Return empty result if there are no partitions or nothing to hash; the offsets vector always has num_partitions + 1
+  // entries (reference partitioning.cu:880-888)
   if (num_partitions <= 0 || input.num_rows() == 0 || table_to_hash.num_columns() == 0) {
-    return {empty_like(input), std::vector<size_type>(std::max(num_partitions, 0), 0)};
+    return {empty_like(input), std::vector<size_type>(static_cast<std::size_t>(std::max(num_partitions, 0)) + 1, 0)};
   }
   CUDF_EXPECTS(num_partitions <= MAX_LDS_PARTITIONS, "hash_partition: more than 4096 partitions are not implemented.");
   hipStream_t const s = stream.value();
@@ -368,10 +382,19 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_v
   hipLaunchKernelGGL(k_hp_scan, dim3(1), dim3(1024), P * sizeof(int64_t), s, da);
   {
     size_t const lds = PART_TILE * 8 + P * (8 + 8 + 4 + 4) + PART_TILE * 2;
+    // beyond 1024 partitions the tile needs more than the default 64 KiB of dynamic LDS (139 KiB at 4096): opt in once
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncAttributes attr{};
+      CUDF_HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<void const*>(&k_hp_scatter)));
+      CUDF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(&k_hp_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
+      attr_set = true;
+    }
     prof::scope p_{"hash_partition_scatter", s};
     hipLaunchKernelGGL(k_hp_scatter, dim3(a.slices), dim3(PART_BLOCK), lds, s, da);
+    CUDF_HIP_TRY(hipGetLastError());
   }
-  CUDF_HIP_TRY(hipGetLastError());
   std::vector<int64_t> h_off(P + 1);
   CUDF_HIP_TRY(hipMemcpyAsync(h_off.data(), a.offsets, (P + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
   CUDF_HIP_TRY(hipStreamSynchronize(s));
@@ -382,8 +405,10 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_v
     auto [mask, nulls] = gather_mask(col, a.order, n, false, stream, mr);
     out_cols[c]->set_null_mask(std::move(mask), nulls);
   }
-  std::vector<size_type> starts(P);
-  for (size_t p = 0; p < P; ++p) starts[p] = static_cast<size_type>(h_off[p]);
+  // num_partitions + 1 offsets: partition i = rows [offsets[i], offsets[i + 1]); the last one is the row count
+  // (reference partitioning.hpp:84-101, partitioning.cu:688-690)
+  std::vector<size_type> starts(P + 1);
+  for (size_t p = 0; p <= P; ++p) starts[p] = static_cast<size_type>(h_off[p]);
   return {std::make_unique<table>(std::move(out_cols)), std::move(starts)};
 }
 

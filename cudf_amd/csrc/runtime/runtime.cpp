@@ -165,7 +165,9 @@ bool nullable(table_view const& view)
 column::column(column_view view, stream_ref stream, rmm::device_async_resource_ref mr)
   : _type{view.type()}, _size{view.size()}, _null_count{view.null_count()}
 {
-  CUDF_EXPECTS(view.num_children() == 0, "Only fixed-width columns are supported on this path.");
+  // a STRUCT column (SUM_OVERFLOW's {sum, overflow}): the children are copied, the parent holds only the mask
+  CUDF_EXPECTS(view.num_children() == 0 || _type.id() == type_id::STRUCT, "Only fixed-width and STRUCT columns are supported on this path.");
+  for (size_type i = 0; i < view.num_children(); ++i) _children.push_back(std::make_unique<column>(view.child(i), stream, mr));
   if (_size > 0 && is_fixed_width(_type)) {
     auto const w = size_of(_type);
     _data = rmm::device_buffer{static_cast<char const*>(view.head()) + std::size_t(view.offset()) * w,
@@ -199,7 +201,11 @@ void column::set_null_count(size_type new_null_count)
 }
 column_view column::view() const
 {
-  return column_view{_type, _size, _data.data(), static_cast<bitmask_type const*>(_null_mask.data()), _null_count, 0};
+  // (children: reference column.cu - a STRUCT column's view carries the views of its children)
+  std::vector<column_view> kids;
+  kids.reserve(_children.size());
+  for (auto const& c : _children) kids.push_back(c->view());
+  return column_view{_type, _size, _data.data(), static_cast<bitmask_type const*>(_null_mask.data()), _null_count, 0, kids};
 }
 mutable_column_view column::mutable_view()
 {

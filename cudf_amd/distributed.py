@@ -38,7 +38,7 @@ class GpuBackend:
         from cudf_amd import partitioning
         tbl = cudf_amd.Table([cudf_amd.Column.from_torch(c) for c in columns])
         out, offs = partitioning.hash_partition(tbl, [0], num_partitions, stream=self.stream)
-        return [c.to_torch() for c in out.columns()], offs
+        return [c.to_torch() for c in out.columns()], offs[:num_partitions]  # (start offsets; the last entry is the row count)
 
     def groupby_sum(self, keys, value_columns, count=False):
         """SUM of every value column per key (and COUNT_VALID of the first when count=True).

@@ -35,8 +35,10 @@ class GroupBy:
         reqs, keep = [], []
         for r in requests:
             kinds = (C.c_int32 * max(1, len(r._aggregations)))(*[int(a.kind()) for a in r._aggregations])
-            keep.append(kinds)
-            reqs.append(_lib.AggregationRequest(r._values._view(), kinds, len(r._aggregations)))
+            params = (C.c_int32 * max(1, len(r._aggregations)))(*[a.param(1 if a.kind().name in ("VARIANCE", "STD") else 0)
+                                                                   for a in r._aggregations])
+            keep += [kinds, params]
+            reqs.append(_lib.AggregationRequest(r._values._view(), kinds, len(r._aggregations), params))
         rarr = (_lib.AggregationRequest * max(1, len(reqs)))(*reqs)
         out_keys, out_res, path = C.c_void_p(), C.c_void_p(), C.c_int32(0)
         _lib.check(lib.cudf_amd_groupby_aggregate(self._keys._views(), self._keys.num_columns(),

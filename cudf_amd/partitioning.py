@@ -8,13 +8,13 @@ from .types import OutOfBoundsPolicy
 
 
 def hash_partition(input: Table, columns_to_hash, num_partitions: int, seed: int = 0, stream=None, mr=None):
-    """-> (partitioned Table, [start offset of each partition])."""
+    """-> (partitioned Table, num_partitions + 1 row offsets: partition i = rows [offsets[i], offsets[i+1]))."""
     cols = (C.c_int32 * max(1, len(columns_to_hash)))(*columns_to_hash)
-    offs = (C.c_int32 * max(1, num_partitions))()
+    offs = (C.c_int32 * (max(0, num_partitions) + 1))()
     out = C.c_void_p()
     _lib.check(_lib.load().cudf_amd_hash_partition(input._views(), input.num_columns(), cols, len(columns_to_hash),
                                                    num_partitions, seed, _stream_ptr(stream), C.byref(out), offs))
-    return Table._from_handle(out), list(offs)[:max(num_partitions, 0)]
+    return Table._from_handle(out), list(offs)[:max(num_partitions, 0) + 1]
 
 
 def murmurhash3_x86_32(input: Table, seed: int = 0, stream=None) -> Column:

@@ -1,7 +1,7 @@
 // SPDX-License-Identifier: Apache-2.0
 // Aggregation descriptors for groupby requests. Kind values are numerically identical to the reference
 // (cpp/include/cudf/aggregation.hpp:78-121) because pylibcudf passes them through as ints; factories
-// mirror :212-266. Only the hash-groupby kinds are constructible on this path (SUM, PRODUCT, MIN, MAX,
+// mirror :212-266. Only the hash-groupby kinds are constructible on this path (SUM, SUM_OVERFLOW, PRODUCT, MIN, MAX,
 // COUNT_VALID, COUNT_ALL, SUM_OF_SQUARES, MEAN, M2, VARIANCE, STD, ARGMAX, ARGMIN); the rest of the enum is
 // kept so that values line up.
 #pragma once
@@ -74,6 +74,8 @@ class groupby_aggregation : public virtual aggregation {};
 class reduce_aggregation : public virtual aggregation {};
 
 template <typename Base = aggregation> std::unique_ptr<Base> make_sum_aggregation();
+// SUM with overflow detection: struct {sum: source type, overflow: bool} (reference aggregation.hpp:214-217)
+template <typename Base = aggregation> std::unique_ptr<Base> make_sum_overflow_aggregation();
 template <typename Base = aggregation> std::unique_ptr<Base> make_product_aggregation();
 template <typename Base = aggregation> std::unique_ptr<Base> make_min_aggregation();
 template <typename Base = aggregation> std::unique_ptr<Base> make_max_aggregation();

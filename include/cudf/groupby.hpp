@@ -12,6 +12,7 @@
 #include <cudf/utilities/default_stream.hpp>
 #include <rmm/resource_ref.hpp>
 #include <memory>
+#include <span>
 #include <utility>
 #include <vector>
 
@@ -45,8 +46,9 @@ class groupby {
                    std::vector<order> const& column_order         = {},
                    std::vector<null_order> const& null_precedence = {});
 
+  // (reference groupby.hpp:181-184; a std::vector<aggregation_request> converts implicitly)
   std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> aggregate(
-    std::vector<aggregation_request> const& requests,
+    std::span<aggregation_request const> requests,
     stream_ref stream                 = get_default_stream(),
     rmm::device_async_resource_ref mr = get_current_device_resource_ref());
 

@@ -1,7 +1,8 @@
 // SPDX-License-Identifier: Apache-2.0
 // Arrow C Data Interface import / export for the fixed-width types of the hash-groupby / hash-join path.
 // Mirrors the reference entry points of cpp/include/cudf/interop.hpp: from_arrow (:685-689), from_arrow_column
-// (:705-709), to_arrow_schema (:473-475), to_arrow_host (:618-621, :643-646), from_arrow_device (:834-838).
+// (:705-709), to_arrow_schema (:473-475), to_arrow_host (:618-621, :643-646), from_arrow_device (:834-838),
+// to_arrow_device (:500-610).
 // The ABI structs are the ones the Arrow specification publishes (ArrowSchema / ArrowArray / ArrowDeviceArray);
 // an including translation unit that already has them (arrow/c/abi.h, nanoarrow) keeps its own definitions.
 #pragma once
@@ -104,5 +105,18 @@ unique_schema_t to_arrow_schema(table_view const& input, std::vector<column_meta
 // Copies the table to host memory owned by the returned array (device_type ARROW_DEVICE_CPU, struct array).
 unique_device_array_t to_arrow_host(table_view const& table, stream_ref stream = get_default_stream(),
                                     rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+
+// Device export (reference interop.hpp:500-610): an ArrowDeviceArray (device_type ARROW_DEVICE_ROCM, sync_event = a
+// hipEvent_t* recorded on `stream`) whose buffers are the table's device buffers - no host bounce. The view forms only wrap the
+// caller's memory, which must outlive the array; the rvalue forms move the buffers' ownership into the array. Copies happen
+// only where the layouts differ: BOOL8 (Arrow booleans are bit-packed) and the validity bits of a sliced column.
+unique_device_array_t to_arrow_device(table_view const& table, stream_ref stream = get_default_stream(),
+                                      rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+unique_device_array_t to_arrow_device(column_view const& col, stream_ref stream = get_default_stream(),
+                                      rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+unique_device_array_t to_arrow_device(table&& table, stream_ref stream = get_default_stream(),
+                                      rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+unique_device_array_t to_arrow_device(column&& col, stream_ref stream = get_default_stream(),
+                                      rmm::device_async_resource_ref mr = get_current_device_resource_ref());
 
 }  // namespace cudf

@@ -4,6 +4,7 @@
 // left_join, full_join, *_join_size. Probes are const and may run concurrently on different streams.
 #pragma once
 #include <cudf/join/join.hpp>
+#include <cudf/utilities/span.hpp>
 #include <memory>
 #include <optional>
 
@@ -71,8 +72,8 @@ class hash_join {
     join_partition_context const& context, stream_ref stream = get_default_stream(),
     rmm::device_async_resource_ref mr = get_current_device_resource_ref()) const;
   [[nodiscard]] static join_index_pair finalize_partitioned_full_join(
-    std::vector<std::pair<size_type const*, std::size_t>> const& left_partials,
-    std::vector<std::pair<size_type const*, std::size_t>> const& right_partials, size_type left_table_num_rows,
+    cudf::host_span<cudf::device_span<size_type const> const> left_partials,
+    cudf::host_span<cudf::device_span<size_type const> const> right_partials, size_type left_table_num_rows,
     size_type right_table_num_rows, stream_ref stream = get_default_stream(),
     rmm::device_async_resource_ref mr = get_current_device_resource_ref());
 

@@ -30,7 +30,8 @@ typedef enum {
   CUDF_AMD_DATA_TYPE_ERROR  = 3, /* cudf::data_type_error    -> TypeError       */
   CUDF_AMD_DEVICE_ERROR     = 4, /* cudf::cuda_error (HIP)   -> RuntimeError    */
   CUDF_AMD_BAD_ALLOC        = 5, /* std::bad_alloc           -> MemoryError     */
-  CUDF_AMD_OTHER_ERROR      = 6
+  CUDF_AMD_OTHER_ERROR      = 6,
+  CUDF_AMD_OUT_OF_RANGE     = 7  /* std::out_of_range        -> IndexError      */
 } cudf_amd_status;
 
 /* cudf::column_view (reference cpp/include/cudf/column/column_view.hpp:236-244): element i at
@@ -51,6 +52,9 @@ typedef struct {
   cudf_amd_column_view values;
   const int32_t* kinds;
   int32_t num_kinds;
+  /* one parameter per aggregation, or NULL for the defaults: ddof of VARIANCE / STD (make_variance_aggregation(ddof),
+   * aggregation.hpp:259-266; default 1), n of NTH_ELEMENT; ignored by the other kinds */
+  const int32_t* params;
 } cudf_amd_aggregation_request;
 
 /* Owning cudf::table / vector of cudf::column. */
@@ -81,6 +85,10 @@ cudf_amd_status cudf_amd_profile_report(char* buf, size_t n);
 int32_t cudf_amd_table_num_columns(cudf_amd_table_t t);
 int32_t cudf_amd_table_num_rows(cudf_amd_table_t t);
 cudf_amd_status cudf_amd_table_column(cudf_amd_table_t t, int32_t i, cudf_amd_column_view* out);
+/* children of a STRUCT column (SUM_OVERFLOW: {sum, overflow}; reference column_view.hpp:469 child()): their number, and
+ * child j as a view (valid while the table lives) */
+int32_t cudf_amd_table_column_num_children(cudf_amd_table_t t, int32_t i);
+cudf_amd_status cudf_amd_table_column_child(cudf_amd_table_t t, int32_t i, int32_t j, cudf_amd_column_view* out);
 void cudf_amd_table_free(cudf_amd_table_t t);
 
 /* ---- cudf::groupby::groupby(keys, null_handling, keys_are_sorted).aggregate(requests, stream, mr)
@@ -149,8 +157,9 @@ cudf_amd_status cudf_amd_to_arrow_host(const cudf_amd_column_view* columns, int3
                                        void* stream, struct ArrowSchema* out_schema, struct ArrowArray* out_array);
 
 /* ---- cudf::hash_partition(input, columns_to_hash, num_partitions, HASH_MURMUR3, seed, stream, mr)
- * (reference cpp/include/cudf/partitioning.hpp; src/partitioning/partitioning.cu:925-947). out_offsets receives
- * num_partitions start offsets (first is 0), as the reference's std::vector<size_type>. */
+ * (reference cpp/include/cudf/partitioning.hpp:84-101; src/partitioning/partitioning.cu:925-947). out_offsets receives
+ * num_partitions + 1 row offsets (partition i = rows [offsets[i], offsets[i+1]); the last one is the row count), as the
+ * reference's std::vector<size_type>. A column index outside the table returns CUDF_AMD_OUT_OF_RANGE. */
 cudf_amd_status cudf_amd_hash_partition(const cudf_amd_column_view* input, int32_t num_columns,
                                         const int32_t* columns_to_hash, int32_t num_hash_columns, int32_t num_partitions,
                                         uint32_t seed, void* stream, cudf_amd_table_t* out_table, int32_t* out_offsets);

@@ -208,6 +208,11 @@ static int target_type(int src, int kind)
       if (is_plain_numeric(src)) return T_INT64; /* integral incl. bool */
       if (is_duration(src) || is_decimal(src)) return src;
       return -1;
+    case K_SUM_OVERFLOW:
+      /* struct {sum: source type, overflow: bool}; signed integers (not bool) and decimals
+       * (detail/aggregation/aggregation.hpp:981-995). Reported here as the sum child's type. */
+      if ((cls == C_SINT && is_plain_numeric(src)) || is_decimal(src)) return src;
+      return -1;
     case K_PRODUCT: case K_SUM_OF_SQUARES:
       if (cls == C_F32 || cls == C_F64) return src;
       if (is_plain_numeric(src)) return T_INT64;
@@ -222,7 +227,7 @@ static int target_type(int src, int kind)
 static int kind_supported(int kind)
 {
   switch (kind) {
-    case K_SUM: case K_PRODUCT: case K_MIN: case K_MAX: case K_COUNT_VALID: case K_COUNT_ALL: case K_MEAN:
+    case K_SUM: case K_SUM_OVERFLOW: case K_PRODUCT: case K_MIN: case K_MAX: case K_COUNT_VALID: case K_COUNT_ALL: case K_MEAN:
     case K_SUM_OF_SQUARES: case K_M2: case K_VARIANCE: case K_STD: case K_ARGMAX: case K_ARGMIN: return 1;
     default: return 0;
   }
@@ -250,6 +255,7 @@ typedef struct {
   int64_t nvalid;
   int64_t nall;
   int32_t arg;
+  int overflow; /* SUM_OVERFLOW */
 } acc_t;
 
 static void out_col_alloc(orc_out_column* o, int type_id, int32_t n, int nullable)
@@ -279,7 +285,7 @@ void orc_groupby_free(orc_groupby_result* r)
 {
   if (!r) return;
   for (int i = 0; i < r->nkeys; ++i) { free(r->keys[i].data); free(r->keys[i].mask); }
-  for (int i = 0; i < r->nresults; ++i) { free(r->results[i].data); free(r->results[i].mask); }
+  for (int i = 0; i < r->nresults; ++i) { free(r->results[i].data); free(r->results[i].mask); free(r->results[i].aux); }
   free(r->keys); free(r->results); free(r);
 }
 
@@ -366,6 +372,22 @@ int orc_groupby(const orc_column* keys, int32_t nkeys, int32_t include_null_keys
           case K_SUM: case K_MEAN:
             /* integral -> int64 wrapping add (unsigned arithmetic = two's complement wrap); float -> fp add */
             acc[g].f += x; acc[g].i = (int64_t)((uint64_t)acc[g].i + (uint64_t)xi); break;
+          case K_SUM_OVERFLOW: {
+            /* device_aggregators.cuh:136-160, in row order: once a group's flag is up its sum is left alone; the add is
+             * done in the source's storage type and flags the group when it overflows that type. (The reference's atomics
+             * arrive in any order: flag and sum are reproducible only for inputs where every order agrees - all the
+             * reference's own tests, and the ones here, are of that kind.) */
+            if (acc[g].overflow) break;
+            int w = type_width(v->type_id);
+            int64_t lo = w == 1 ? INT8_MIN : w == 2 ? INT16_MIN : w == 4 ? INT32_MIN : INT64_MIN;
+            int64_t hi = w == 1 ? INT8_MAX : w == 2 ? INT16_MAX : w == 4 ? INT32_MAX : INT64_MAX;
+            __int128 t = (__int128)acc[g].i + (__int128)xi;
+            if (t < lo || t > hi) acc[g].overflow = 1;
+            /* wrapped to the storage type, as atomic_add leaves it */
+            uint64_t wrapped = (uint64_t)acc[g].i + (uint64_t)xi;
+            acc[g].i = w == 1 ? (int64_t)(int8_t)wrapped : w == 2 ? (int64_t)(int16_t)wrapped : w == 4 ? (int64_t)(int32_t)wrapped : (int64_t)wrapped;
+            break;
+          }
           case K_PRODUCT: acc[g].f *= x; acc[g].i = (int64_t)((uint64_t)acc[g].i * (uint64_t)xi); break;
           case K_SUM_OF_SQUARES: acc[g].f += x * x; acc[g].i = (int64_t)((uint64_t)acc[g].i + (uint64_t)xi * (uint64_t)xi); break;
           case K_MIN:
@@ -406,6 +428,7 @@ int orc_groupby(const orc_column* keys, int32_t nkeys, int32_t include_null_keys
       if (kind == K_VARIANCE || kind == K_STD) nullable = 1; /* mask rebuilt from the group counts */
       orc_out_column* o = &res->results[oc];
       out_col_alloc(o, tgt, G, nullable);
+      if (kind == K_SUM_OVERFLOW) o->aux = (uint8_t*)calloc((size_t)(G ? G : 1), 1);
       int tcls = type_class(tgt);
       for (int32_t g = 0; g < G; ++g) {
         int valid = 1;
@@ -415,6 +438,13 @@ int orc_groupby(const orc_column* keys, int32_t nkeys, int32_t include_null_keys
           case K_SUM: case K_PRODUCT: case K_SUM_OF_SQUARES:
             valid = acc[g].nvalid > 0;
             if (tcls == C_F32 || tcls == C_F64) store_float(o, g, acc[g].f); else store_int(o, g, acc[g].i);
+            break;
+          case K_SUM_OVERFLOW:
+            /* children carry no masks; the struct is null when no valid value reached the group (output_utils.cu:83-111;
+             * KAT sum_overflow_tests.cpp:190-258: the children of a null struct read 0 / false) */
+            valid = acc[g].nvalid > 0;
+            store_int(o, g, valid ? acc[g].i : 0);
+            o->aux[g] = (uint8_t)(valid && acc[g].overflow);
             break;
           case K_MIN: case K_MAX:
             valid = acc[g].nvalid > 0;
@@ -427,7 +457,14 @@ int orc_groupby(const orc_column* keys, int32_t nkeys, int32_t include_null_keys
              * (extract_single_pass_aggs.cpp:63-74; hash_compound_agg_finalizer.cu:92-133) */
             valid = acc[g].nvalid > 0;
             double s = (cls == C_F32 || cls == C_F64) ? acc[g].f : (double)acc[g].i;
-            if (tgt != T_FLOAT64) { free(acc); orc_groupby_free(res); free(gid); free(rep); return fail(ORC_NOT_IMPLEMENTED, "MEAN of duration/decimal"); }
+            if (tgt != T_FLOAT64) {
+              /* duration / decimal: SUM in the source type (wrapped to its width) DIV count with the source type as output,
+               * i.e. C++ integer division of the representation (KATs mean_tests.cpp:152-198: {9,19,17}/{3,4,3} -> {3,4,5}) */
+              int w = type_width(tgt);
+              int64_t sw = w == 4 ? (int64_t)(int32_t)acc[g].i : acc[g].i;
+              store_int(o, g, valid ? sw / acc[g].nvalid : 0);
+              break;
+            }
             store_float(o, g, valid ? s / (double)acc[g].nvalid : 0.0);
             break;
           }

@@ -39,6 +39,7 @@ typedef struct {
   void* data;
   uint32_t* mask; /* NULL if the column is not nullable */
   int32_t null_count;
+  uint8_t* aux;   /* SUM_OVERFLOW: the overflow child (one bool per group); `data` is the sum child, `mask` the struct's; else NULL */
 } orc_out_column;
 
 typedef struct {

@@ -26,7 +26,7 @@ NP_OF_TYPE_ID = {1: np.int8, 2: np.int16, 3: np.int32, 4: np.int64, 5: np.uint8,
                  14: np.int64, 15: np.int64, 16: np.int64, 17: np.int32, 18: np.int64, 19: np.int64,
                  20: np.int64, 21: np.int64, 25: np.int32, 26: np.int64}
 # cudf::aggregation::Kind values (reference cpp/include/cudf/aggregation.hpp:78-121)
-KIND = {"sum": 0, "product": 2, "min": 3, "max": 4, "count_valid": 5, "count_all": 6, "sum_of_squares": 9,
+KIND = {"sum": 0, "sum_overflow": 1, "product": 2, "min": 3, "max": 4, "count_valid": 5, "count_all": 6, "sum_of_squares": 9,
         "mean": 10, "m2": 11, "variance": 12, "std": 13, "argmax": 16, "argmin": 17, "nth_element": 19}
 JOIN_NO_MATCH = -2**31
 
@@ -48,7 +48,7 @@ class _Req(C.Structure):
 
 class _OutCol(C.Structure):
     _fields_ = [("type_id", C.c_int32), ("size", C.c_int32), ("data", C.c_void_p), ("mask", C.c_void_p),
-                ("null_count", C.c_int32)]
+                ("null_count", C.c_int32), ("aux", C.c_void_p)]
 
 
 class _GbRes(C.Structure):
@@ -128,6 +128,9 @@ def _take_out(oc):
     if oc.mask:
         words = np.frombuffer(C.string_at(oc.mask, ((n + 31) // 32) * 4), dtype=np.uint32)
         valid = unpack_mask(words, n)
+    if oc.aux:  # SUM_OVERFLOW: struct {sum, overflow} -> tuple of the children, as Column.to_numpy() of a STRUCT column
+        flags = np.frombuffer(C.string_at(oc.aux, max(n, 0)), dtype=np.uint8).astype(bool) if n else np.zeros(0, bool)
+        return (data, flags), valid, oc.type_id
     return data, valid, oc.type_id
 
 

@@ -10,6 +10,8 @@
 #include <cudf/interop.hpp>
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
+#include <cudf/partitioning.hpp>
+#include <cudf/utilities/span.hpp>
 #include <cudf/table/table.hpp>
 
 #include <hip/hip_runtime.h>
@@ -18,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <map>
+#include <span>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -79,6 +82,29 @@ int main()
   CHECK(s[at[1]] == 9 && s[at[2]] == 19 && s[at[3]] == 17);
   CHECK(c[at[1]] == 3 && c[at[2]] == 4 && c[at[3]] == 3);
   CHECK(std::abs(m[at[1]] - 3.0) < 1e-12 && std::abs(m[at[2]] - 19.0 / 4) < 1e-12 && std::abs(m[at[3]] - 17.0 / 3) < 1e-12);
+
+  // the reference signature takes std::span<aggregation_request const> (groupby.hpp:181-184): a vector converts, and a
+  // span over part of it works the same
+  {
+    auto again = gb_obj.aggregate(std::span<cudf::groupby::aggregation_request const>{requests.data(), 1});
+    CHECK(again.first->num_rows() == 3 && again.second[0].results.size() == 3);
+  }
+  // SUM_OVERFLOW: struct {sum: source type, overflow: bool} (aggregation.hpp:214-217; sum_overflow_tests.cpp:41-90)
+  {
+    std::vector<cudf::groupby::aggregation_request> ro(1);
+    ro[0].values = vcol;
+    ro[0].aggregations.push_back(cudf::make_sum_overflow_aggregation<cudf::groupby_aggregation>());
+    auto out = gb_obj.aggregate(ro);
+    auto const& st = *out.second[0].results[0];
+    CHECK(st.type().id() == cudf::type_id::STRUCT && st.num_children() == 2 && st.size() == 3);
+    CHECK(st.view().child(0).type().id() == cudf::type_id::INT32 && st.view().child(1).type().id() == cudf::type_id::BOOL8);
+    auto ko = to_host<int32_t>(out.first->view().column(0));
+    auto so = to_host<int32_t>(st.view().child(0));
+    auto fo = to_host<uint8_t>(st.view().child(1));
+    std::map<int32_t, int32_t> mo;
+    for (int i = 0; i < 3; ++i) { mo[ko[i]] = so[i]; CHECK(fo[i] == 0); }
+    CHECK(mo[1] == 9 && mo[2] == 19 && mo[3] == 17);
+  }
 
   // size mismatch -> cudf::logic_error (groupby.cu:225-229)
   {
@@ -144,6 +170,32 @@ int main()
     CHECK(std::all_of(hcl.begin(), hcl.end(), [](auto x) { return x >= 2 && x < 5; }));
   }
 
+  // ---- finalize_partitioned_full_join takes host_span<device_span<size_type const> const> (hash_join.hpp:433-441)
+  {
+    auto ctx = hj.full_join_match_context(t0v);
+    cudf::join_partition_context p0{std::make_unique<cudf::join_match_context>(std::move(ctx)), 0, 5};
+    auto [fl, fr] = hj.partitioned_full_join(p0);
+    std::vector<cudf::device_span<cudf::size_type const>> lparts{cudf::device_span<cudf::size_type const>{*fl}};
+    std::vector<cudf::device_span<cudf::size_type const>> rparts{cudf::device_span<cudf::size_type const>{*fr}};
+    auto [tl, tr] = cudf::hash_join::finalize_partitioned_full_join(lparts, rparts, 5, 5);
+    // left rows {3,1,2,0,2} vs right {2,2,0,4,3}: 6 matched pairs + left row 1 (key 1) alone + right row 3 (key 4) alone
+    CHECK(tl->size() == 8 && tr->size() == 8);
+  }
+  // ---- hash_partition: num_partitions + 1 offsets, the last one the row count (partitioning.hpp:84-101); a keys table
+  {
+    auto [pt, offs] = cudf::hash_partition(t0v, std::vector<cudf::size_type>{0}, 3);
+    CHECK(offs.size() == 4 && offs[0] == 0 && offs[3] == 5 && pt->num_rows() == 5);
+    auto [pt2, offs2] = cudf::hash_partition(t0v, t1v, 3);
+    CHECK(offs2.size() == 4 && offs2[3] == 5);
+    bool threw = false;
+    try {
+      (void)cudf::hash_partition(t0v, std::vector<cudf::size_type>{-1}, 3);
+    } catch (std::out_of_range const&) {
+      threw = true;
+    }
+    CHECK(threw);
+  }
+
   // ---- Arrow C Data Interface: export the groupby result to host Arrow memory and import it again (interop.hpp)
   {
     std::vector<cudf::column_view> out_cols{result.first->view().column(0), result.second[0].results[0]->view()};
@@ -158,6 +210,24 @@ int main()
     auto k2 = to_host<int32_t>(back->view().column(0));
     auto s2 = to_host<int64_t>(back->view().column(1));
     CHECK(k2 == k && s2 == s);
+  }
+  // ---- device export and re-import without a host bounce (to_arrow_device, interop.hpp:500-610): the array's buffers are the
+  // columns' device buffers; from_arrow_device views them again
+  {
+    std::vector<cudf::column_view> out_cols{result.first->view().column(0), result.second[0].results[0]->view()};
+    cudf::table_view out_tv{out_cols};
+    auto schema = cudf::to_arrow_schema(out_tv, {cudf::column_metadata{"k"}, cudf::column_metadata{"sum"}});
+    auto darr   = cudf::to_arrow_device(out_tv);
+    CHECK(darr->device_type == ARROW_DEVICE_ROCM && darr->sync_event != nullptr && darr->array.n_children == 2);
+    CHECK(darr->array.children[0]->buffers[1] == out_tv.column(0).head());  // zero copy
+    auto tv = cudf::from_arrow_device(schema.get(), darr.get());
+    CHECK(tv->view.num_rows() == 3 && tv->view.column(1).data<int64_t>() == out_tv.column(1).data<int64_t>());
+    // the owning form: the table's buffers move into the array and stay valid until its release callback runs
+    auto copy  = std::make_unique<cudf::table>(out_tv);
+    auto owned = cudf::to_arrow_device(std::move(*copy));
+    copy.reset();
+    auto tv2 = cudf::from_arrow_device(schema.get(), owned.get());
+    CHECK(to_host<int32_t>(tv2->view.column(0)) == k && to_host<int64_t>(tv2->view.column(1)) == s);
   }
   // ---- zero-copy import of DEVICE Arrow data (ArrowDeviceArray, device_type ARROW_DEVICE_ROCM): the views alias the
   // producer's memory; a validity bitmap and an array offset are honoured

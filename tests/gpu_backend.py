@@ -8,7 +8,7 @@ from cudf_amd import groupby as gb
 from cudf_amd.types import DataType, NullEquality, NullPolicy, TypeId
 from oracle.oracle import KIND, HostColumn
 
-_AGG = {"sum": agg.sum, "min": agg.min, "max": agg.max, "mean": agg.mean,
+_AGG = {"sum": agg.sum, "sum_overflow": agg.sum_with_overflow, "min": agg.min, "max": agg.max, "mean": agg.mean,
         "count_valid": lambda: agg.count(NullPolicy.EXCLUDE), "count_all": lambda: agg.count(NullPolicy.INCLUDE),
         "sum_of_squares": agg.sum_of_squares, "nth_element": lambda: agg.nth_element(0), "median": agg.median,
         "variance": agg.variance, "std": agg.std, "m2": agg.m2, "product": agg.product, "argmin": agg.argmin, "argmax": agg.argmax}
@@ -25,7 +25,7 @@ def to_host_column(c):
 def to_device(c) -> cudf_amd.Column:
     h = to_host_column(c)
     data = h.data
-    dt = DataType(TypeId(h.type_id))
+    dt = DataType(TypeId(h.type_id), getattr(h, "scale", 0))
     if h.type_id == TypeId.BOOL8:
         data = data.astype(np.uint8)
     col = cudf_amd.Column.from_numpy(data, h.valid, dtype=dt, offset=h.offset)
@@ -34,6 +34,8 @@ def to_device(c) -> cudf_amd.Column:
 
 def from_device(col):
     data, valid = col.to_numpy()
+    if col.num_children():  # STRUCT (SUM_OVERFLOW {sum, overflow}): reported under the sum child's type, as the oracle does
+        return data, valid, int(col.child(0).type().id())
     return data, valid, int(col.type().id())
 
 

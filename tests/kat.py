@@ -27,9 +27,18 @@ def _num(x):
     return {"inf": np.inf, "-inf": -np.inf, "nan": np.nan}.get(x, x) if isinstance(x, str) else x
 
 
+def _sym(v, npt):
+    """"max-5" / "min+5": offsets from the limits of the column's storage type (the reference's typed overflow tests
+    build their inputs from numeric_limits, sum_overflow_tests.cpp:300-352)."""
+    if isinstance(v, str) and v[:3] in ("max", "min"):
+        base = np.iinfo(npt).max if v[:3] == "max" else np.iinfo(npt).min
+        return int(base) + (int(v[3:]) if len(v) > 3 else 0)
+    return _num(v)
+
+
 def host_col(values, type_name, valid=None):
     npt = NP_OF_TYPE_ID[TYPE_ID[type_name]]
-    arr = np.array([_num(v) for v in values], dtype=np.float64 if "float" in type_name else np.int64).astype(npt)
+    arr = np.array([_sym(v, npt) for v in values], dtype=np.float64 if "float" in type_name else np.int64).astype(npt)
     return HostColumn(arr, None if valid is None else np.array(valid, dtype=bool), type_name)
 
 
@@ -37,6 +46,8 @@ def expected_type_id(value_type, agg):
     integral = value_type in ("int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "bool")
     if agg in ("count_valid", "count_all", "argmin", "argmax"):
         return TYPE_ID["int32"]
+    if agg == "mean" and (value_type.startswith("duration") or value_type.startswith("decimal")):
+        return TYPE_ID[value_type]  # integer division in the source type (aggregation.hpp:935-941)
     if agg in ("mean", "variance", "std", "m2"):
         return TYPE_ID["float64"]
     if agg in ("sum", "sum_of_squares", "product"):
@@ -91,7 +102,8 @@ def sort_groups(key_cols, result_cols):
         else:
             sort_keys.append(d)
     order = np.lexsort(sort_keys)
-    perm = lambda col: (col[0][order], None if col[1] is None else col[1][order], col[2])
+    take = lambda d: tuple(x[order] for x in d) if isinstance(d, tuple) else d[order]  # (struct column: tuple of children)
+    perm = lambda col: (take(col[0]), None if col[1] is None else col[1][order], col[2])
     return [perm(c) for c in key_cols], [[perm(c) for c in req] for req in result_cols]
 
 
@@ -107,6 +119,20 @@ def compare_columns(actual, expected, what="", atol=0.0):
     a_data, a_valid, a_tid = actual
     e_data, e_valid, e_tid = expected
     assert a_tid == e_tid, f"{what}: type id {a_tid} != {e_tid}"
+    if isinstance(e_data, tuple):
+        # SUM_OVERFLOW struct {sum, overflow}: validity and flags exact; sums exact where the group did not overflow (an
+        # overflowed group's sum depends on the arrival order of the reference's atomics; its own tests compare only the flags,
+        # sum_overflow_tests.cpp:271-288)
+        assert isinstance(a_data, tuple) and len(a_data) == 2, f"{what}: expected a struct of two children"
+        n = len(e_data[0])
+        av = np.ones(n, bool) if a_valid is None else a_valid
+        ev = np.ones(n, bool) if e_valid is None else e_valid
+        assert len(a_data[0]) == n and np.array_equal(av, ev), f"{what}: struct validity differs\n{av}\n{ev}"
+        af, ef = np.asarray(a_data[1], bool), np.asarray(e_data[1], bool)
+        assert np.array_equal(af[ev], ef[ev]), f"{what}: overflow flags differ\n{af}\n{ef}"
+        ok = ev & ~ef
+        assert np.array_equal(np.asarray(a_data[0])[ok], np.asarray(e_data[0])[ok]), f"{what}: sums differ\n{a_data[0]}\n{e_data[0]}"
+        return
     assert len(a_data) == len(e_data), f"{what}: size {len(a_data)} != {len(e_data)}"
     av = np.ones(len(a_data), bool) if a_valid is None else a_valid
     ev = np.ones(len(e_data), bool) if e_valid is None else e_valid
@@ -117,6 +143,8 @@ def compare_columns(actual, expected, what="", atol=0.0):
     is_float = np.dtype(NP_OF_TYPE_ID[a_tid]).kind == "f"
     a = a_data[av]
     e = e_data[ev]
+    if isinstance(atol, np.ndarray):  # one bound per row (per group)
+        atol = atol[ev]
     if a_tid == TYPE_ID["float32"]:
         assert equivalent_f32(a, e, atol), f"{what}: values differ\n{a}\n{e}"
     else:
@@ -143,6 +171,8 @@ def run_groupby_case(backend, c, kt, vt):
     exp_tid = expected_type_id(vt, c["agg"])
     exp_np = NP_OF_TYPE_ID[exp_tid]
     ev_data = np.array([_num(v) for v in c["expect"]], dtype=np.float64 if np.dtype(exp_np).kind == "f" else np.int64).astype(exp_np)
+    if c["agg"] == "sum_overflow":
+        ev_data = (ev_data, np.array(c["expect_overflow"], dtype=bool))
     ev_valid = None if c["expect_valid"] is None else np.array(c["expect_valid"], dtype=bool)
     ekc, erc = sort_groups([(ek.data, ek.valid, ek.type_id)], [[(ev_data, ev_valid, exp_tid)]])
     compare_columns(kc[0], ekc[0], "keys")

@@ -13,7 +13,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "api_compat.bin")
 def _build():
     lib_dir = os.path.join(ROOT, "cudf_amd", "lib")
     assert os.path.exists(os.path.join(lib_dir, "libcudf_amd.so")), "build the library first (__graft_entry__.build())"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++20", "-O1", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "include"),
                            SRC, "-o", EXE, "-L", lib_dir, "-lcudf_amd", f"-Wl,-rpath,{lib_dir}"])
 
 

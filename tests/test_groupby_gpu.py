@@ -485,13 +485,35 @@ def test_fuzz_against_oracle(G, oracle, seed, monkeypatch):
     assert len(got[0]) == len(exp[0])
     for a, e in zip(got[0], exp[0]):
         kat.compare_columns(a, e, "keys")
+    eps = np.finfo(np.float64).eps
     for (vals, kinds), ra, re_ in zip(requests, got[1], exp[1]):
         is_f = np.dtype(vals.data.dtype).kind == "f"
+        # per-group bounds from the rows actually present: m = valid rows of the group, vmax = largest magnitude
+        cnt = kat.sort_groups(*oracle.groupby(keys, [(vals, ["count_valid"])], include_null_keys=include))[1][0][0][0]
+        m = np.maximum(cnt.astype(np.float64), 1.0)
+        vmax = float(np.max(np.abs(vals.data.astype(np.float64)))) if vals.size else 0.0
         for kind, a, e in zip(kinds, ra, re_):
-            # values are multiples of 0.25 below 2.25 in magnitude: float sums of <= n terms are exact in float64; float32
-            # results and the cancelling M2/variance/std formulas carry rounding
-            loose = kind in ("variance", "std", "m2", "product", "mean") or (is_f and vals.data.dtype == np.float32)
-            kat.compare_columns(a, e, f"{kind}({vals.type_name if hasattr(vals, 'type_name') else ''})", atol=1e-6 * max(1, n) if loose else 0.0)
+            # The reference sums with unordered atomics, so two correct results differ by at most the worst-case bound of any
+            # summation order, m^2 * eps * max|v| (kat.sum_atol) - per GROUP here, not per input size:
+            if not is_f:
+                atol = 0.0 if kind not in ("mean", "variance", "std", "m2") else None
+            if kind in ("sum", "sum_of_squares") and is_f:
+                atol = m * m * eps * max(vmax, vmax * vmax)
+            elif kind == "mean":
+                # sum error / count; an integer sum is exact and the division is one correctly rounded operation
+                atol = (m * m * eps * vmax / m) if is_f else 0.0
+            elif kind in ("m2", "variance", "std"):
+                # M2 = ssq - s*s/n: the subtraction cancels, the absolute error stays within a few ulps of ssq <= m * vmax^2
+                # (the bound test_variance_std_m2 uses); VAR divides it by (m - 1); |sqrt(a) - sqrt(b)| <= sqrt(|a - b|) for STD
+                m2_atol = 8.0 * eps * m * vmax * vmax + (m * m * eps * vmax * vmax if is_f else 0.0)
+                atol = m2_atol if kind == "m2" else m2_atol / np.maximum(m - 1.0, 1.0)
+                if kind == "std":
+                    atol = np.sqrt(atol)
+            elif kind == "product" and is_f:
+                atol = 2.0 * m * eps * np.maximum(1.0, vmax) ** np.minimum(m, 64.0)  # m roundings of a product of magnitude <= vmax^m
+            elif is_f or kind in ("min", "max", "count_valid", "count_all", "argmin", "argmax"):
+                atol = 0.0  # exact (float32 results: compare_columns allows 4 float32 ulps of the float64 reference)
+            kat.compare_columns(a, e, f"{kind}({vals.type_id})", atol=atol)
 
 
 @pytest.mark.parametrize("vt", ["float64", "int64"])
@@ -509,3 +531,68 @@ def test_heavy_hitters(G, oracle, vt, hot_fraction):
     npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
     v = rng.random(n).astype(npt) if vt == "float64" else rng.integers(-1000, 1000, n).astype(npt)
     _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), ["sum", "count_valid", "mean"])], expect_path="PARTITIONED_LDS")
+
+
+@pytest.mark.parametrize("vt", ["int8", "int16", "int32", "int64", "decimal32", "decimal64"])
+@pytest.mark.parametrize("n,groups", [(20_000, 37), (600_000, 90_000)])
+def test_sum_overflow_against_oracle(G, oracle, vt, n, groups):
+    """SUM_OVERFLOW -> struct {sum: source type, overflow: bool} (reference device_aggregators.cuh:136-160). Values of one
+    sign per group, so that a group overflows in every order of the additions or in none: the reference's flag depends on
+    the arrival order of its atomics otherwise. Sums compared where the group did not overflow, flags everywhere."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(61)
+    npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
+    info = np.iinfo(npt)
+    k = rng.integers(0, groups, n).astype(np.int32)
+    sign = np.where((k % 3) == 0, -1, 1)
+    per_group = max(1, n // groups)
+    mag = rng.integers(0, max(2, int(info.max // per_group) * 2), n, dtype=np.int64)  # about half the groups overflow
+    v = (sign * mag).astype(np.int64).clip(info.min, info.max).astype(npt)
+    vv = rng.random(n) > 0.2
+    _check_against_oracle(G, oracle, [k], [(HostColumn(v, vv, vt), ["sum_overflow", "count_valid"])])
+    _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), ["sum_overflow"])])
+
+
+@pytest.mark.parametrize("ddof", [0, 1, 3])
+def test_variance_std_ddof(G, ddof):
+    """ddof travels through the C ABI (cudf_amd_aggregation_request.params; make_variance_aggregation(ddof),
+    reference aggregation.hpp:259-266): VAR = M2 / (count - ddof), null when count - ddof <= 0."""
+    import cudf_amd
+    from cudf_amd import aggregation as agg, groupby as gb
+    rng = np.random.default_rng(5)
+    n = 50_000
+    k = rng.integers(0, 500, n).astype(np.int32)
+    k[:3] = [10_000, 10_000, 10_001]  # groups of 2 rows and 1 row
+    v = rng.normal(size=n)
+    req = gb.GroupByRequest(cudf_amd.Column.from_numpy(v), [agg.variance(ddof), agg.std(ddof), agg.count()])
+    keys, res = gb.GroupBy(cudf_amd.Table([cudf_amd.Column.from_numpy(k)])).aggregate([req])
+    kk = keys.columns()[0].to_numpy()[0]
+    (var, var_valid), (std, std_valid), (cnt, _) = [c.to_numpy() for c in res[0].columns()]
+    for g, key in enumerate(kk):
+        x = v[k == key]
+        if len(x) - ddof <= 0:
+            assert not var_valid[g] and not std_valid[g]
+            continue
+        assert var_valid[g] and std_valid[g]
+        np.testing.assert_allclose(var[g], np.var(x, ddof=ddof), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(std[g], np.std(x, ddof=ddof), rtol=1e-9, atol=1e-12)
+
+
+def test_all_nan_group_min_max_argmin_argmax_pinned(G):
+    """The chosen behaviour for a group whose valid values are all NaN (the reference pins only
+    termination, max_tests.cpp:526-549, and its CAS loops leave the outcome to the arrival order): a NaN never replaces a
+    number, so MIN / MAX stay at their identities (+inf / -inf), and ARGMIN / ARGMAX, which look for a row that attains the
+    extreme, find none and return -1. A group with one number among NaNs returns that number and its row."""
+    import cudf_amd
+    from cudf_amd import aggregation as agg, groupby as gb
+    k = np.array([1, 1, 2, 2, 2, 3], np.int32)
+    v = np.array([np.nan, np.nan, np.nan, 5.0, np.nan, 7.0])
+    req = gb.GroupByRequest(cudf_amd.Column.from_numpy(v), [agg.min(), agg.max(), agg.argmin(), agg.argmax()])
+    keys, res = gb.GroupBy(cudf_amd.Table([cudf_amd.Column.from_numpy(k)])).aggregate([req])
+    kk = keys.columns()[0].to_numpy()[0]
+    order = np.argsort(kk)
+    mn, mx, amn, amx = [c.to_numpy()[0][order] for c in res[0].columns()]
+    assert kk[order].tolist() == [1, 2, 3]
+    assert mn[0] == np.inf and mx[0] == -np.inf and amn[0] == -1 and amx[0] == -1
+    assert mn[1:].tolist() == [5.0, 7.0] and mx[1:].tolist() == [5.0, 7.0]
+    assert amn[1:].tolist() == [3, 5] and amx[1:].tolist() == [3, 5]

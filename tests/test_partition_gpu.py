@@ -48,7 +48,8 @@ def test_hash_partition(G, oracle, nparts, n):
     cols = _cols(rng, n)
     t = cudf_amd.Table([G.to_device(c) for c in cols])
     out, offs = partitioning.hash_partition(t, [0, 1], nparts)
-    assert len(offs) == nparts
+    assert len(offs) == nparts + 1 and offs[-1] == n  # reference partitioning.hpp:84-101
+    offs = offs[:nparts]
     if n == 0:
         assert out.num_rows() == 0 and all(o == 0 for o in offs)
         return
@@ -73,6 +74,72 @@ def test_hash_partition(G, oracle, nparts, n):
     # null counts preserved
     for c, o in zip(cols, out.columns()):
         assert o.null_count() == c.null_count
+
+
+def test_hash_partition_edge_cases(G):
+    """The reference's edge KATs (cpp/tests/partitioning/hash_partition_test.cpp:48-141,341-368): a column index outside
+    the table, zero partitions, zero rows, zero hash columns, a custom seed."""
+    import cudf_amd
+    from cudf_amd import partitioning
+    floats = np.arange(1, 9, dtype=np.float32)
+    ints = np.arange(1, 9, dtype=np.int16)
+    codes = np.array([0, 1, 2, 3, 4, 5, 6, 7], dtype=np.int32)  # (the reference's string column, as codes)
+    t = cudf_amd.Table([G.to_device(floats), G.to_device(ints), G.to_device(codes)])
+    with pytest.raises(IndexError):  # InvalidColumnsToHash: std::out_of_range
+        partitioning.hash_partition(t, [-1], 3)
+    out, offs = partitioning.hash_partition(t, [2], 0)  # ZeroPartitions
+    assert out.num_columns() == 3 and out.num_rows() == 0 and len(offs) == 1
+    empty = cudf_amd.Table([G.to_device(floats[:0]), G.to_device(ints[:0]), G.to_device(codes[:0])])
+    out, offs = partitioning.hash_partition(empty, [2], 3)  # ZeroRows
+    assert out.num_columns() == 3 and out.num_rows() == 0 and offs == [0, 0, 0, 0]
+    out, offs = partitioning.hash_partition(cudf_amd.Table([]), [], 3)  # ZeroColumns
+    assert out.num_columns() == 0 and out.num_rows() == 0 and len(offs) == 4
+    out, offs = partitioning.hash_partition(t, [], 3)  # ZeroColumnsNonEmptyTable
+    assert out.num_columns() == 3 and out.num_rows() == 0 and len(offs) == 4
+    assert [int(c.type().id()) for c in out.columns()] == [int(c.type().id()) for c in t.columns()]
+    o1, f1 = partitioning.hash_partition(t, [0, 2], 3, seed=12345)  # CustomSeedValue: deterministic, same shape
+    o2, f2 = partitioning.hash_partition(t, [0, 2], 3, seed=12345)
+    assert len(f1) == 4 and f1 == f2 and o1.num_rows() == 8
+    for a, b in zip(o1.columns(), o2.columns()):
+        assert np.array_equal(a.to_numpy()[0], b.to_numpy()[0])
+    o3, f3 = partitioning.hash_partition(t, [0, 2], 3, seed=0)
+    assert sorted(o3.columns()[1].to_numpy()[0].tolist()) == list(range(1, 9))
+
+
+@pytest.mark.parametrize("nparts", [2048, 4096])
+def test_hash_partition_many_partitions(G, oracle, nparts):
+    """More than 1024 partitions need more than the default 64 KiB of dynamic LDS (139 KiB at 4096): the kernel opts in."""
+    import cudf_amd
+    from cudf_amd import partitioning
+    rng = np.random.default_rng(9)
+    n = 200_000
+    k = rng.integers(0, 1 << 40, n, dtype=np.int64)
+    v = rng.random(n)
+    out, offs = partitioning.hash_partition(cudf_amd.Table([G.to_device(k), G.to_device(v)]), [0], nparts)
+    part, eoffs, order = oracle.hash_partition([k], nparts)
+    assert offs[:nparts] == [int(x) for x in eoffs] and offs[-1] == n
+    ok, ov = out.columns()[0].to_numpy()[0], out.columns()[1].to_numpy()[0]
+    assert np.array_equal(oracle.hash_partition([ok], nparts)[0], np.repeat(np.arange(nparts), np.diff(offs)))
+    assert sorted(zip(ok.tolist(), ov.tolist())) == sorted(zip(k.tolist(), v.tolist()))
+
+
+def test_gather_negative_indices(G):
+    """Negative indices of a signed gather map count from the end (reference copying/gather.cu:81-82); JoinNoMatch
+    (INT32_MIN) stays out of bounds."""
+    import cudf_amd
+    from cudf_amd import partitioning
+    from cudf_amd.types import OutOfBoundsPolicy
+    data = np.arange(100, 110, dtype=np.int64)
+    valid = np.array([1, 1, 0, 1, 1, 1, 1, 1, 1, 0], bool)
+    t = cudf_amd.Table([G.to_device((data, valid)), G.to_device(np.arange(10, dtype=np.float64))])
+    idx = np.array([-1, -10, 0, 9, -2**31, 10, -3, -11], np.int32)
+    out = partitioning.gather(t, G.to_device(idx), OutOfBoundsPolicy.NULLIFY)
+    d0, v0 = out.columns()[0].to_numpy()
+    d1, v1 = out.columns()[1].to_numpy()
+    assert v1.tolist() == [True, True, True, True, False, False, True, False]
+    assert d1[v1].tolist() == [9.0, 0.0, 0.0, 9.0, 7.0]
+    assert v0.tolist() == [False, True, True, False, False, False, True, False]
+    assert d0[v0].tolist() == [100, 100, 107]
 
 
 def test_gather_with_nullify(G):
