@@ -8,13 +8,11 @@ with 1M groups (configs[1], "C2"), one process per GPU.
 A step = one pass of the hot path over one batch of synthetic rows already resident in HBM:
   N == 1: cudf::groupby::groupby(keys).aggregate({values, [SUM, COUNT_VALID]}) through the C ABI.
   N  > 1: configs[4] ("C5", weak scaling, 1B rows per GPU), hash-partitioned all-to-all in its COMBINER form
-          (`value`): per-GPU groupby of the local 1B rows -> hash-range partition of the partial groups by owner rank
-          -> RCCL all-to-all (torch.distributed, backend nccl == RCCL over xGMI) -> per-GPU merge groupby. Every row
-          is aggregated, the result is identical, and xGMI carries the <= 1M partial groups instead of 16 GB of raw
-          rows per GPU. The literal raw-row form (partition the ROWS -> all-to-all -> groupby) is timed in the same
-          run and reported beside it as `raw_row_shuffle_variant`: it is bound by the point-to-point xGMI links
-          ((N-1)/N of 16 GB per GPU over N-1 links), not by anything this library does. BENCH_DIST_MODE=shuffle swaps
-          which of the two is `value`.
+          (`value`) in its LITERAL form, inside the library: cudf::distributed::shuffle_groupby = hash-range partition of the
+          local ROWS by owner rank -> counts by ncclAllGather, rows by ncclSend/ncclRecv over xGMI -> per-GPU groupby. It is
+          bound by the point-to-point xGMI links ((N-1)/N of 16 GB per GPU over N-1 links). The combiner form (per-GPU
+          groupby -> exchange of the <= 1M partial groups -> merge; identical result, xGMI carries MBs) is timed in the
+          same run and reported beside it as `preaggregated_variant`. BENCH_DIST_MODE=preaggregate swaps which is `value`.
 Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events on the launch stream (the library's
 per-kernel profiler); `cpu_baseline` times the CPU oracle (oracle/, test infrastructure) on a bounded sample of the
 same workload on this box's host cores, plus pandas/Arrow on configs[0] (10M rows).
@@ -115,8 +113,11 @@ def main():
     stream = torch.cuda.current_stream()
 
     force_dist = os.environ.get("BENCH_FORCE_DISTRIBUTED") == "1"  # rehearse the N>1 code path on one GPU
-    dist_mode = os.environ.get("BENCH_DIST_MODE", "preaggregate")
-    other_mode = "shuffle" if dist_mode == "preaggregate" else "preaggregate"
+    # N > 1: `value` is the LITERAL config-5 form, inside the library (cudf::distributed::shuffle_groupby: hash-range partition of
+    # the rows -> RCCL Send/Recv -> per-GPU groupby); the combiner form is timed in the same run and reported beside it.
+    # BENCH_DIST_MODE = shuffle_native (default) | shuffle (the same through torch.distributed) | preaggregate (combiner as `value`)
+    dist_mode = os.environ.get("BENCH_DIST_MODE", "shuffle_native")
+    other_mode = "shuffle_native" if dist_mode == "preaggregate" else "preaggregate"
     if world == 1 and force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
@@ -190,23 +191,25 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("C2: 1xMI355X hash-groupby SUM+COUNT_VALID, single int64 key, float64 value, no nulls"
                                     if world == 1 else
-                                    ("C5 (combiner form): per-GPU groupby SUM+COUNT_VALID -> hash-range partition of the partial "
-                                     "groups + RCCL all-to-all -> per-GPU merge groupby" if dist_mode == "preaggregate" else
-                                     "C5 (raw-row form): hash-range partition of the rows + RCCL all-to-all -> per-GPU groupby SUM+COUNT_VALID")),
+                                    ("combiner variant of C5 (NOT the BASELINE config): per-GPU groupby SUM+COUNT_VALID -> hash partition of the "
+                                     "partial groups + RCCL all-to-all -> per-GPU merge groupby" if dist_mode == "preaggregate" else
+                                     "C5: 8xMI355X hash-partition of the ROWS by owner rank (hash-range) + RCCL all-to-all over xGMI, then per-GPU "
+                                     "groupby SUM+COUNT_VALID" + (" [inside the library: cudf::distributed::shuffle_groupby]" if dist_mode == "shuffle_native"
+                                                                  else " [exchange through torch.distributed]"))),
                        "rows_per_gpu": n, "groups": groups, "key": "int64 uniform [0, groups)", "value": "float64 uniform [0,1)",
                        "path": (last[0].last_path.name if (world == 1 and not force_dist) else "PARTITION+ALLTOALL+GROUPBY:" + dist_mode)},
             "roofline": roof,
         }
         if pre is not None:
-            name = "raw_row_shuffle_variant" if other_mode == "shuffle" else "preaggregated_variant"
-            what = ("hash-partition the raw ROWS by owner rank -> RCCL all-to-all (16 GB x (N-1)/N per GPU over the "
-                    "point-to-point xGMI links) -> per-GPU groupby; same result" if other_mode == "shuffle" else
+            name = "raw_row_shuffle_variant" if other_mode != "preaggregate" else "preaggregated_variant"
+            what = ("C5 literal form: hash-range partition of the raw ROWS by owner rank -> RCCL Send/Recv (16 GB x (N-1)/N per GPU over the "
+                    "point-to-point xGMI links) -> per-GPU groupby; same result" if other_mode != "preaggregate" else
                     "local groupby -> hash-partition + RCCL all-to-all of the partial (key, sum, count) rows -> merge; "
                     "same result, xGMI carries MBs")
             line[name] = {"value": total_rows * args.steps / pre, "unit": "rows/s", "ms_per_step": pre / args.steps * 1e3,
                           "what": what}
         if pre_error is not None:
-            line["raw_row_shuffle_variant" if other_mode == "shuffle" else "preaggregated_variant"] = {"error": pre_error}
+            line["raw_row_shuffle_variant" if other_mode != "preaggregate" else "preaggregated_variant"] = {"error": pre_error}
         if world == 1 and not force_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(groups, args.cpu_sample_rows)
         return line

@@ -57,6 +57,14 @@ SYMBOLS = {
                                                    C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     "cudf_amd_hash_partition": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
                                           C.c_uint32, _P, C.POINTER(_P), C.POINTER(C.c_int32)]),
+    "cudf_amd_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "cudf_amd_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "cudf_amd_comm_destroy": (None, [_P]),
+    "cudf_amd_range_partition": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P,
+                                           C.POINTER(_P), C.POINTER(C.c_int32)]),
+    "cudf_amd_shuffle": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.POINTER(C.c_int32), C.c_int32, _P, C.POINTER(_P)]),
+    "cudf_amd_shuffle_groupby": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.c_int32, C.POINTER(AggregationRequest),
+                                           C.c_int32, _P, C.POINTER(_P), C.POINTER(_P)]),
     "cudf_amd_murmurhash3_x86_32": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.c_uint32, _P, C.POINTER(_P)]),
     "cudf_amd_gather": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.POINTER(ColumnView), C.c_int32, _P, C.POINTER(_P)]),
 }

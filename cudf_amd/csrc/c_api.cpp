@@ -6,6 +6,7 @@
 #include "common/profiler.hpp"
 
 #include <cudf/copying.hpp>
+#include <cudf/distributed.hpp>
 #include <cudf/groupby.hpp>
 #include <cudf/partitioning.hpp>
 #include <cudf/interop.hpp>
@@ -25,6 +26,9 @@
 
 struct cudf_amd_table_s {
   std::vector<std::unique_ptr<cudf::column>> cols;
+};
+struct cudf_amd_comm_s {
+  std::unique_ptr<cudf::distributed::communicator> comm;
 };
 struct cudf_amd_hash_join_s {
   std::unique_ptr<cudf::hash_join> hj;
@@ -450,6 +454,80 @@ cudf_amd_status cudf_amd_hash_partition(const cudf_amd_column_view* input, int32
     auto h  = std::make_unique<cudf_amd_table_s>();
     h->cols = tbl->release();
     *out_table = h.release();
+  });
+}
+
+cudf_amd_status cudf_amd_comm_unique_id(uint8_t* out_id_128_bytes)
+{
+  return guarded([&] {
+    auto const id = cudf::distributed::communicator::make_unique_id();
+    std::memcpy(out_id_128_bytes, id.data(), id.size());
+  });
+}
+cudf_amd_status cudf_amd_comm_create(const uint8_t* id_128_bytes, int32_t world_size, int32_t rank, cudf_amd_comm_t* out)
+{
+  return guarded([&] {
+    *out = nullptr;
+    cudf::distributed::unique_id id{};
+    std::memcpy(id.data(), id_128_bytes, id.size());
+    auto h  = std::make_unique<cudf_amd_comm_s>();
+    h->comm = std::make_unique<cudf::distributed::communicator>(id, world_size, rank);
+    *out    = h.release();
+  });
+}
+void cudf_amd_comm_destroy(cudf_amd_comm_t comm) { delete comm; }
+cudf_amd_status cudf_amd_range_partition(const cudf_amd_column_view* input, int32_t num_columns, const int32_t* key_columns,
+                                         int32_t num_key_columns, int32_t num_destinations, void* stream,
+                                         cudf_amd_table_t* out_table, int32_t* out_offsets)
+{
+  return guarded([&] {
+    *out_table = nullptr;
+    std::vector<cudf::size_type> keys(key_columns, key_columns + num_key_columns);
+    auto [tbl, offs] = cudf::distributed::range_partition(to_table(input, num_columns), keys, num_destinations, cudf::stream_ref{as_stream(stream)});
+    for (size_t i = 0; i < offs.size(); ++i) out_offsets[i] = offs[i];
+    auto h  = std::make_unique<cudf_amd_table_s>();
+    h->cols = tbl->release();
+    *out_table = h.release();
+  });
+}
+cudf_amd_status cudf_amd_shuffle(cudf_amd_comm_t comm, const cudf_amd_column_view* input, int32_t num_columns,
+                                 const int32_t* key_columns, int32_t num_key_columns, void* stream, cudf_amd_table_t* out_table)
+{
+  return guarded([&] {
+    *out_table = nullptr;
+    CUDF_EXPECTS(comm != nullptr && comm->comm != nullptr, "null communicator", std::invalid_argument);
+    std::vector<cudf::size_type> keys(key_columns, key_columns + num_key_columns);
+    auto tbl = cudf::distributed::shuffle(to_table(input, num_columns), keys, *comm->comm, cudf::stream_ref{as_stream(stream)});
+    auto h   = std::make_unique<cudf_amd_table_s>();
+    h->cols  = tbl->release();
+    *out_table = h.release();
+  });
+}
+cudf_amd_status cudf_amd_shuffle_groupby(cudf_amd_comm_t comm, const cudf_amd_column_view* keys, int32_t num_keys,
+                                         int32_t include_null_keys, const cudf_amd_aggregation_request* requests,
+                                         int32_t num_requests, void* stream, cudf_amd_table_t* out_keys,
+                                         cudf_amd_table_t* out_results)
+{
+  return guarded([&] {
+    *out_keys    = nullptr;
+    *out_results = nullptr;
+    CUDF_EXPECTS(comm != nullptr && comm->comm != nullptr, "null communicator", std::invalid_argument);
+    auto const kt = to_table(keys, num_keys);
+    std::vector<cudf::groupby::aggregation_request> reqs(num_requests);
+    for (int32_t r = 0; r < num_requests; ++r) {
+      reqs[r].values = to_view(requests[r].values);
+      for (int32_t k = 0; k < requests[r].num_kinds; ++k)
+        reqs[r].aggregations.push_back(make_agg(requests[r].kinds[k], requests[r].params ? requests[r].params + k : nullptr));
+    }
+    auto [ukeys, results] = cudf::distributed::shuffle_groupby(
+      kt, reqs, *comm->comm, include_null_keys ? cudf::null_policy::INCLUDE : cudf::null_policy::EXCLUDE, cudf::stream_ref{as_stream(stream)});
+    auto kh  = std::make_unique<cudf_amd_table_s>();
+    kh->cols = ukeys->release();
+    auto rh  = std::make_unique<cudf_amd_table_s>();
+    for (auto& r : results)
+      for (auto& c : r.results) rh->cols.push_back(std::move(c));
+    *out_keys    = kh.release();
+    *out_results = rh.release();
   });
 }
 

@@ -1,0 +1,516 @@
+// SPDX-License-Identifier: Apache-2.0
+// Multi-GPU exchange of table rows by key ownership (include/cudf/distributed.hpp): hash-range partition kernels and the
+// RCCL point-to-point exchange. Role of the reference's cpp/libcudf_streaming/src/partition_utils.cpp:72-185
+// (hash_partition -> pack -> shuffle -> unpack); the split itself restates partitioning.cu:187-337 (histogram, scan,
+// LDS-staged scatter) for a handful of destinations and 64-lane waves.
+#include "../common/device_table.hpp"
+#include "../common/profiler.hpp"
+
+#include <cudf/distributed.hpp>
+#include <cudf/null_mask.hpp>
+#include <cudf/utilities/error.hpp>
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+
+namespace cudf {
+namespace distributed {
+namespace {
+using cudf::detail::device_column;
+using cudf::detail::device_table;
+using cudf::detail::gload;
+using cudf::detail::gstore;
+using cudf::detail::MAX_COLS;
+
+// ------------------------------------------------------------------ RCCL, resolved at run time
+struct rccl_api {
+  decltype(&ncclGetUniqueId) GetUniqueId{};
+  decltype(&ncclCommInitRank) CommInitRank{};
+  decltype(&ncclCommDestroy) CommDestroy{};
+  decltype(&ncclAllGather) AllGather{};
+  decltype(&ncclSend) Send{};
+  decltype(&ncclRecv) Recv{};
+  decltype(&ncclGroupStart) GroupStart{};
+  decltype(&ncclGroupEnd) GroupEnd{};
+  decltype(&ncclGetErrorString) GetErrorString{};
+};
+rccl_api const& rccl()
+{
+  static rccl_api api = [] {
+    rccl_api a{};
+    // a copy already in the process (torch.distributed's) is reused; otherwise ROCm's
+    void* h = nullptr;
+    for (char const* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h != nullptr) break;
+    }
+    CUDF_EXPECTS(h != nullptr, "librccl.so could not be loaded: the multi-GPU exchange needs RCCL");
+    auto sym = [&](char const* n) {
+      void* p = dlsym(h, n);
+      CUDF_EXPECTS(p != nullptr, std::string{"librccl.so lacks "} + n);
+      return p;
+    };
+    a.GetUniqueId    = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank   = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy    = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.AllGather      = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+    a.Send           = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv           = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.GroupStart     = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd       = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    return a;
+  }();
+  return api;
+}
+#define CUDF_RCCL_TRY(call)                                                                              \
+  do {                                                                                                   \
+    ncclResult_t const r_ = (call);                                                                      \
+    if (r_ != ncclSuccess) CUDF_FAIL(std::string{"RCCL error: "} + rccl().GetErrorString(r_) + " in " #call); \
+  } while (0)
+
+// ------------------------------------------------------------------ hash-range partition kernels
+constexpr int RP_BLOCK = 1024, RP_R = 4, RP_TILE = RP_BLOCK * RP_R, RP_MAX_PARTS = 64;
+struct rp_args {
+  device_table hashed;
+  device_table all;
+  int32_t nparts;
+  int32_t wgs;
+  int64_t nrows;
+  int64_t chunk;       // rows per workgroup (multiple of RP_TILE)
+  uint32_t* counts;    // [wgs][nparts]
+  int64_t* cell_base;  // [wgs][nparts]
+  int64_t* offsets;    // [nparts + 1]
+  void* out[MAX_COLS];
+};
+template <typename T>
+__global__ void k_store(T v, T* dst)
+{
+  *dst = v;
+}
+__device__ __forceinline__ uint32_t dest_of(rp_args const& a, int64_t row)
+{
+  uint32_t const h = cudf::detail::row_hash(a.hashed, row, 0u);
+  return static_cast<uint32_t>((static_cast<uint64_t>(h) * static_cast<uint32_t>(a.nparts)) >> 32);
+}
+__global__ void __launch_bounds__(RP_BLOCK) k_rp_hist(rp_args const* __restrict__ ap)
+{
+  __shared__ uint32_t whist[16 * RP_MAX_PARTS];  // one histogram per wave: 64 lanes on <= 64 addresses
+  rp_args const& a = *ap;
+  int const N = a.nparts, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 16 * N; i += RP_BLOCK) whist[i] = 0;
+  __syncthreads();
+  int64_t const begin = static_cast<int64_t>(blockIdx.x) * a.chunk, end = min(a.nrows, begin + a.chunk);
+  for (int64_t r = begin + threadIdx.x; r < end; r += RP_BLOCK) atomicAdd(&whist[wave * N + dest_of(a, r)], 1u);
+  __syncthreads();
+  for (int d = threadIdx.x; d < N; d += RP_BLOCK) {
+    uint32_t t = 0;
+    for (int w = 0; w < 16; ++w) t += whist[w * N + d];
+    a.counts[static_cast<int64_t>(blockIdx.x) * N + d] = t;
+  }
+}
+__global__ void __launch_bounds__(64) k_rp_scan(rp_args const* __restrict__ ap)
+{
+  rp_args const& a = *ap;
+  int const N = a.nparts;
+  if (threadIdx.x == 0) {  // (wgs * nparts <= 64K entries: one lane is enough)
+    int64_t run = 0;
+    for (int d = 0; d < N; ++d) {
+      a.offsets[d] = run;
+      for (int w = 0; w < a.wgs; ++w) {
+        a.cell_base[static_cast<int64_t>(w) * N + d] = run;
+        run += a.counts[static_cast<int64_t>(w) * N + d];
+      }
+    }
+    a.offsets[N] = run;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void move_column(device_column const& col, void* out, int64_t tile, int64_t end, uint32_t const (&lpos)[RP_R],
+                                            T* stage, uint8_t const* sdest, uint32_t const* doff, int64_t const* gcur, uint32_t tile_rows)
+{
+  T const* src = static_cast<T const*>(col.head) + col.offset;
+  T v[RP_R];
+#pragma unroll
+  for (int k = 0; k < RP_R; ++k) {
+    int64_t const r = tile + static_cast<int64_t>(k) * RP_BLOCK + threadIdx.x;
+    if (r < end) v[k] = gload(src + r);
+  }
+#pragma unroll
+  for (int k = 0; k < RP_R; ++k) {
+    int64_t const r = tile + static_cast<int64_t>(k) * RP_BLOCK + threadIdx.x;
+    if (r < end) stage[lpos[k]] = v[k];
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < tile_rows; j += RP_BLOCK) {
+    uint32_t const d = sdest[j];
+    gstore(static_cast<T*>(out) + gcur[d] + (j - doff[d]), stage[j]);
+  }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(RP_BLOCK) k_rp_scatter(rp_args const* __restrict__ ap)
+{
+  __shared__ uint64_t stage64[RP_TILE];        // one column's values of a tile, in destination order
+  __shared__ uint8_t sdest[RP_TILE];           // destination of every staged position
+  __shared__ uint32_t whist[16 * RP_MAX_PARTS];
+  __shared__ uint32_t doff[RP_MAX_PARTS + 1];  // first staged position of a destination
+  __shared__ int64_t gcur[RP_MAX_PARTS];       // this workgroup's write cursor per destination
+  rp_args const& a = *ap;
+  int const N = a.nparts, wave = threadIdx.x >> 6;
+  int64_t const begin = static_cast<int64_t>(blockIdx.x) * a.chunk, end = min(a.nrows, begin + a.chunk);
+  for (int d = threadIdx.x; d < N; d += RP_BLOCK) gcur[d] = a.cell_base[static_cast<int64_t>(blockIdx.x) * N + d];
+  for (int64_t tile = begin; tile < end; tile += RP_TILE) {
+    for (int i = threadIdx.x; i < 16 * N; i += RP_BLOCK) whist[i] = 0;
+    __syncthreads();
+    uint32_t dst[RP_R], rank[RP_R], lpos[RP_R];
+#pragma unroll
+    for (int k = 0; k < RP_R; ++k) {
+      int64_t const r = tile + static_cast<int64_t>(k) * RP_BLOCK + threadIdx.x;
+      dst[k] = 0; rank[k] = 0;
+      if (r < end) {
+        dst[k]  = dest_of(a, r);
+        rank[k] = atomicAdd(&whist[wave * N + dst[k]], 1u);  // rank inside (wave, destination); waves rank in row order
+      }
+    }
+    __syncthreads();
+    // per destination: exclusive prefix over the waves (in place), tile total; then the staged offset of every destination
+    if (static_cast<int>(threadIdx.x) < N) {
+      uint32_t run = 0;
+      for (int w = 0; w < 16; ++w) {
+        uint32_t const c = whist[w * N + threadIdx.x];
+        whist[w * N + threadIdx.x] = run;
+        run += c;
+      }
+      doff[threadIdx.x + 1] = run;  // (totals for now)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t run = 0;
+      for (int d = 0; d < N; ++d) {
+        uint32_t const c = doff[d + 1];
+        doff[d] = run;
+        run += c;
+      }
+      doff[N] = run;
+    }
+    __syncthreads();
+    uint32_t const tile_rows = doff[N];
+#pragma unroll
+    for (int k = 0; k < RP_R; ++k) {
+      int64_t const r = tile + static_cast<int64_t>(k) * RP_BLOCK + threadIdx.x;
+      lpos[k] = 0;
+      if (r < end) {
+        // rows of one (wave, destination) keep their order: row sets k are ranked one after the other by the same wave
+        lpos[k]        = doff[dst[k]] + whist[wave * N + dst[k]] + rank[k];
+        sdest[lpos[k]] = static_cast<uint8_t>(dst[k]);
+      }
+    }
+    __syncthreads();
+    for (int c = 0; c < a.all.ncols; ++c) {
+      device_column const col = a.all.col[c];
+      switch (col.width) {
+        case 1: move_column<uint8_t>(col, a.out[c], tile, end, lpos, reinterpret_cast<uint8_t*>(stage64), sdest, doff, gcur, tile_rows); break;
+        case 2: move_column<uint16_t>(col, a.out[c], tile, end, lpos, reinterpret_cast<uint16_t*>(stage64), sdest, doff, gcur, tile_rows); break;
+        case 4: move_column<uint32_t>(col, a.out[c], tile, end, lpos, reinterpret_cast<uint32_t*>(stage64), sdest, doff, gcur, tile_rows); break;
+        default: move_column<uint64_t>(col, a.out[c], tile, end, lpos, stage64, sdest, doff, gcur, tile_rows);
+      }
+    }
+    if (static_cast<int>(threadIdx.x) < N) gcur[threadIdx.x] += doff[threadIdx.x + 1] - doff[threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// validity bits [offset, offset + n) -> one byte per row (1 = valid), and back
+__global__ void __launch_bounds__(256) k_mask_to_bytes(bitmask_type const* mask, int64_t offset, int64_t n, uint8_t* out)
+{
+  int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) out[i] = mask == nullptr ? 1 : ((mask[(offset + i) >> 5] >> ((offset + i) & 31)) & 1u);
+}
+__global__ void __launch_bounds__(256) k_bytes_to_mask(uint8_t const* bytes, int64_t n, bitmask_type* mask, int32_t* null_count)
+{
+  int64_t const i               = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  bool const valid              = i < n && bytes[i] != 0;
+  unsigned long long const b    = __ballot(valid);
+  unsigned long long const live = __ballot(i < n);
+  int const lane                = threadIdx.x & 63;
+  if (i < n && (lane & 31) == 0) mask[i >> 5] = static_cast<uint32_t>(b >> (lane & 32));
+  int const nulls = __popcll(live & ~b);
+  if (lane == 0 && nulls) atomicAdd(null_count, nulls);
+}
+
+// The columns that travel: the input columns, then one validity-byte column per column listed in `with_validity`.
+struct flat_table {
+  std::vector<column_view> cols;            // what is partitioned / exchanged
+  std::vector<int> validity_of;             // cols[ninput + j] holds the validity bytes of input column validity_of[j]
+  std::vector<rmm::device_buffer> temps;    // the byte columns' storage
+  int ninput{0};
+};
+flat_table flatten(table_view const& input, uint64_t with_validity, hipStream_t s)
+{
+  flat_table f;
+  f.ninput = input.num_columns();
+  auto tmp = cudf::get_current_device_resource_ref();
+  for (auto const& c : input) {
+    CUDF_EXPECTS(c.num_children() == 0 && size_of_id(c.type().id()) >= 1 && size_of_id(c.type().id()) <= 8,
+                 "distributed shuffle: fixed-width columns of at most 8 bytes only");
+    f.cols.push_back(column_view{c.type(), c.size(), c.head(), nullptr, 0, c.offset()});
+  }
+  for (int c = 0; c < f.ninput; ++c) {
+    if (!((with_validity >> c) & 1u)) continue;
+    auto const& col = input.column(c);
+    f.temps.emplace_back(static_cast<std::size_t>(std::max<size_type>(col.size(), 1)), s, tmp);
+    if (col.size() > 0) {
+      hipLaunchKernelGGL(k_mask_to_bytes, dim3(static_cast<unsigned>((col.size() + 255) / 256)), dim3(256), 0, s,
+                         col.has_nulls() ? col.null_mask() : nullptr, static_cast<int64_t>(col.offset()), static_cast<int64_t>(col.size()),
+                         static_cast<uint8_t*>(f.temps.back().data()));
+    }
+    f.cols.push_back(column_view{data_type{type_id::UINT8}, col.size(), f.temps.back().data(), nullptr, 0, 0});
+    f.validity_of.push_back(c);
+  }
+  CUDF_EXPECTS(static_cast<int>(f.cols.size()) <= MAX_COLS, "distributed shuffle: too many columns (limit 16 including validity columns)");
+  return f;
+}
+// buffers of the flat columns (nrows rows each) -> owning table with the input's types and re-packed validity
+std::unique_ptr<table> assemble(table_view const& like, flat_table const& f, std::vector<rmm::device_buffer>&& bufs, int64_t nrows,
+                                stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  hipStream_t const s = stream.value();
+  std::vector<std::unique_ptr<column>> cols;
+  for (int c = 0; c < f.ninput; ++c)
+    cols.push_back(std::make_unique<column>(like.column(c).type(), static_cast<size_type>(nrows), std::move(bufs[c]), rmm::device_buffer{}, 0));
+  if (!f.validity_of.empty() && nrows > 0) {
+    rmm::device_buffer counters{sizeof(int32_t) * f.validity_of.size(), s, cudf::get_current_device_resource_ref()};
+    CUDF_HIP_TRY(hipMemsetAsync(counters.data(), 0, counters.size(), s));
+    std::vector<rmm::device_buffer> masks;
+    for (std::size_t j = 0; j < f.validity_of.size(); ++j) {
+      masks.push_back(create_null_mask(static_cast<size_type>(nrows), mask_state::UNINITIALIZED, stream, mr));
+      hipLaunchKernelGGL(k_bytes_to_mask, dim3(static_cast<unsigned>((nrows + 255) / 256)), dim3(256), 0, s,
+                         static_cast<uint8_t const*>(bufs[f.ninput + j].data()), nrows, static_cast<bitmask_type*>(masks.back().data()),
+                         static_cast<int32_t*>(counters.data()) + j);
+    }
+    CUDF_HIP_TRY(hipGetLastError());
+    std::vector<int32_t> h(f.validity_of.size());
+    CUDF_HIP_TRY(hipMemcpyAsync(h.data(), counters.data(), counters.size(), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    for (std::size_t j = 0; j < f.validity_of.size(); ++j)
+      if (h[j] > 0) cols[f.validity_of[j]]->set_null_mask(std::move(masks[j]), h[j]);
+  }
+  return std::make_unique<table>(std::move(cols));
+}
+
+// Partitions the flat columns by the hash range of `hashed`'s rows; returns one buffer per flat column and N + 1 offsets.
+std::pair<std::vector<rmm::device_buffer>, std::vector<int64_t>> partition_flat(flat_table const& f, table_view const& hashed, int N,
+                                                                                stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  CUDF_EXPECTS(N >= 1 && N <= RP_MAX_PARTS, "distributed shuffle: 1 to 64 destinations", std::invalid_argument);
+  hipStream_t const s = stream.value();
+  int64_t const n     = f.cols.empty() ? 0 : f.cols.front().size();
+  std::vector<rmm::device_buffer> out;
+  for (auto const& c : f.cols) out.emplace_back(static_cast<std::size_t>(std::max<int64_t>(n, 1)) * size_of_id(c.type().id()), s, mr);
+  std::vector<int64_t> h_off(static_cast<std::size_t>(N) + 1, 0);
+  if (n == 0) return {std::move(out), std::move(h_off)};
+  if (N == 1) {  // one destination: the rows stay as they are
+    for (std::size_t c = 0; c < f.cols.size(); ++c) {
+      auto const w = size_of_id(f.cols[c].type().id());
+      CUDF_HIP_TRY(hipMemcpyAsync(out[c].data(), static_cast<char const*>(f.cols[c].head()) + static_cast<std::size_t>(f.cols[c].offset()) * w,
+                                  static_cast<std::size_t>(n) * w, hipMemcpyDeviceToDevice, s));
+    }
+    h_off[1] = n;
+    return {std::move(out), std::move(h_off)};
+  }
+  auto tmp = cudf::get_current_device_resource_ref();
+  rp_args a{};
+  a.hashed = cudf::detail::make_device_table(hashed);
+  a.all    = cudf::detail::make_device_table(table_view{f.cols});
+  a.nparts = N;
+  a.nrows  = n;
+  a.wgs    = static_cast<int32_t>(std::clamp<int64_t>((n + RP_TILE - 1) / RP_TILE, 1, 512));
+  a.chunk  = ((n + a.wgs - 1) / a.wgs + RP_TILE - 1) / RP_TILE * RP_TILE;
+  rmm::device_buffer counts{sizeof(uint32_t) * a.wgs * N, s, tmp}, cell{sizeof(int64_t) * a.wgs * N, s, tmp},
+    offs{sizeof(int64_t) * (N + 1), s, tmp}, d_args{sizeof(rp_args), s, tmp};
+  a.counts    = static_cast<uint32_t*>(counts.data());
+  a.cell_base = static_cast<int64_t*>(cell.data());
+  a.offsets   = static_cast<int64_t*>(offs.data());
+  for (std::size_t c = 0; c < f.cols.size(); ++c) a.out[c] = out[c].data();
+  auto* da = static_cast<rp_args*>(d_args.data());
+  hipLaunchKernelGGL(k_store<rp_args>, dim3(1), dim3(1), 0, s, a, da);
+  {
+    cudf::detail::prof::scope p_{"range_partition_hist", s};
+    hipLaunchKernelGGL(k_rp_hist, dim3(a.wgs), dim3(RP_BLOCK), 0, s, da);
+  }
+  hipLaunchKernelGGL(k_rp_scan, dim3(1), dim3(64), 0, s, da);
+  {
+    cudf::detail::prof::scope p_{"range_partition_scatter", s};
+    hipLaunchKernelGGL(k_rp_scatter, dim3(a.wgs), dim3(RP_BLOCK), 0, s, da);
+  }
+  CUDF_HIP_TRY(hipGetLastError());
+  CUDF_HIP_TRY(hipMemcpyAsync(h_off.data(), a.offsets, sizeof(int64_t) * (N + 1), hipMemcpyDeviceToHost, s));
+  CUDF_HIP_TRY(hipStreamSynchronize(s));
+  return {std::move(out), std::move(h_off)};
+}
+
+uint64_t nullable_bits(table_view const& t)
+{
+  uint64_t b = 0;
+  for (int c = 0; c < t.num_columns(); ++c)
+    if (t.column(c).has_nulls()) b |= uint64_t{1} << c;
+  return b;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ communicator
+unique_id communicator::make_unique_id()
+{
+  ncclUniqueId id;
+  CUDF_RCCL_TRY(rccl().GetUniqueId(&id));
+  unique_id out{};
+  static_assert(sizeof(id) == UNIQUE_ID_BYTES);
+  std::memcpy(out.data(), &id, sizeof(id));
+  return out;
+}
+communicator::communicator(unique_id const& id, int world_size, int rank) : _world{world_size}, _rank{rank}
+{
+  CUDF_EXPECTS(world_size >= 1 && rank >= 0 && rank < world_size, "communicator: rank outside the world", std::invalid_argument);
+  ncclUniqueId nid;
+  std::memcpy(&nid, id.data(), sizeof(nid));
+  ncclComm_t c{};
+  CUDF_RCCL_TRY(rccl().CommInitRank(&c, world_size, nid, rank));
+  _comm = c;
+}
+communicator::~communicator()
+{
+  if (_comm != nullptr) (void)rccl().CommDestroy(static_cast<ncclComm_t>(_comm));
+}
+
+// ------------------------------------------------------------------ range_partition
+std::pair<std::unique_ptr<table>, std::vector<size_type>> range_partition(table_view const& input, std::vector<size_type> const& key_columns,
+                                                                          int num_destinations, stream_ref stream,
+                                                                          rmm::device_async_resource_ref mr)
+{
+  auto const hashed = input.select(key_columns);
+  CUDF_EXPECTS(hashed.num_columns() >= 1, "range_partition: at least one key column", std::invalid_argument);
+  auto f            = flatten(input, nullable_bits(input), stream.value());
+  auto [bufs, off]  = partition_flat(f, hashed, num_destinations, stream, mr);
+  std::vector<size_type> offsets(off.begin(), off.end());
+  return {assemble(input, f, std::move(bufs), input.num_rows(), stream, mr), std::move(offsets)};
+}
+
+// ------------------------------------------------------------------ shuffle
+std::unique_ptr<table> shuffle(table_view const& input, std::vector<size_type> const& key_columns, communicator& comm, stream_ref stream,
+                               rmm::device_async_resource_ref mr)
+{
+  hipStream_t const s = stream.value();
+  int const N = comm.size(), me = comm.rank();
+  auto const nc = static_cast<ncclComm_t>(comm.handle());
+  auto tmp      = cudf::get_current_device_resource_ref();
+  CUDF_EXPECTS(input.num_columns() >= 1 && input.num_columns() < 60, "shuffle: 1 to 59 columns", std::invalid_argument);
+  auto const hashed = input.select(key_columns);
+  CUDF_EXPECTS(hashed.num_columns() >= 1, "shuffle: at least one key column", std::invalid_argument);
+
+  // ---- round 0 of the control traffic: which columns carry nulls on ANY rank (they travel with validity bytes everywhere)
+  rmm::device_buffer ctl_send{sizeof(int64_t) * (N + 1), s, tmp}, ctl_recv{sizeof(int64_t) * (N + 1) * N, s, tmp};
+  std::vector<int64_t> h_send(static_cast<std::size_t>(N) + 1, 0), h_all(static_cast<std::size_t>(N + 1) * N, 0);
+  h_send[N] = static_cast<int64_t>(nullable_bits(input));
+  CUDF_HIP_TRY(hipMemcpyAsync(ctl_send.data(), h_send.data(), ctl_send.size(), hipMemcpyHostToDevice, s));
+  CUDF_RCCL_TRY(rccl().AllGather(ctl_send.data(), ctl_recv.data(), static_cast<std::size_t>(N) + 1, ncclInt64, nc, s));
+  CUDF_HIP_TRY(hipMemcpyAsync(h_all.data(), ctl_recv.data(), ctl_recv.size(), hipMemcpyDeviceToHost, s));
+  CUDF_HIP_TRY(hipStreamSynchronize(s));
+  uint64_t with_validity = 0;
+  for (int p = 0; p < N; ++p) with_validity |= static_cast<uint64_t>(h_all[static_cast<std::size_t>(p) * (N + 1) + N]);
+
+  // ---- local split by owner rank
+  auto f           = flatten(input, with_validity, s);
+  auto [bufs, off] = partition_flat(f, hashed, N, stream, tmp);
+
+  // ---- counts: every rank learns what every rank sends to every rank
+  for (int p = 0; p < N; ++p) h_send[p] = off[p + 1] - off[p];
+  CUDF_HIP_TRY(hipMemcpyAsync(ctl_send.data(), h_send.data(), ctl_send.size(), hipMemcpyHostToDevice, s));
+  CUDF_RCCL_TRY(rccl().AllGather(ctl_send.data(), ctl_recv.data(), static_cast<std::size_t>(N) + 1, ncclInt64, nc, s));
+  CUDF_HIP_TRY(hipMemcpyAsync(h_all.data(), ctl_recv.data(), ctl_recv.size(), hipMemcpyDeviceToHost, s));
+  CUDF_HIP_TRY(hipStreamSynchronize(s));
+  std::vector<int64_t> rcnt(N), roff(static_cast<std::size_t>(N) + 1, 0);
+  int64_t biggest = 0;  // the largest (sender, receiver) message in rows: every rank runs the same number of rounds
+  for (int p = 0; p < N; ++p) {
+    rcnt[p]     = h_all[static_cast<std::size_t>(p) * (N + 1) + me];
+    roff[p + 1] = roff[p] + rcnt[p];
+    for (int q = 0; q < N; ++q)
+      if (p != q) biggest = std::max(biggest, h_all[static_cast<std::size_t>(p) * (N + 1) + q]);
+  }
+  int64_t const total = roff[N];
+  CUDF_EXPECTS(total <= std::numeric_limits<size_type>::max(), "shuffle: a rank would receive more rows than a column holds", std::overflow_error);
+
+  // ---- payload: per column, ncclGroupStart { Send / Recv per peer } ncclGroupEnd in rounds of <= 1 GiB messages; the own
+  // slice is a device copy
+  constexpr int64_t MAX_MESSAGE_BYTES = int64_t{1} << 30;
+  std::vector<rmm::device_buffer> recv;
+  cudf::detail::prof::scope p_{"shuffle_exchange", s};
+  for (std::size_t c = 0; c < f.cols.size(); ++c) {
+    int64_t const w = static_cast<int64_t>(size_of_id(f.cols[c].type().id()));
+    recv.emplace_back(static_cast<std::size_t>(std::max<int64_t>(total, 1) * w), s, c < static_cast<std::size_t>(f.ninput) ? mr : tmp);
+    char const* src = static_cast<char const*>(bufs[c].data());
+    char* dst       = static_cast<char*>(recv.back().data());
+    if (h_send[me] > 0)
+      CUDF_HIP_TRY(hipMemcpyAsync(dst + roff[me] * w, src + off[me] * w, static_cast<std::size_t>(h_send[me] * w), hipMemcpyDeviceToDevice, s));
+    int64_t const chunk = std::max<int64_t>(1, MAX_MESSAGE_BYTES / w);
+    for (int64_t done = 0; done < biggest; done += chunk) {
+      CUDF_RCCL_TRY(rccl().GroupStart());
+      for (int p = 0; p < N; ++p) {
+        if (p == me) continue;
+        int64_t const sb = std::min(done, h_send[p]), se = std::min(done + chunk, h_send[p]);
+        if (se > sb) CUDF_RCCL_TRY(rccl().Send(src + (off[p] + sb) * w, static_cast<std::size_t>((se - sb) * w), ncclInt8, p, nc, s));
+        int64_t const rb = std::min(done, rcnt[p]), re = std::min(done + chunk, rcnt[p]);
+        if (re > rb) CUDF_RCCL_TRY(rccl().Recv(dst + (roff[p] + rb) * w, static_cast<std::size_t>((re - rb) * w), ncclInt8, p, nc, s));
+      }
+      CUDF_RCCL_TRY(rccl().GroupEnd());
+    }
+  }
+  return assemble(input, f, std::move(recv), total, stream, mr);
+}
+
+// ------------------------------------------------------------------ shuffle_groupby (BASELINE config 5)
+std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> shuffle_groupby(
+  table_view const& keys, std::span<groupby::aggregation_request const> requests, communicator& comm, null_policy null_handling,
+  stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  // the rows that travel: the key columns, then each DISTINCT value column once
+  std::vector<column_view> cols(keys.begin(), keys.end());
+  std::vector<size_type> key_idx(static_cast<std::size_t>(keys.num_columns()));
+  std::iota(key_idx.begin(), key_idx.end(), 0);
+  std::vector<int> value_at(requests.size(), -1);
+  for (std::size_t r = 0; r < requests.size(); ++r) {
+    CUDF_EXPECTS(requests[r].values.size() == keys.num_rows(), "Size mismatch between request values and groupby keys.");
+    for (std::size_t q = 0; q < r; ++q)
+      if (cudf::detail::is_shallow_equivalent(requests[q].values, requests[r].values)) value_at[r] = value_at[q];
+    if (value_at[r] < 0) {
+      value_at[r] = static_cast<int>(cols.size());
+      cols.push_back(requests[r].values);
+    }
+  }
+  auto mine = shuffle(table_view{cols}, key_idx, comm, stream, cudf::get_current_device_resource_ref());
+  auto const mv = mine->view();
+  std::vector<column_view> kcols;
+  for (int c = 0; c < keys.num_columns(); ++c) kcols.push_back(mv.column(c));
+  std::vector<groupby::aggregation_request> local(requests.size());
+  for (std::size_t r = 0; r < requests.size(); ++r) {
+    local[r].values = mv.column(value_at[r]);
+    for (auto const& a : requests[r].aggregations) {
+      auto cl = a->clone();
+      auto* g = dynamic_cast<groupby_aggregation*>(cl.get());
+      CUDF_EXPECTS(g != nullptr, "not a groupby aggregation");
+      (void)cl.release();
+      local[r].aggregations.emplace_back(g);
+    }
+  }
+  groupby::groupby gb{table_view{kcols}, null_handling};
+  return gb.aggregate(local, stream, mr);
+}
+
+}  // namespace distributed
+}  // namespace cudf

@@ -14,8 +14,86 @@ The exchange itself (counts all-to-all, then one all_to_all_single per column wi
 the device: `backend` supplies the local hash partition and the local groupby, so the collective logic is covered
 by world_size-2 gloo tests on CPU with a host backend (tests/test_distributed_gloo.py).
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
+from .column import Column, Table, _stream_ptr
+
+
+# ------------------------------------------------------------------ native exchange (C++: RCCL Send/Recv inside the library)
+class Communicator:
+    """cudf::distributed::communicator (include/cudf/distributed.hpp): this rank's end of an RCCL communicator created by
+    the library itself. The 128-byte ncclUniqueId travels from rank 0 to the other ranks over `group` (any torch.distributed
+    backend; only the control plane - the payload goes through the library's own RCCL communicator)."""
+
+    def __init__(self, group=None, world_size=None, rank=None):
+        lib = _lib.load()
+        if world_size is None:
+            world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(lib.cudf_amd_comm_unique_id(ident))
+        if world_size > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_uint8 * 128)(*box[0])
+        self._handle = C.c_void_p()
+        _lib.check(lib.cudf_amd_comm_create(ident, world_size, rank, C.byref(self._handle)))
+        self.world_size, self.rank = world_size, rank
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.load().cudf_amd_comm_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+def range_partition(table: Table, key_columns, num_destinations: int, stream=None):
+    """-> (Table with the rows of one destination contiguous, num_destinations + 1 row offsets); destination of a row =
+    (murmur3 row hash of its key columns * num_destinations) >> 32 (hash-range ownership)."""
+    cols = (C.c_int32 * max(1, len(key_columns)))(*key_columns)
+    offs = (C.c_int32 * (num_destinations + 1))()
+    out = C.c_void_p()
+    _lib.check(_lib.load().cudf_amd_range_partition(table._views(), table.num_columns(), cols, len(key_columns), num_destinations,
+                                                    _stream_ptr(stream), C.byref(out), offs))
+    return Table._from_handle(out), list(offs)
+
+
+def shuffle(comm: Communicator, table: Table, key_columns, stream=None) -> Table:
+    """Collective: every rank passes its rows and receives the rows whose keys it owns."""
+    cols = (C.c_int32 * max(1, len(key_columns)))(*key_columns)
+    out = C.c_void_p()
+    _lib.check(_lib.load().cudf_amd_shuffle(comm._handle, table._views(), table.num_columns(), cols, len(key_columns),
+                                            _stream_ptr(stream), C.byref(out)))
+    return Table._from_handle(out)
+
+
+def shuffle_groupby(comm: Communicator, keys: Table, requests, null_handling=0, stream=None):
+    """BASELINE config 5 inside the library: hash-range partition of the rows -> RCCL exchange -> local hash groupby.
+    requests: cudf_amd.groupby.GroupByRequest list. -> (keys Table, [results Table per request]) of the groups this rank owns."""
+    reqs, keep = [], []
+    for r in requests:
+        kinds = (C.c_int32 * max(1, len(r._aggregations)))(*[int(a.kind()) for a in r._aggregations])
+        params = (C.c_int32 * max(1, len(r._aggregations)))(*[a.param(1 if a.kind().name in ("VARIANCE", "STD") else 0)
+                                                               for a in r._aggregations])
+        keep += [kinds, params]
+        reqs.append(_lib.AggregationRequest(r._values._view(), kinds, len(r._aggregations), params))
+    rarr = (_lib.AggregationRequest * max(1, len(reqs)))(*reqs)
+    out_keys, out_res = C.c_void_p(), C.c_void_p()
+    _lib.check(_lib.load().cudf_amd_shuffle_groupby(comm._handle, keys._views(), keys.num_columns(), int(null_handling), rarr,
+                                                    len(reqs), _stream_ptr(stream), C.byref(out_keys), C.byref(out_res)))
+    flat = Table._from_handle(out_res).columns()
+    results, p = [], 0
+    for r in requests:
+        results.append(Table(flat[p:p + len(r._aggregations)]))
+        p += len(r._aggregations)
+    return Table._from_handle(out_keys), results
 
 
 class GpuBackend:
@@ -111,10 +189,29 @@ def exchange(columns, offsets, group=None, max_message_bytes=None):
     return out
 
 
+_COMMS = {}
+
+
+def _native_comm(group=None):
+    """One library communicator per torch process group (created on first use: a collective)."""
+    key = id(group)
+    if key not in _COMMS:
+        _COMMS[key] = Communicator(group)
+    return _COMMS[key]
+
+
 def distributed_groupby_sum_count(keys, vals, stream=None, mode="shuffle", backend=None, group=None,
                                   max_message_bytes=None):
     """Global SUM(vals) and COUNT per key over all ranks; every rank returns the groups it owns
     (keys, sums, counts). The union over ranks is the global result; ownership is by key hash."""
+    if mode == "shuffle_native":  # the literal config-5 form, entirely inside the library (C++ + RCCL)
+        import cudf_amd
+        from cudf_amd import aggregation as agg, groupby as gb
+        from cudf_amd.types import NullPolicy
+        comm = _native_comm(group)
+        req = gb.GroupByRequest(cudf_amd.Column.from_torch(vals), [agg.sum(), agg.count(NullPolicy.EXCLUDE)])
+        uk, res = shuffle_groupby(comm, cudf_amd.Table([cudf_amd.Column.from_torch(keys)]), [req], stream=stream)
+        return uk.columns()[0].to_torch(), res[0].columns()[0].to_torch(), res[0].columns()[1].to_torch()
     backend = backend or GpuBackend(stream)
     world = dist.get_world_size(group)
     if mode == "shuffle":

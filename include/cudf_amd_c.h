@@ -164,6 +164,29 @@ cudf_amd_status cudf_amd_hash_partition(const cudf_amd_column_view* input, int32
                                         const int32_t* columns_to_hash, int32_t num_hash_columns, int32_t num_partitions,
                                         uint32_t seed, void* stream, cudf_amd_table_t* out_table, int32_t* out_offsets);
 
+/* ---- multi-GPU exchange (include/cudf/distributed.hpp; the reference's data flow: cpp/libcudf_streaming/src/
+ * partition_utils.cpp:72-185). One process per GPU; RCCL over xGMI, resolved at run time.
+ * cudf_amd_comm_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks over its control plane.
+ * cudf_amd_comm_create: collective over all ranks of the new communicator.
+ * cudf_amd_range_partition: rows reordered by destination = (murmur3 row hash of the key columns * num_destinations) >> 32;
+ *   out_offsets receives num_destinations + 1 row offsets.
+ * cudf_amd_shuffle: collective; every rank receives the rows it owns (from rank 0, then rank 1, ...).
+ * cudf_amd_shuffle_groupby: BASELINE config 5 = cudf_amd_shuffle of (keys, values) + the local hash groupby; the ranks'
+ *   results are disjoint, their union is the global result. */
+typedef struct cudf_amd_comm_s* cudf_amd_comm_t;
+cudf_amd_status cudf_amd_comm_unique_id(uint8_t* out_id_128_bytes);
+cudf_amd_status cudf_amd_comm_create(const uint8_t* id_128_bytes, int32_t world_size, int32_t rank, cudf_amd_comm_t* out);
+void cudf_amd_comm_destroy(cudf_amd_comm_t comm);
+cudf_amd_status cudf_amd_range_partition(const cudf_amd_column_view* input, int32_t num_columns, const int32_t* key_columns,
+                                         int32_t num_key_columns, int32_t num_destinations, void* stream,
+                                         cudf_amd_table_t* out_table, int32_t* out_offsets);
+cudf_amd_status cudf_amd_shuffle(cudf_amd_comm_t comm, const cudf_amd_column_view* input, int32_t num_columns,
+                                 const int32_t* key_columns, int32_t num_key_columns, void* stream, cudf_amd_table_t* out_table);
+cudf_amd_status cudf_amd_shuffle_groupby(cudf_amd_comm_t comm, const cudf_amd_column_view* keys, int32_t num_keys,
+                                         int32_t include_null_keys, const cudf_amd_aggregation_request* requests,
+                                         int32_t num_requests, void* stream, cudf_amd_table_t* out_keys,
+                                         cudf_amd_table_t* out_results);
+
 /* ---- cudf::hashing::murmurhash3_x86_32(input, seed) -> UINT32 column (reference cpp/include/cudf/hashing.hpp). */
 cudf_amd_status cudf_amd_murmurhash3_x86_32(const cudf_amd_column_view* input, int32_t num_columns, uint32_t seed,
                                             void* stream, cudf_amd_table_t* out_column);

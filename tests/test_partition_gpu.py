@@ -232,3 +232,62 @@ def test_distributed_inner_join_single_rank_rccl(G, oracle):
         assert kat.sorted_pairs(gl.cpu().numpy(), gr.cpu().numpy()) == kat.sorted_pairs(el, er)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ndest", [2, 3, 8])
+def test_range_partition_hash_range_ownership(G, oracle, ndest):
+    """cudf::distributed::range_partition: destination = (murmur3 row hash * N) >> 32 on the high hash bits (SURVEY.md
+    section 8e), rows of one destination contiguous, nulls and narrow types carried, num_destinations + 1 offsets."""
+    import cudf_amd
+    from cudf_amd import distributed as D
+    rng = np.random.default_rng(12)
+    n = 300_000
+    cols = _cols(rng, n)
+    t = cudf_amd.Table([G.to_device(c) for c in cols])
+    out, offs = D.range_partition(t, [0, 1], ndest)
+    assert len(offs) == ndest + 1 and offs[0] == 0 and offs[-1] == n
+    h = oracle.row_hash(cols[:2], 0).astype(np.uint64)
+    dest = ((h * np.uint64(ndest)) >> np.uint64(32)).astype(np.int64)
+    assert np.array_equal(np.diff(offs), np.bincount(dest, minlength=ndest))
+    got = [c.to_numpy() for c in out.columns()]
+    for c, o in zip(cols, out.columns()):
+        assert o.null_count() == c.null_count
+    # every output row of destination p hashes to p, and the multiset of rows is preserved
+    from oracle.oracle import HostColumn
+    oh = oracle.row_hash([HostColumn(got[0][0], got[0][1], "int64"), HostColumn(got[1][0], None, "int32")], 0).astype(np.uint64)
+    odest = ((oh * np.uint64(ndest)) >> np.uint64(32)).astype(np.int64)
+    assert np.array_equal(odest, np.repeat(np.arange(ndest), np.diff(offs)))
+    key = lambda d, v: sorted(zip(np.where(v, d[0], -999).tolist() if v is not None else d[0].tolist()))
+    for (d, v), c in zip(got, cols):
+        src = c.data if c.type_id != 11 else c.data != 0
+        a = np.where(v, d, 0) if v is not None else d
+        b = np.where(c.valid, src, 0) if c.valid is not None else src
+        assert sorted(np.nan_to_num(a.astype(np.float64), nan=-7.5).tolist()) == sorted(np.nan_to_num(b.astype(np.float64), nan=-7.5).tolist())
+
+
+def test_native_shuffle_groupby_single_rank_rccl(G, oracle):
+    """The literal config-5 form through the C++ entry points at world_size 1: the library creates its own RCCL
+    communicator (ncclCommInitRank), allgathers the counts, copies its own slice, and runs the local hash groupby on the
+    received rows; nullable values travel with validity bytes."""
+    import cudf_amd
+    import kat
+    from cudf_amd import aggregation as agg, distributed as D, groupby as gb
+    from cudf_amd.types import NullPolicy
+    rng = np.random.default_rng(15)
+    n = 500_000
+    k = rng.integers(-40_000, 40_000, n, dtype=np.int64)
+    v = rng.random(n)
+    vv = rng.random(n) > 0.1
+    comm = D.Communicator(world_size=1, rank=0)
+    t = cudf_amd.Table([G.to_device(k), G.to_device((v, vv))])
+    mine = D.shuffle(comm, t, [0])
+    assert mine.num_rows() == n and mine.columns()[1].null_count() == int((~vv).sum())
+    gk, gv = mine.columns()[0].to_numpy()[0], mine.columns()[1].to_numpy()
+    assert sorted(zip(gk.tolist(), np.where(gv[1], gv[0], -1.0).tolist())) == sorted(zip(k.tolist(), np.where(vv, v, -1.0).tolist()))
+    req = gb.GroupByRequest(G.to_device((v, vv)), [agg.sum(), agg.count(NullPolicy.EXCLUDE), agg.max()])
+    uk, res = D.shuffle_groupby(comm, cudf_amd.Table([G.to_device(k)]), [req])
+    got = kat.sort_groups([G.from_device(c) for c in uk.columns()], [[G.from_device(c) for c in res[0].columns()]])
+    exp = kat.sort_groups(*oracle.groupby([k], [((v, vv), ["sum", "count_valid", "max"])]))
+    kat.compare_columns(got[0][0], exp[0][0], "keys")
+    for a, e, name in zip(got[1][0], exp[1][0], ["sum", "count", "max"]):
+        kat.compare_columns(a, e, name, atol=kat.sum_atol(64, 1.0) if name == "sum" else 0.0)
