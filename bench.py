@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=int(os.environ.get("BENCH_ROWS", 1_000_000_000)))
     ap.add_argument("--groups", type=int, default=int(os.environ.get("BENCH_GROUPS", 1_000_000)))
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c3sparse", "c4"],
+                    help="c2 (default, the headline); c3 = configs[2] inner join; c3sparse = the same with keys that do not span a small "
+                         "range (hash table instead of the direct-address table); c4 = configs[3] multi-key groupby. One GPU only.")
+    ap.add_argument("--scale", type=float, default=1.0, help="c3 / c4: fraction of the BASELINE size (parity / smoke runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=60_000_000)
     return ap.parse_args()
@@ -75,6 +79,86 @@ def cpu_baseline(groups, sample_rows):
     return out
 
 
+def cpu_baseline_config(config, scale_rows):
+    """CPU oracle (kind "port", 1 core) on a bounded sample of the C3 / C4 workload."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(42)
+    if config.startswith("c3"):
+        nl, nr = 20_000_000, 2_000_000
+        rk = rng.permutation(nr).astype(np.int64)
+        lk = np.where(rng.random(nl) < 0.3, rng.integers(0, nr, nl), rng.integers(nr, 2 * nr, nl)).astype(np.int64)
+        lv, rv = rng.random(nl) > 0.05, rng.random(nr) > 0.05
+        t0 = time.perf_counter()
+        n_pairs = O.join_size([(lk, lv)], [(rk, rv)], nulls_equal=False, kind="inner")
+        dt = time.perf_counter() - t0
+        return {"value": (nl + nr) / dt, "unit": "rows/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+                "sample": f"{nl} x {nr} rows of the same int64-key workload (5% nulls, selectivity 0.3, UNEQUAL), oracle/oracle.c inner join "
+                          f"size pass ({n_pairs} pairs), {dt:.1f} s"}
+    n = 30_000_000
+    k0 = rng.integers(0, 10_000, n, dtype=np.int64)
+    k1 = rng.integers(0, 1_000, n).astype(np.int32)
+    v = rng.random(n)
+    k1v, vv = rng.random(n) > 0.1, rng.random(n) > 0.1
+    t0 = time.perf_counter()
+    O.groupby([k0, (k1, k1v)], [((v, vv), ["mean", "min", "max"])])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port", "host_cores": os.cpu_count(),
+            "sample": f"{n} rows of the same (int64, int32)-key / float64-value workload, 10% nulls on k1 and on the value, ~10M groups, "
+                      f"oracle/oracle.c groupby MEAN+MIN+MAX, {dt:.1f} s"}
+
+
+def run_config(args, json_fd):
+    """--config c3 | c3sparse | c4: the same JSON shape as the headline line, for BASELINE configs[2] / configs[3] on one GPU."""
+    import torch
+    import bench_configs as BC
+    from cudf_amd import _lib
+    torch.cuda.set_device(0)
+    if args.config == "c4":
+        run, check, rows, algo_bytes = BC.make_c4(args.scale)
+        algo = lambda _res: algo_bytes  # noqa: E731
+        metric = "rows/s hash-groupby MEAN+MIN+MAX, 1B rows, keys (int64, int32), 10M groups, 10% nulls"
+        workload = "C4: 1xMI355X multi-key groupby (int64+int32) with mean/min/max, 1B rows, 10M groups, 10% nulls on k1 and on the value"
+    else:
+        run, check, rows, algo_of, _ = BC.make_c3(args.scale, sparse=args.config == "c3sparse")
+        algo = lambda res: algo_of(res[0].size())  # noqa: E731
+        metric = "rows/s hash inner_join, 500M x 50M int64 keys, 5% nulls"
+        workload = ("C3: 1xMI355X hash inner_join, 500M x 50M int64 keys with 5% null mask, selectivity 0.3, null_equality::UNEQUAL"
+                    + (" [keys x 1,000,003: sparse, served by the hash table]" if args.config == "c3sparse" else ""))
+    for _ in range(max(args.warmup, 1)):
+        run()
+    torch.cuda.synchronize()
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res = None
+        res = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.profile_enable(False)
+    prof = _lib.profile_report()
+    checks = check(res)
+    nbytes = algo(res)
+    ms = dt / args.steps * 1e3
+    name, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
+    avg_ms = total_ms / max(launches, 1)
+    per_launch = nbytes * (args.steps / max(launches, 1))  # a kernel launched several times per step shares the step's bytes
+    line = {"metric": metric, "value": rows * args.steps / dt, "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64" if args.config.startswith("c3") else "f64", "data": "synthetic",
+            "config": {"workload": workload, "scale": args.scale, "rows": rows, "checks": checks},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                         "launches_per_step": launches / args.steps, "algorithmic_bytes_per_step": nbytes,
+                         "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items())},
+                         "whole_call_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_config(args.config, rows)
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+
 def _timeit(fn):
     t0 = time.perf_counter()
     fn()
@@ -88,6 +172,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.config != "c2":
+        assert args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1, "--config c3 / c4 run on one GPU"
+        return run_config(args, json_fd)
     import torch
     import torch.distributed as dist
 

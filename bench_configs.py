@@ -39,6 +39,7 @@ def timed(fn, steps, warmup):
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
+        out = None  # the previous result goes back to the pool first: a caller keeps one result alive, not two
         out = fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
@@ -47,8 +48,9 @@ def timed(fn, steps, warmup):
     return out, dt, prof
 
 
-def c4(scale):
-    dev = torch.device("cuda", 0)
+def make_c4(scale, dev=None):
+    """-> (run callable, check callable(result) -> dict, rows, algorithmic bytes)."""
+    dev = dev or torch.device("cuda", 0)
     n = int(1_000_000_000 * scale)
     g = torch.Generator(device=dev).manual_seed(46)
     k0 = torch.randint(0, 10_000, (n,), generator=g, device=dev, dtype=torch.int64)
@@ -63,25 +65,35 @@ def c4(scale):
         grp = gb.GroupBy(keys, NullPolicy.EXCLUDE)
         return grp, grp.aggregate([gb.GroupByRequest(vals, [agg.mean(), agg.min(), agg.max()])], stream=torch.cuda.current_stream())
 
-    (grp, (uk, res)), dt, prof = timed(run, 3, 1)
-    G = uk.num_rows()
-    mean, mn, mx = [c.to_torch() for c in res[0].columns()]
-    # properties: group count == distinct valid (k0,k1) pairs; min <= mean <= max where valid; global max matches
-    combo = (k0 * 1000 + k1.to(torch.int64))[k1valid]
-    distinct = int(torch.unique(combo).numel())
-    checks = {"groups": G, "distinct_pairs": distinct, "groups_ok": G == distinct}
-    mvalid = ~torch.isnan(mean) if res[0].columns()[0].null_count() == 0 else None
-    sel = k1valid & vvalid
-    checks["global_max_ok"] = bool(abs(float(mx.max()) - float(v[sel].max())) == 0.0)
-    checks["global_min_ok"] = bool(abs(float(mn.min()) - float(v[sel].min())) == 0.0)
-    algo_bytes = n * (8 + 4 + 8) + 2 * n / 8
-    print(json.dumps({"config": "C4", "rows": n, "groups": G, "ms": dt * 1e3, "rows_per_s": n / dt,
-                      "algorithmic_GBps": algo_bytes / dt / 1e9, "path": grp.last_path.name,
-                      "kernels_ms": prof, "checks": checks}), flush=True)
+    def check(result):
+        grp, (uk, res) = result
+        G = uk.num_rows()
+        mean, mn, mx = [c.to_torch() for c in res[0].columns()]
+        # properties: group count == distinct valid (k0,k1) pairs; global min / max exact; every mean within [min, max]
+        combo = (k0 * 1000 + k1.to(torch.int64))[k1valid]
+        distinct = int(torch.unique(combo).numel())
+        sel = k1valid & vvalid
+        ok = ~torch.isnan(mean)
+        return {"groups": G, "distinct_pairs": distinct, "groups_ok": G == distinct,
+                "global_max_ok": bool(float(mx[ok].max()) == float(v[sel].max())), "global_min_ok": bool(float(mn[ok].min()) == float(v[sel].min())),
+                "mean_within_min_max": bool(((mean[ok] >= mn[ok]) & (mean[ok] <= mx[ok])).all()), "path": grp.last_path.name}
+
+    return run, check, n, n * (8 + 4 + 8) + 2 * n / 8
 
 
-def c3(scale):
-    dev = torch.device("cuda", 0)
+def c4(scale):
+    run, check, n, algo_bytes = make_c4(scale)
+    result, dt, prof = timed(run, 3, 2)
+    checks = check(result)
+    print(json.dumps({"config": "C4", "rows": n, "groups": checks["groups"], "ms": dt * 1e3, "rows_per_s": n / dt,
+                      "algorithmic_GBps": algo_bytes / dt / 1e9, "path": checks["path"], "kernels_ms": prof, "checks": checks}), flush=True)
+
+
+def make_c3(scale, dev=None, sparse=False):
+    """-> (run callable, check callable(result) -> dict, L + R rows, algorithmic bytes given the pair count).
+    sparse: the same tables with every key multiplied by an odd constant (keys no longer span a small range: the hash table
+    instead of the direct-address table)."""
+    dev = dev or torch.device("cuda", 0)
     nl, nr = int(500_000_000 * scale), int(50_000_000 * scale)
     g = torch.Generator(device=dev).manual_seed(12345)
     rk = torch.randperm(nr, generator=g, device=dev).to(torch.int64)  # unique build keys [0, nr)
@@ -91,22 +103,37 @@ def c3(scale):
     del sel
     lm, lnulls, lvalid = bernoulli_mask(nl, 0.05, 44, dev)
     rm, rnulls, rvalid = bernoulli_mask(nr, 0.05, 45, dev)
+    present = torch.zeros(2 * nr, dtype=torch.bool, device=dev)
+    present[rk[rvalid]] = True
+    expect = int((present[lk] & lvalid).sum())
+    del present
+    if sparse:
+        lk, rk = lk * 1_000_003, rk * 1_000_003
     L = cudf_amd.Table([cudf_amd.Column.from_torch(lk, lm, lnulls)])
     R = cudf_amd.Table([cudf_amd.Column.from_torch(rk, rm, rnulls)])
 
     def run():
         return J.inner_join(L, R, NullEquality.UNEQUAL, stream=torch.cuda.current_stream())
 
-    (li, ri), dt, prof = timed(run, 3, 1)
-    M = li.size()
-    li_t, ri_t = li.to_torch().long(), ri.to_torch().long()
-    present = torch.zeros(2 * nr, dtype=torch.bool, device=dev)
-    present[rk[rvalid]] = True
-    expect = int((present[lk] & lvalid).sum())
-    checks = {"pairs": M, "expected_pairs": expect, "count_ok": M == expect,
-              "keys_equal": bool((lk[li_t] == rk[ri_t]).all()), "no_null_rows": bool(lvalid[li_t].all() and rvalid[ri_t].all())}
-    algo_bytes = 8 * (nl + nr) + (nl + nr) / 8 + 8 * M
-    out = {"config": "C3", "left_rows": nl, "right_rows": nr, "pairs": M, "join_ms": dt * 1e3,
+    def check(result):
+        li, ri = result
+        M = li.size()
+        li_t, ri_t = li.to_torch().long(), ri.to_torch().long()
+        return {"pairs": M, "expected_pairs": expect, "count_ok": M == expect, "keys_equal": bool((lk[li_t] == rk[ri_t]).all()),
+                "no_null_rows": bool(lvalid[li_t].all() and rvalid[ri_t].all()),
+                "pairs_distinct": bool(torch.unique(li_t * (2 * nr) + ri_t).numel() == M) if M < 200_000_000 else None}
+
+    return run, check, nl + nr, lambda M: 8 * (nl + nr) + (nl + nr) / 8 + 8 * M, (nl, nr, dev)
+
+
+def c3(scale, sparse=False):
+    run, check, rows, algo, (nl, nr, dev) = make_c3(scale, sparse=sparse)
+    (li, ri), dt, prof = timed(run, 3, 2)
+    checks = check((li, ri))
+    M = checks["pairs"]
+    li_t = li.to_torch().long()
+    algo_bytes = algo(M)
+    out = {"config": "C3" + (" (sparse keys: hash table)" if sparse else ""), "left_rows": nl, "right_rows": nr, "pairs": M, "join_ms": dt * 1e3,
            "rows_per_s": (nl + nr) / dt, "algorithmic_GBps": algo_bytes / dt / 1e9, "kernels_ms": prof, "checks": checks}
     # gather 2 + 2 float64 payload columns by the returned indices
     lp = cudf_amd.Table([cudf_amd.Column.from_torch(torch.rand(nl, device=dev, dtype=torch.float64)) for _ in range(2)])
@@ -132,3 +159,6 @@ if __name__ == "__main__":
         torch.cuda.empty_cache()
     if "c3" in which:
         c3(scale)
+        torch.cuda.empty_cache()
+    if "c3sparse" in which:
+        c3(scale, sparse=True)

@@ -67,11 +67,27 @@ struct join_args {
   size_type* row_counts;
   // probe rows are rows [probe_row_base, ...) of a larger left table (partitioned_*_join): added to emitted indices
   int64_t probe_row_base;
+  // Dense build keys (one 8-byte integer key column whose valid values span a small range; NULLs never match): a
+  // direct-address table instead of the hash table. dense_head[key - dense_lo] = the LAST build row with that key (-1: none),
+  // dense_next[row] = the previous build row with the same key (-1: none): equal keys form a chain through dense_next.
+  // A probe is one range test (keys outside [lo, lo + range) touch no memory at all) and one 4-byte load; no hash, no tag, no
+  // key comparison. The reference probes cuco::static_multiset for every row (retrieve_impl.cuh:29-133).
+  int32_t* dense_head;
+  int32_t* dense_next;
+  uint64_t dense_lo;
+  uint64_t dense_range;
+  int32_t dense_has_dups;  // some key occurs more than once on the build side (chains longer than one)
+  int32_t* dense_dups;     // build only: device flag behind dense_has_dups
 };
 constexpr uint32_t MATCH_NONE  = 0xffffffffu;
 constexpr uint32_t MATCH_MULTI = 0x80000000u;
 
 void launch_build(join_args const& a, join_args* d_args, hipStream_t stream);
+// minimum and maximum of the valid keys of the (single 8-byte integer) build column: out[0] = min, out[1] = max (bit patterns);
+// out must hold {max value, min value} of the ordering before (launch_key_minmax initialises it)
+void launch_key_minmax(join_args const& a, join_args* d_args, int is_signed, uint64_t* out, hipStream_t stream);
+// fills dense_head / dense_next (dense_head preset to -1); sets *dense_dups when a key repeats
+void launch_dense_build(join_args const& a, join_args* d_args, hipStream_t stream);
 // probe-side radix partition (write-combining scatter, common/wc_scatter.hpp) into a.precs / a.region_count
 void launch_probe_partition(join_args const& a, join_args* d_args, hipStream_t stream);
 void launch_count(join_args const& a, join_args* d_args, hipStream_t stream);

@@ -104,6 +104,40 @@ class hash_join_impl {
     // sides are radix-partitioned on the same bits. Default: 8-byte slots, direct windowed probe.
     bool const build_check_nulls = _has_nulls && cudf::has_nulls(right);
     bool const key64 = is_single64(right) && (!build_check_nulls || _nulls_equal != null_equality::EQUAL);
+    // Dense build keys (one 8-byte integer key column, NULLs never match, valid values within a small range): a direct-address
+    // table over [min, max] replaces the hash table - see engine.hpp. Decided from the exact minimum / maximum of the build keys.
+    if (key64 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
+      hipStream_t const s = stream.value();
+      auto tmp            = cudf::get_current_device_resource_ref();
+      bool const is_signed = class_of(right.column(0).type().id()) == CLS_SINT;
+      rmm::device_buffer mm{2 * sizeof(uint64_t), s, tmp}, d_args{sizeof(join_args), s, tmp};
+      join_args a = base_args(right, 0);
+      join::launch_key_minmax(a, static_cast<join_args*>(d_args.data()), is_signed ? 1 : 0, static_cast<uint64_t*>(mm.data()), s);
+      uint64_t h_mm[2] = {0, 0};
+      CUDF_HIP_TRY(hipMemcpyAsync(h_mm, mm.data(), sizeof(h_mm), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipStreamSynchronize(s));
+      bool const any_valid = is_signed ? static_cast<int64_t>(h_mm[0]) <= static_cast<int64_t>(h_mm[1]) : h_mm[0] <= h_mm[1];
+      uint64_t const width = h_mm[1] - h_mm[0];  // exact in two's complement for either ordering
+      // at most 4 table entries (16 bytes) per build row, and at most 2^29 entries (2 GiB)
+      if (any_valid && width < std::min<uint64_t>(std::max<uint64_t>(4 * rows, uint64_t{1} << 20), uint64_t{1} << 29)) {
+        _dense_lo    = h_mm[0];
+        _dense_range = width + 1;
+        _dense_head  = rmm::device_buffer{_dense_range * sizeof(int32_t), s, mr};
+        _dense_next  = rmm::device_buffer{rows * sizeof(int32_t), s, mr};
+        CUDF_HIP_TRY(hipMemsetAsync(_dense_head.data(), 0xff, _dense_head.size(), s));
+        rmm::device_buffer dups{sizeof(int32_t), s, tmp};
+        CUDF_HIP_TRY(hipMemsetAsync(dups.data(), 0, sizeof(int32_t), s));
+        _dense       = true;
+        join_args b  = base_args(right, 0);
+        b.dense_dups = static_cast<int32_t*>(dups.data());
+        join::launch_dense_build(b, static_cast<join_args*>(d_args.data()), s);
+        int32_t h_dups = 0;
+        CUDF_HIP_TRY(hipMemcpyAsync(&h_dups, dups.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        CUDF_HIP_TRY(hipStreamSynchronize(s));
+        _dense_has_dups = h_dups != 0;
+        return;
+      }
+    }
     _slot_words      = (key64 && env_flag("CUDF_AMD_JOIN_PARTITIONED", 0)) ? 2 : 1;
     // big inline-key tables are sliced by the top hash bits (~2-4 MB per slice, what one XCD's L2 holds) so that a
     // radix-partitioned probe side walks one slice at a time
@@ -349,6 +383,13 @@ class hash_join_impl {
     a.nulls_equal = _nulls_equal == null_equality::EQUAL;
     a.check_nulls = _has_nulls && (cudf::has_nulls(_right) || cudf::has_nulls(probe));
     a.kind        = kind;
+    if (_dense) {
+      a.dense_head     = const_cast<int32_t*>(static_cast<int32_t const*>(_dense_head.data()));
+      a.dense_next     = const_cast<int32_t*>(static_cast<int32_t const*>(_dense_next.data()));
+      a.dense_lo       = _dense_lo;
+      a.dense_range    = _dense_range;
+      a.dense_has_dups = _dense_has_dups ? 1 : 0;
+    }
     // one 8-byte integer key per side; NULLs are fine as long as they can never match (UNEQUAL): then every key
     // comparison is between valid values and needs no descriptor walk
     a.single64    = is_single64(_right) && is_single64(probe) && (!a.check_nulls || !a.nulls_equal);
@@ -401,6 +442,9 @@ class hash_join_impl {
   int32_t _part_bits{0};
   uint64_t _slice{0};
   rmm::device_buffer _table{};
+  bool _dense{false}, _dense_has_dups{false};
+  uint64_t _dense_lo{0}, _dense_range{0};
+  rmm::device_buffer _dense_head{}, _dense_next{};
 };
 }  // namespace detail
 

@@ -478,6 +478,169 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
   }
 }
 
+
+// ------------------------------------------------------------------ dense build keys: direct-address table (engine.hpp)
+template <bool SIGNED>
+__global__ void __launch_bounds__(256) k_key_minmax(join_args const* __restrict__ ap, uint64_t* out)
+{
+  join_args const& a = *ap;
+  using T = std::conditional_t<SIGNED, long long, unsigned long long>;
+  __shared__ T s_lo[4], s_hi[4];
+  int64_t const n      = a.build.nrows;
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint64_t const* keys = static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset;
+  bool const masked    = a.check_nulls && a.build.col[0].mask != nullptr;
+  T lo = SIGNED ? static_cast<T>(INT64_MAX) : static_cast<T>(UINT64_MAX), hi = SIGNED ? static_cast<T>(INT64_MIN) : T{0};
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+    if (masked && !col_is_valid(a.build.col[0], i)) continue;
+    T const k = static_cast<T>(gload(keys + i));
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    T const l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      lo = s_lo[w] < lo ? s_lo[w] : lo;
+      hi = s_hi[w] > hi ? s_hi[w] : hi;
+    }
+    atomicMin(reinterpret_cast<T*>(out), lo);
+    atomicMax(reinterpret_cast<T*>(out) + 1, hi);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_dense_build(join_args const* __restrict__ ap)
+{
+  join_args const& a   = *ap;
+  int64_t const n      = a.build.nrows;
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint64_t const* keys = static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset;
+  bool const masked    = a.check_nulls && a.build.col[0].mask != nullptr;
+  bool dup             = false;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
+    if (masked && !col_is_valid(a.build.col[0], i)) continue;  // a NULL key is never inserted (null_equality::UNEQUAL)
+    uint64_t const idx = gload(keys + i) - a.dense_lo;         // < dense_range: lo / range come from these very keys
+    int32_t const old  = atomicExch(a.dense_head + idx, static_cast<int32_t>(i));
+    gstore(a.dense_next + i, old);
+    dup = dup || old >= 0;
+  }
+  if (__any(dup) && (threadIdx.x & 63) == 0) gstore(a.dense_dups, 1);
+}
+
+// count pass over a dense table: same outputs as k_probe_count (match cache, per-workgroup pair counts, optional row counts)
+__global__ void __launch_bounds__(256) k_dense_count(join_args const* __restrict__ ap)
+{
+  join_args const& a = *ap;
+  __shared__ unsigned long long s_total;
+  int64_t const n       = a.probe.nrows;
+  int const kind        = a.kind;
+  uint64_t const* pkeys = static_cast<uint64_t const*>(a.probe.col[0].head) + a.probe.col[0].offset;
+  bitmask_type const* probe_mask = a.check_nulls ? a.probe.col[0].mask : nullptr;
+  int64_t const probe_off        = a.probe.col[0].offset;
+  uint64_t const lo = a.dense_lo, range = a.dense_range;
+  bool const dups   = a.dense_has_dups != 0;
+  if (threadIdx.x == 0) s_total = 0;
+  __syncthreads();
+  constexpr int R = 4;
+  unsigned long long local_count = 0;
+  int64_t const begin = static_cast<int64_t>(blockIdx.x) * a.chunk, end = min(n, begin + a.chunk);
+  for (int64_t base = begin; base < end; base += static_cast<int64_t>(blockDim.x) * R) {
+    int64_t j[R];
+    bool live[R], in[R];
+    uint64_t idx[R];
+    int32_t head[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      j[k]    = base + static_cast<int64_t>(k) * blockDim.x + threadIdx.x;
+      live[k] = j[k] < end;
+      in[k]   = false;
+      idx[k]  = 0;
+      if (live[k]) {
+        bool valid = true;
+        if (probe_mask != nullptr) valid = (gload(probe_mask + ((probe_off + j[k]) >> 5)) >> ((probe_off + j[k]) & 31)) & 1u;
+        idx[k] = gload(pkeys + j[k]) - lo;
+        in[k]  = valid && idx[k] < range;  // a key outside the build side's range matches nothing and reads nothing
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) head[k] = in[k] ? gload(a.dense_head + idx[k]) : -1;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (!live[k]) continue;
+      unsigned int cnt = head[k] >= 0 ? 1u : 0u;
+      if (dups && cnt) {  // the rest of the key's chain
+        for (int32_t r = gload(a.dense_next + head[k]); r >= 0; r = gload(a.dense_next + r)) ++cnt;
+      }
+      gstore(a.match_cache + j[k], cnt == 0 ? MATCH_NONE : (static_cast<uint32_t>(head[k]) | (cnt > 1 ? MATCH_MULTI : 0u)));
+      unsigned int const emitted = (cnt == 0 && kind != 0) ? 1u : cnt;
+      if (a.row_counts != nullptr) gstore(a.row_counts + j[k], static_cast<size_type>(emitted));
+      local_count += emitted;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) local_count += __shfl_down(local_count, o);
+  if ((threadIdx.x & 63) == 0 && local_count) atomicAdd(&s_total, local_count);
+  __syncthreads();
+  if (threadIdx.x == 0) a.block_counts[blockIdx.x] = s_total;
+}
+
+// retrieve pass over a dense table: streams the match cache; rows with several matches walk their key's chain
+__global__ void __launch_bounds__(256) k_dense_retrieve(join_args const* __restrict__ ap)
+{
+  join_args const& a = *ap;
+  __shared__ unsigned long long s_cursor;
+  int64_t const n = a.probe.nrows;
+  int const kind  = a.kind;
+  if (threadIdx.x == 0) s_cursor = a.block_counts[blockIdx.x];
+  __syncthreads();
+  int const lane = threadIdx.x & 63;
+  auto emit = [&](bool want, size_type prow, size_type brow) {
+    unsigned long long const ballot = __ballot(want);
+    if (ballot == 0) return;
+    int const lead = __ffsll(static_cast<long long>(ballot)) - 1;
+    int const rank = __popcll(ballot & ((1ull << lane) - 1));
+    unsigned long long base = 0;
+    if (lane == lead) base = atomicAdd(&s_cursor, static_cast<unsigned long long>(__popcll(ballot)));
+    base = __shfl(base, lead);
+    if (want) {
+      uint64_t const o = base + rank;
+      if (o < a.out_capacity) {
+        gstore(a.out_probe + o, prow);
+        gstore(a.out_build + o, brow);
+      }
+      if (kind == 2 && brow != JoinNoMatch) gstore(a.build_matched + brow, uint8_t{1});
+    }
+  };
+  int64_t const begin = static_cast<int64_t>(blockIdx.x) * a.chunk, end = min(n, begin + a.chunk);
+  for (int64_t j0 = begin; j0 < end; j0 += blockDim.x) {
+    int64_t const j  = j0 + threadIdx.x;
+    bool const live  = j < end;
+    uint32_t const c = live ? gload(a.match_cache + j) : MATCH_NONE;
+    bool const none  = c == MATCH_NONE;
+    bool const multi = !none && (c & MATCH_MULTI);
+    size_type const prow = static_cast<size_type>(j + a.probe_row_base);
+    int32_t r = static_cast<int32_t>(c & ~MATCH_MULTI);
+    emit(live && !none, prow, r);  // the head of the chain (the only match of most rows)
+    if (kind != 0) emit(live && none, prow, JoinNoMatch);
+    bool walking = multi;
+    while (__any(walking)) {
+      if (walking) {
+        r       = gload(a.dense_next + r);
+        walking = r >= 0;
+      }
+      emit(walking, prow, r);
+    }
+  }
+}
+
 // exclusive scan of the per-block pair counts (nblocks <= 65536): one workgroup
 __global__ void __launch_bounds__(1024) k_scan_counts(unsigned long long* counts, int32_t nblocks)
 {
@@ -572,6 +735,25 @@ void launch_build(join_args const& a, join_args* d_args, hipStream_t stream)
   else hipLaunchKernelGGL(k_build<false>, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
+void launch_key_minmax(join_args const& a, join_args* d_args, int is_signed, uint64_t* out, hipStream_t stream)
+{
+  struct range_init { uint64_t lo, hi; };
+  range_init const init{is_signed ? static_cast<uint64_t>(INT64_MAX) : UINT64_MAX, is_signed ? static_cast<uint64_t>(INT64_MIN) : uint64_t{0}};
+  hipLaunchKernelGGL(k_store_args<range_init>, dim3(1), dim3(1), 0, stream, init, reinterpret_cast<range_init*>(out));
+  hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_build", stream};
+  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((a.build.nrows + 4095) / 4096, 1, 1024));
+  if (is_signed) hipLaunchKernelGGL(k_key_minmax<true>, dim3(grid), dim3(256), 0, stream, d_args, out);
+  else hipLaunchKernelGGL(k_key_minmax<false>, dim3(grid), dim3(256), 0, stream, d_args, out);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+void launch_dense_build(join_args const& a, join_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_build", stream};
+  hipLaunchKernelGGL(k_dense_build, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
 void launch_probe_partition(join_args const& a, join_args* d_args, hipStream_t stream)
 {
   hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
@@ -595,7 +777,8 @@ void launch_count(join_args const& a, join_args* d_args, hipStream_t stream)
 {
   hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_count", stream};
-  if (a.partitioned) hipLaunchKernelGGL((k_probe_count<MODE_KEY64_INLINE, true>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  if (a.dense_head != nullptr) hipLaunchKernelGGL(k_dense_count, dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  else if (a.partitioned) hipLaunchKernelGGL((k_probe_count<MODE_KEY64_INLINE, true>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else if (a.single64 && a.slot_words == 2) hipLaunchKernelGGL((k_probe_count<MODE_KEY64_INLINE, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else if (a.single64) hipLaunchKernelGGL((k_probe_count<MODE_KEY64, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else hipLaunchKernelGGL((k_probe_count<MODE_GENERIC, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
@@ -610,7 +793,8 @@ void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream)
 {
   hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_retrieve", stream};
-  if (a.partitioned) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64_INLINE, true>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  if (a.dense_head != nullptr) hipLaunchKernelGGL(k_dense_retrieve, dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  else if (a.partitioned) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64_INLINE, true>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else if (a.single64 && a.slot_words == 2) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64_INLINE, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else if (a.single64) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else hipLaunchKernelGGL((k_probe_retrieve<MODE_GENERIC, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);

@@ -358,3 +358,53 @@ def test_fuzz_joins_against_oracle(G, oracle, seed, monkeypatch):
     nulls_equal = bool(rng.random() < 0.5)
     kind = str(rng.choice(["inner", "left", "full"]))
     _check(G, oracle, left, right, nulls_equal, kind)
+
+
+@pytest.mark.parametrize("kind", ["inner", "left", "full"])
+@pytest.mark.parametrize("shape", ["unique", "duplicates", "negative", "nulls"])
+def test_dense_key_join_against_oracle(G, oracle, monkeypatch, kind, shape):
+    """One int64 key column whose build-side values span a small range: the direct-address table (head + chain through the
+    build rows) replaces the hash table. Unique and repeated build keys, negative keys, NULLs that never match (UNEQUAL),
+    probe keys outside the build side's range, all three join kinds; the same call with CUDF_AMD_JOIN_DENSE=0 agrees."""
+    rng = np.random.default_rng(91)
+    nl, nr = 120_000, 70_000
+    lo = -35_000 if shape == "negative" else 1_000_000
+    if shape == "duplicates":
+        rk = rng.integers(0, 9_000, nr, dtype=np.int64) + lo  # ~8 build rows per key
+    else:
+        rk = rng.permutation(nr).astype(np.int64) + lo
+    lk = rng.integers(-20_000, nr + 40_000, nl, dtype=np.int64) + lo  # a third of the probe keys lie outside the range
+    lv = rv = None
+    if shape == "nulls":
+        lv, rv = rng.random(nl) > 0.1, rng.random(nr) > 0.1
+    left, right = [(lk, lv)] if lv is not None else [lk], [(rk, rv)] if rv is not None else [rk]
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
+    li, ri = G.join(left, right, nulls_equal=False, kind=kind)
+    el, er = oracle.join(left, right, nulls_equal=False, kind=kind)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE", "0")
+    li2, ri2 = G.join(left, right, nulls_equal=False, kind=kind)
+    assert kat.sorted_pairs(li2, ri2) == kat.sorted_pairs(el, er)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_dense_joins_against_oracle(G, oracle, monkeypatch, seed):
+    """Seeded shapes on the dense path (CUDF_AMD_JOIN_DENSE_MIN_ROWS=1): sizes 0 .. 60K, key ranges from a handful of values to
+    sparse (where the planner must fall back to the hash table), heavy duplication, nulls under both null equalities."""
+    rng = np.random.default_rng(7000 + seed)
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
+    nl, nr = int(rng.choice([0, 1, 300, 60_000])), int(rng.choice([1, 17, 5_000, 40_000]))
+    spread = int(rng.choice([3, 500, 50_000, 10**12]))
+    while nl * nr / spread > 2e6:  # keep the result enumerable on the host
+        nl, nr = max(1, nl // 2), max(1, nr // 2)
+    base = int(rng.choice([0, -10**9, 2**62]))
+    rk = rng.integers(0, spread, nr, dtype=np.int64) + base
+    lk = rng.integers(0, max(2, int(spread * 1.3)), nl, dtype=np.int64) + base - int(0.1 * min(spread, 10**6))
+    lv = (rng.random(nl) > 0.2) if rng.random() < 0.5 else None
+    rv = (rng.random(nr) > 0.2) if rng.random() < 0.5 else None
+    left, right = [(lk, lv)] if lv is not None else [lk], [(rk, rv)] if rv is not None else [rk]
+    for kind in ("inner", "left", "full"):
+        for eq in (False, True):
+            li, ri = G.join(left, right, nulls_equal=eq, kind=kind)
+            el, er = oracle.join(left, right, nulls_equal=eq, kind=kind)
+            assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er), (kind, eq)
