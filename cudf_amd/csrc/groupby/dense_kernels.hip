@@ -55,6 +55,58 @@ __global__ void __launch_bounds__(256) k_key_range(plan_dev const* __restrict__ 
   }
 }
 
+// sample minimum / maximum of EVERY key column of a plan (any integer width, nullable): valid values only, as int64
+__global__ void __launch_bounds__(256) k_key_ranges(plan_dev const* __restrict__ pp, int nkeycols, int64_t nrows, int64_t sample, long long* out)
+{
+  plan_dev const& p = *pp;
+  __shared__ long long s_lo[4][MAX_KU], s_hi[4][MAX_KU];
+  long long lo[MAX_KU], hi[MAX_KU];
+#pragma unroll
+  for (int c = 0; c < MAX_KU; ++c) {
+    lo[c] = INT64_MAX;
+    hi[c] = INT64_MIN;
+  }
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < sample; i += stride) {
+    int64_t const row = dense_sample_row(i, nrows, sample);
+#pragma unroll
+    for (int c = 0; c < MAX_KU; ++c) {
+      if (c >= nkeycols) break;
+      device_column const col = p.cols[c];
+      if (!col_is_valid(col, row)) continue;
+      uint64_t const raw = col_load_bits(col, row);
+      int const sh       = 64 - 8 * col.width;
+      long long const v  = col.cls == cudf::detail::CLS_SINT ? (static_cast<long long>(raw << sh) >> sh) : static_cast<long long>(raw);
+      lo[c] = v < lo[c] ? v : lo[c];
+      hi[c] = v > hi[c] ? v : hi[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < MAX_KU; ++c) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      long long const l2 = __shfl_xor(lo[c], o), h2 = __shfl_xor(hi[c], o);
+      lo[c] = l2 < lo[c] ? l2 : lo[c];
+      hi[c] = h2 > hi[c] ? h2 : hi[c];
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_lo[threadIdx.x >> 6][c] = lo[c];
+      s_hi[threadIdx.x >> 6][c] = hi[c];
+    }
+  }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < nkeycols) {
+    int const c = threadIdx.x;
+    long long l = s_lo[0][c], h = s_hi[0][c];
+    for (int w = 1; w < 4; ++w) {
+      l = s_lo[w][c] < l ? s_lo[w][c] : l;
+      h = s_hi[w][c] > h ? s_hi[w][c] : h;
+    }
+    atomicMin(out + 2 * c, l);
+    atomicMax(out + 2 * c + 1, h);
+  }
+}
+
 // ------------------------------------------------------------------ K_aggregate_dense
 // LDS image of a table: accumulator q as [slots] u64 (u32 for a COUNT), 8-byte arrays first; then the occupancy bitmap
 // [slots / 32] u32 if no accumulator counts every row. The image is copied verbatim from / to HBM between chunks.
@@ -97,7 +149,7 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
   int const NACC  = STATIC_SIG ? sig_n(SIG) : p.NACC;
   int const slots = a.slots, item = blockIdx.x, B = blockDim.x;
   int const occ_acc = a.occ_acc;
-  int acc_op[NACCT], acc_src[NACCT];
+  int acc_op[NACCT], acc_src[NACCT], acc_vbit[NACCT];
   uint32_t acc_off[NACCT];
   bool acc_narrow[NACCT];
   uint32_t off8 = 0, off4 = 0;
@@ -106,6 +158,7 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
     uint32_t const w = j < NACC ? reinterpret_cast<uint32_t const*>(p.acc)[j] : 0u;
     acc_op[j]        = STATIC_SIG ? sig_op(SIG, j) : static_cast<int8_t>(w);
     acc_src[j]       = STATIC_SIG ? sig_src(SIG, j) : static_cast<int8_t>(w >> 8);
+    acc_vbit[j]      = STATIC_SIG ? sig_vbit(SIG, j) : static_cast<int8_t>(w >> 24);
     acc_narrow[j]    = j < NACC && acc_is_narrow(acc_op[j], acc_src[j]);
     if (j < NACC && !acc_narrow[j]) off4 += static_cast<uint32_t>(slots) * 8u;
   }
@@ -143,13 +196,17 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
 
   uint64_t const lo = a.map.lo;
   uint32_t const mult = a.map.mult, smask = static_cast<uint32_t>(slots - 1);
+  bool const composite = a.map.nkeys > 0;  // records hold {index | validity of the value, value}
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
   // an upstream scatter gave up (region overflow / key outside the dense range): its counts are not valid
   bool const upstream_ok = *a.overflow == 0;
-  // ---- this wave's regions as one virtual range
-  int const g      = (a.slices + nwaves - 1) / nwaves;  // <= 64 (slices <= 1024)
-  int const r_base = wave * g;
-  int32_t cnt      = 0;
+  // ---- the partition's regions as virtual record ranges. Many short regions (one per scatter workgroup): wave w walks the
+  // regions [w * g, (w + 1) * g) as ONE range. A few long ones (the output of a second partition level): every wave sees all
+  // of them as one range and the waves take its batches in turn.
+  bool const shared = a.slices <= 64;
+  int const g       = shared ? a.slices : (a.slices + nwaves - 1) / nwaves;  // regions in this wave's range, <= 64
+  int const r_base  = shared ? 0 : wave * g;
+  int32_t cnt       = 0;
   if (upstream_ok && lane < g && r_base + lane < a.slices)
     cnt = min(max(a.region_count[static_cast<int64_t>(item) * a.slices + r_base + lane], 0), static_cast<int32_t>(a.region_cap));
   int32_t pend = cnt;  // inclusive prefix: end of region `lane` in the virtual range
@@ -178,11 +235,15 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
     return static_cast<int64_t>(reg) * cap + (v - start);
   };
   auto accumulate = [&](uint64_t key, uint64_t value) {
-    uint32_t const s = (static_cast<uint32_t>(key - lo) * mult) & smask;
+    uint32_t const idx   = composite ? static_cast<uint32_t>(key) : static_cast<uint32_t>(key - lo);
+    bool const val_valid = !composite || ((key >> 32) & 1u);  // (a single plain key column comes with a plain value column)
+    uint32_t const s     = (idx * mult) & smask;
 #pragma unroll
     for (int q = 0; q < NACCT; ++q) {
       if (q >= NACC) break;
-      if (acc_narrow[q]) {  // row counts (no nulls on this path: COUNT_VALID == COUNT_ALL)
+      bool const counts_all = acc_src[q] == SRC_ONE;
+      if (!counts_all && acc_vbit[q] >= 0 && !val_valid) continue;  // a NULL value reaches nothing but COUNT_ALL
+      if (acc_narrow[q]) {
         atomicAdd(acc32(q) + s, 1u);
         continue;
       }
@@ -195,7 +256,8 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
     }
   };
   constexpr int R = 4;
-  for (int32_t v0 = 0; v0 < total; v0 += R * 64) {
+  int32_t const vstep = shared ? R * 64 * nwaves : R * 64;
+  for (int32_t v0 = shared ? wave * R * 64 : 0; v0 < total; v0 += vstep) {
     u64x2 rec[R];
     bool act[R];
 #pragma unroll
@@ -217,8 +279,9 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
       gstore(reinterpret_cast<u64x2*>(image) + i, reinterpret_cast<u64x2 const*>(lds_raw)[i]);
     return;
   }
-  // ---- last chunk: occupied slots -> partial records [key | accumulators] (k_finalize reads them)
-  int const PU       = 1 + NACC;
+  // ---- last chunk: occupied slots -> partial records [key units | accumulators] (k_finalize reads them)
+  int const KU       = a.KU;
+  int const PU       = KU + NACC;
   uint64_t* out      = a.out_records + static_cast<int64_t>(item) * slots * PU;
   uint32_t const hi  = static_cast<uint32_t>(item) << (a.map.bits - a.map.log2P);
   uint32_t const bmask = (1u << a.map.bits) - 1u;
@@ -236,11 +299,28 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
     uint32_t const pos = atomicAdd(&s_dump, 1u);
     uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
     uint32_t const idx = ((hi | static_cast<uint32_t>(s)) * a.map.mult_inv) & bmask;
-    gstore(o, lo + idx);
+    if (!composite) {
+      gstore(o, lo + idx);
+    } else {
+      // the key columns' values from the mixed-radix digits of the index, placed where the plan's key units hold them
+      uint64_t unit[MAX_KU] = {0, 0, 0, 0};
+      for (int c = 0; c < a.map.nkeys; ++c) {
+        dense_key const dk   = a.map.key[c];
+        uint64_t const digit = (idx / dk.stride) % dk.range;
+        uint64_t v           = dk.lo + digit;
+        if (dk.width < 8) v &= (uint64_t{1} << (8 * dk.width)) - 1;  // key units hold the zero-extended raw bits
+#pragma unroll
+        for (int u = 0; u < MAX_KU; ++u)
+          if (u == dk.unit) unit[u] |= dk.half == 1 ? (v << 32) : v;
+      }
+#pragma unroll
+      for (int u = 0; u < MAX_KU; ++u)
+        if (u < KU) gstore(o + u, unit[u]);
+    }
 #pragma unroll
     for (int q = 0; q < NACCT; ++q) {
       if (q >= NACC) break;
-      gstore(o + 1 + q, acc_narrow[q] ? static_cast<uint64_t>(acc32(q)[s]) : acc64(q)[s]);
+      gstore(o + KU + q, acc_narrow[q] ? static_cast<uint64_t>(acc32(q)[s]) : acc64(q)[s]);
     }
   }
   __syncthreads();
@@ -279,7 +359,8 @@ static void launch_dense_n(dense_agg_args const& a, dense_agg_args const* d_args
 
 void launch_aggregate_dense(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream)
 {
-  CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1 && a.plan.narg == 0, "dense keys: one plain key column, one plain value column");
+  CUDF_EXPECTS(a.plan.narg == 0 && (a.map.nkeys > 0 || (a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1)),
+               "dense keys: one plain key column and one plain value column, or composite integer keys and one value column");
   CUDF_EXPECTS(a.block == 1024 && a.slices <= 1024 && a.image_bytes <= 159 * 1024 && (a.slots & (a.slots - 1)) == 0 &&
                  a.occ_acc == dense_occ_acc(a.plan) && a.image_bytes == static_cast<int32_t>(dense_table_bytes(a.plan, a.slots)),
                "dense keys: table geometry");
@@ -290,8 +371,27 @@ void launch_aggregate_dense(dense_agg_args const& a, dense_agg_args const* d_arg
   if (sig == SIG_SUMI) return launch_dense_n<SIG_SUMI, 2>(a, d_args, first_chunk, last_chunk, stream);
   if (sig == SIG_CNT) return launch_dense_n<SIG_CNT, 2>(a, d_args, first_chunk, last_chunk, stream);
   if (sig == SIG_MEAN_MIN_MAX_F) return launch_dense_n<SIG_MEAN_MIN_MAX_F, 4>(a, d_args, first_chunk, last_chunk, stream);
+  if (sig == SIG_MEAN_MIN_MAX_F_NULLS) return launch_dense_n<SIG_MEAN_MIN_MAX_F_NULLS, 4>(a, d_args, first_chunk, last_chunk, stream);
+  if (sig == SIG_SUMF_CNT_NULLS) return launch_dense_n<SIG_SUMF_CNT_NULLS, 2>(a, d_args, first_chunk, last_chunk, stream);
+  if (sig == SIG_SUMI_CNT_NULLS) return launch_dense_n<SIG_SUMI_CNT_NULLS, 2>(a, d_args, first_chunk, last_chunk, stream);
   if (a.plan.NACC <= 4) return launch_dense_n<0, 4>(a, d_args, first_chunk, last_chunk, stream);
   return launch_dense_n<0, MAX_ACC>(a, d_args, first_chunk, last_chunk, stream);
+}
+
+void launch_key_ranges(plan_dev const* d_plan, int nkeycols, int64_t nrows, int64_t sample, int64_t* out, hipStream_t stream)
+{
+  CUDF_EXPECTS(nkeycols >= 1 && nkeycols <= MAX_KU, "dense keys: 1 to 4 key columns");
+  struct ranges_init { int64_t v[2 * MAX_KU]; };
+  ranges_init init{};
+  for (int c = 0; c < MAX_KU; ++c) {
+    init.v[2 * c]     = INT64_MAX;
+    init.v[2 * c + 1] = INT64_MIN;
+  }
+  hipLaunchKernelGGL(k_store_args<ranges_init>, dim3(1), dim3(1), 0, stream, init, reinterpret_cast<ranges_init*>(out));
+  cudf::detail::prof::scope prof_{"estimate", stream};
+  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((sample + 1023) / 1024, 1, 1024));
+  hipLaunchKernelGGL(k_key_ranges, dim3(grid), dim3(256), 0, stream, d_plan, nkeycols, nrows, sample, reinterpret_cast<long long*>(out));
+  CUDF_HIP_TRY(hipGetLastError());
 }
 
 void launch_key_range(plan_dev const* d_plan, int64_t nrows, int64_t sample, int is_signed, uint64_t* out, hipStream_t stream)

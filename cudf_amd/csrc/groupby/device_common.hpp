@@ -631,7 +631,8 @@ struct region_input {
       int32_t run = 0;
       for (int j = 0; j < nreg; ++j) {
         pre[j] = run;
-        run += max(a.in_region_count[static_cast<int64_t>(g) * a.in_slices + s + static_cast<int64_t>(j) * a.geom.slices], 0);
+        // (clamped: a level-1 workgroup that gave up left its counts unwritten)
+        run += static_cast<int32_t>(min(static_cast<int64_t>(max(a.in_region_count[static_cast<int64_t>(g) * a.in_slices + s + static_cast<int64_t>(j) * a.geom.slices], 0)), a.in_region_cap));
       }
       pre[nreg] = run;
     }

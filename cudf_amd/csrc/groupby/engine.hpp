@@ -186,13 +186,33 @@ struct agg_args {
 // bits (mult odd) that spreads runs and strides of keys over the partitions; partition = its top log2P bits, table
 // slot = the remaining low bits. A table holds no key words and no state words: slot s of partition d IS the key
 // lo + ((d << (bits - log2P) | s) * mult_inv mod 2^bits).
-struct dense_map {
+constexpr int DENSE_MAX_KEYS = 4;
+// One integer key column of a COMPOSITE dense key: digit = value - lo in [0, range); the row's index is the mixed-radix number
+// sum(digit_c * stride_c). unit / half say where the column's bits sit in the key units of a partial record (engine.hpp plan).
+struct dense_key {
   uint64_t lo;
-  uint64_t range;
+  uint32_t range;
+  uint32_t stride;
+  int8_t col;        // plan column
+  int8_t unit;
+  int8_t half;       // 0: low half, 1: high half, 2: the whole unit
+  int8_t is_signed;  // narrow signed types are sign-extended before lo is subtracted
+  int32_t width;     // bytes
+};
+struct dense_map {
+  uint64_t lo;        // single plain 8-byte key (nkeys == 0): index = key - lo
+  uint64_t range;     // indices are in [0, range)
   uint32_t mult;
   uint32_t mult_inv;  // mult * mult_inv = 1 mod 2^32
   int32_t bits;       // 2^bits >= range, bits <= 30
-  int32_t log2P;
+  int32_t log2P;      // partition = top log2P bits of scrambled (over all levels), table slot = the low bits - log2P bits
+  // Composite keys (nkeys >= 1): 1-4 integer key columns of any width, nullable under null_policy::EXCLUDE (a row with a NULL
+  // key is dropped), one value column of any fixed-width type, nullable. The 16-byte record is
+  // { index (low 32 bits) | validity of the value (bit 32), value as its 8-byte accumulator class }.
+  int32_t nkeys;
+  int32_t value_col;  // plan column of the value
+  int32_t value_nullable;
+  dense_key key[DENSE_MAX_KEYS];
 };
 
 struct part_args {
@@ -266,6 +286,7 @@ struct dense_agg_args {
   int32_t slots;        // per table: 1 << (bits - log2P)
   int32_t image_bytes;  // multiple of 16
   int32_t occ_acc;      // accumulator that counts every row (SRC_ONE): a slot is occupied iff it is > 0; -1: occupancy bitmap
+  int32_t KU;           // key units of a partial record (composite keys: the plan's; single plain key: 1)
   uint64_t* tables;     // [P][image_bytes / 8]
   uint64_t* out_records;
   int32_t* out_count;
@@ -280,6 +301,9 @@ void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t str
 // Minimum and maximum of a plain 8-byte integer key column over the strided sample of launch_estimate (signed compare
 // for signed keys): out[0] = min, out[1] = max as bit patterns. `out` must hold {max value, min value} of the ordering before.
 void launch_key_range(plan_dev const* d_plan, int64_t nrows, int64_t sample, int is_signed, uint64_t* out, hipStream_t stream);
+// The same for every key column of a plan (any integer width, nullable): out[2 c] = min, out[2 c + 1] = max of the VALID sampled
+// values of key column c, as int64 (signed columns sign-extended, unsigned zero-extended).
+void launch_key_ranges(plan_dev const* d_plan, int nkeycols, int64_t nrows, int64_t sample, int64_t* out, hipStream_t stream);
 
 // Launchers (partition_kernels.hip, aggregate_kernels.hip). All asynchronous on `stream`. Kernel arguments live in DEVICE memory (`d_args`,
 // one slot per launch family, written by a one-thread kernel on the same stream): passed by value, the

@@ -601,8 +601,16 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   bool const dense_signed    = p.cols[0].cls == cudf::detail::CLS_SINT;
   bool const dense_candidate = p.simple && p.KU == 1 && p.NPAY == 1 && p.narg == 0 && n >= (int64_t{1} << 22) &&
                                env_i64("CUDF_AMD_GB_DENSE", 1) != 0;
-  bool allow_dense   = dense_candidate;
+  // Composite dense keys: 1-4 integer key columns of any width (rows with a NULL key are dropped: no nullable key under
+  // null_policy::INCLUDE), exactly one value column, no ARGMIN / ARGMAX
+  bool dense_composite = !dense_candidate && p.nkeycols <= DENSE_MAX_KEYS && hp.value_cols.size() == 1 && p.narg == 0 &&
+                         hp.keynulls_unit < 0 && n >= (int64_t{1} << 22) && env_i64("CUDF_AMD_GB_DENSE", 1) != 0 &&
+                         env_i64("CUDF_AMD_GB_DENSE_COMPOSITE", 1) != 0;
+  for (int c = 0; c < p.nkeycols && dense_composite; ++c)
+    dense_composite = p.cols[c].cls == cudf::detail::CLS_SINT || p.cols[c].cls == cudf::detail::CLS_UINT;
+  bool allow_dense   = dense_candidate || dense_composite;
   uint64_t h_range[2] = {0, 0};  // sample minimum / maximum of the key column (bit patterns)
+  int64_t h_ranges[2 * MAX_KU] = {0};  // composite: per key column, as int64
   int64_t final_cap  = 0;        // records per work item in `partial` (0: ag.cap)
   // ---- distinct-count estimate on a strided sample (skipped when n already fits one table)
   double est_groups = static_cast<double>(n);
@@ -624,6 +632,10 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       d_range = sc.alloc<uint64_t>(2);
       launch_key_range(d_plan, n, sample, dense_signed ? 1 : 0, d_range, s);
       CUDF_HIP_TRY(hipMemcpyAsync(h_range, d_range, 16, hipMemcpyDeviceToHost, s));
+    } else if (dense_composite) {
+      int64_t* d_ranges = sc.alloc<int64_t>(2 * MAX_KU);
+      launch_key_ranges(d_plan, p.nkeycols, n, sample, d_ranges, s);
+      CUDF_HIP_TRY(hipMemcpyAsync(h_ranges, d_ranges, sizeof(h_ranges), hipMemcpyDeviceToHost, s));
     }
     // Heavy hitters (plain int64 key + one plain value, SUM / COUNT): a key above ~0.05 % of the rows overflows its
     // regions of the optimistic partition, and a key with percents of the rows leaves one workgroup aggregating its
@@ -802,57 +814,98 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         nitems  = next;
       }
     } else {
-      // ---------------- path D: dense integer keys -> direct-address LDS tables, chunked through the Infinity Cache
+      // ---------------- path D: dense integer keys -> direct-address LDS tables (no hash, no probe, no key words)
       final_cap = 0;
       if (allow_dense && forced_p == 0 && hot_keys.empty() && !forced_exact) {
-        // key range from the sample, widened by a margin (the sample's extremes of a dense column miss the true ones by
-        // about range / sample); a key outside [lo, lo + range) voids the attempt (overflow bit 2) and the call is redone by hash
-        uint64_t const width  = h_range[1] - h_range[0];  // exact in two's complement for either ordering
-        uint64_t const margin = std::clamp<uint64_t>(width / 64, 4096, uint64_t{1} << 26);
-        uint64_t lo, hi;
-        if (dense_signed) {
-          int64_t const l = static_cast<int64_t>(h_range[0]), h = static_cast<int64_t>(h_range[1]);
-          lo = static_cast<uint64_t>(l < INT64_MIN + static_cast<int64_t>(margin) ? INT64_MIN : l - static_cast<int64_t>(margin));
-          hi = static_cast<uint64_t>(h > INT64_MAX - static_cast<int64_t>(margin) ? INT64_MAX : h + static_cast<int64_t>(margin));
+        dense_map dm{};
+        bool dense_ok = false;
+        if (dense_candidate) {
+          // one plain 8-byte key: range from the sample, widened by a margin (the sample's extremes of a dense column miss the
+          // true ones by about range / sample); a key outside [lo, lo + range) voids the attempt (overflow bit 2): redone by hash
+          uint64_t const width  = h_range[1] - h_range[0];  // exact in two's complement for either ordering
+          uint64_t const margin = std::clamp<uint64_t>(width / 64, 4096, uint64_t{1} << 26);
+          uint64_t lo, hi;
+          if (dense_signed) {
+            int64_t const l = static_cast<int64_t>(h_range[0]), h = static_cast<int64_t>(h_range[1]);
+            lo = static_cast<uint64_t>(l < INT64_MIN + static_cast<int64_t>(margin) ? INT64_MIN : l - static_cast<int64_t>(margin));
+            hi = static_cast<uint64_t>(h > INT64_MAX - static_cast<int64_t>(margin) ? INT64_MAX : h + static_cast<int64_t>(margin));
+          } else {
+            lo = h_range[0] < margin ? 0 : h_range[0] - margin;
+            hi = h_range[1] > UINT64_MAX - margin ? UINT64_MAX : h_range[1] + margin;
+          }
+          dm.lo    = lo;
+          dm.range = hi - lo + 1;  // (0 if the keys span the whole type: fails the test below)
+          dense_ok = width <= (uint64_t{1} << 30) && dm.range != 0;
         } else {
-          lo = h_range[0] < margin ? 0 : h_range[0] - margin;
-          hi = h_range[1] > UINT64_MAX - margin ? UINT64_MAX : h_range[1] + margin;
+          // composite: every key column contributes the digit (value - lo_c) of a mixed-radix index, last column fastest
+          double total = 1.0;
+          dense_ok     = true;
+          for (int c = 0; c < p.nkeycols; ++c) {
+            int64_t const l = h_ranges[2 * c], h = h_ranges[2 * c + 1];
+            if (l > h || static_cast<double>(h) - static_cast<double>(l) > 1e9) { dense_ok = false; break; }  // (no valid sampled value / wide)
+            int64_t const width  = h - l;
+            int64_t const margin = width / 64 + (width >= 64 ? 2 : 0);
+            dense_key& dk = dm.key[c];
+            dk.lo        = static_cast<uint64_t>(l - margin);
+            dk.range     = static_cast<uint32_t>(width + 2 * margin + 1);
+            dk.col       = static_cast<int8_t>(c);
+            dk.unit      = static_cast<int8_t>(hp.key_unit[c]);
+            dk.half      = static_cast<int8_t>(hp.key_half[c]);
+            dk.is_signed = p.cols[c].cls == cudf::detail::CLS_SINT;
+            dk.width     = p.cols[c].width;
+            total *= static_cast<double>(dk.range);
+          }
+          dense_ok = dense_ok && total <= static_cast<double>(uint64_t{1} << 30);
+          if (dense_ok) {
+            uint64_t stride = 1;
+            for (int c = p.nkeycols - 1; c >= 0; --c) {
+              dm.key[c].stride = static_cast<uint32_t>(stride);
+              stride *= dm.key[c].range;
+            }
+            dm.range          = stride;
+            dm.nkeys          = p.nkeycols;
+            dm.value_col      = p.nkeycols;
+            dm.value_nullable = p.cols[p.nkeycols].mask != nullptr;
+          }
         }
-        uint64_t const range = hi - lo + 1;  // (0 if the keys span the whole type: fails the test below)
         int bits = 14;
-        while (bits < 31 && (uint64_t{1} << bits) < range) ++bits;
+        while (bits < 31 && (uint64_t{1} << bits) < dm.range) ++bits;
         double const unit_bytes = static_cast<double>(dense_table_bytes(p, 4096)) / 4096.0;  // LDS bytes per key of the range
-        // tables of ~32 KiB (two 1024-thread workgroups per CU), at least 256 and at most 1024 of them; the carried table
-        // images of all partitions stay below 32 MiB (they travel to LDS and back once per chunk)
+        // One level: tables of ~32 KiB (two 1024-thread workgroups per CU), 256 to 1024 of them. A range that needs more than
+        // 1024 tables of 150 KiB takes two levels (P1 x P2) with the largest tables that fit.
         int log2P = 8;
         while (log2P < 10 && std::ldexp(unit_bytes, bits - log2P) > 32.0 * 1024) ++log2P;
+        while (log2P < 20 && std::ldexp(unit_bytes, bits - log2P) > 150.0 * 1024) ++log2P;
         if (env_i64("CUDF_AMD_GB_DENSE_LOG2P", 0) > 0) log2P = static_cast<int>(env_i64("CUDF_AMD_GB_DENSE_LOG2P", 0));
-        int const slots           = 1 << (bits - log2P);
+        bool const two_level      = log2P > 10;
+        int const log2P1          = two_level ? (log2P + 1) / 2 : log2P;
+        int const log2P2          = log2P - log2P1;
+        int const slots           = 1 << std::max(bits - log2P, 0);
         std::size_t const image   = dense_table_bytes(p, slots);
-        bool const dense_ok = width <= (uint64_t{1} << 30) && range != 0 && range <= (uint64_t{1} << bits) && bits <= 30 &&
-                              image <= 150 * 1024 && static_cast<double>(image) * (1 << log2P) <= 32.0 * 1024 * 1024 &&
-                              static_cast<double>(range) <= 8.0 * std::max(est_groups, 4096.0);
-        int64_t const PD = int64_t{1} << log2P;
+        dense_ok = dense_ok && dm.range <= (uint64_t{1} << bits) && bits <= 30 && bits - log2P >= 6 && log2P <= 20 && image <= 150 * 1024 &&
+                   static_cast<double>(dm.range) <= 8.0 * std::max(est_groups, 4096.0) &&
+                   // (the carried table images of a chunked single-level call travel to LDS and back once per chunk)
+                   (two_level || static_cast<double>(image) * (1 << log2P) <= 32.0 * 1024 * 1024 || env_i64("CUDF_AMD_GB_CHUNKED", 0) == 0);
+        int64_t const PD = int64_t{1} << log2P1, P2D = int64_t{1} << log2P2;
         // scatter workgroups: one of 1024 threads per CU (128-byte granules up to 512 partitions), or - CUDF_AMD_GB_SCATTER_BLOCK=512 -
-        // two of 512 threads per CU with 64-byte granules, so that one's LDS phases overlap the other's memory phases
+        // two of 512 threads per CU with 64-byte granules (measured slower: profiles/r2_mall_pipeline.txt)
         int const SB     = env_i64("CUDF_AMD_GB_SCATTER_BLOCK", 1024) == 512 ? 512 : 1024;
         int const GD     = static_cast<int>(env_i64("CUDF_AMD_GB_WC_G", (PD > 512 || SB == 512) ? 4 : 8));
-        if (dense_ok && partition_wc_fits(RU, static_cast<int>(PD), GD, SB)) {
-          _last_path = hash_path::DENSE_DIRECT;
-          dense_map dm{};
-          dm.lo    = lo;
-          dm.range = range;
-          dm.mult  = 0x9E3779B1u;  // odd: index -> (index * mult) mod 2^bits is a bijection
-          uint32_t inv = dm.mult;  // Newton: inv = mult^-1 mod 2^32
+        if (dense_ok && partition_wc_fits(2, static_cast<int>(PD), GD, SB) && (!two_level || partition_wc_fits(2, static_cast<int>(P2D), P2D > 512 ? 4 : 8))) {
+          _last_path  = hash_path::DENSE_DIRECT;
+          dm.mult     = 0x9E3779B1u;  // odd: index -> (index * mult) mod 2^bits is a bijection
+          uint32_t inv = dm.mult;     // Newton: inv = mult^-1 mod 2^32
           for (int it = 0; it < 5; ++it) inv *= 2u - dm.mult * inv;
           dm.mult_inv = inv;
           dm.bits     = bits;
           dm.log2P    = log2P;
-          // chunks: a multiple of one tile per workgroup; the ring of a chunk's regions stays in the Infinity Cache
+          int const DPU = (dm.nkeys > 0 ? p.KU : 1) + p.NACC;  // units of a dumped partial record
+          // chunks (single level, opt-in): a multiple of one tile per workgroup; the ring of a chunk's regions stays in the
+          // Infinity Cache. Measured: no gain (profiles/r2_mall_pipeline.txt); CUDF_AMD_GB_CHUNKED=1 keeps it testable.
           int64_t const S        = 256 * (1024 / SB), tile_rows = 5 * SB;
           int64_t const quantum  = S * tile_rows;
           int64_t const want     = std::max<int64_t>(quantum, env_i64("CUDF_AMD_GB_CHUNK_ROWS", 8 * quantum));
-          int64_t const nchunks  = env_i64("CUDF_AMD_GB_CHUNKED", 0) != 0 ? std::max<int64_t>(1, (n + want - 1) / want) : 1;
+          int64_t const nchunks  = (!two_level && env_i64("CUDF_AMD_GB_CHUNKED", 0) != 0) ? std::max<int64_t>(1, (n + want - 1) / want) : 1;
           int64_t const C        = ((n + nchunks - 1) / nchunks + quantum - 1) / quantum * quantum;
           double const cell_mean = static_cast<double>(std::min(C, n)) / static_cast<double>(S * PD);
           double const keys_per_p = std::max(1.0, 0.5 * est_groups / static_cast<double>(PD));
@@ -863,7 +916,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           pa.geom.nseg     = 1;
           pa.geom.slices   = static_cast<int32_t>(S);
           pa.geom.P        = static_cast<int32_t>(PD);
-          pa.geom.shift    = 0;
+          pa.geom.shift    = bits - log2P1;  // level 1: the top log2P1 bits of the scrambled index
           pa.geom.block    = SB;
           pa.geom.tile_rows = static_cast<int32_t>(tile_rows);
           pa.from_columns  = 1;
@@ -872,7 +925,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           pa.region_cap    = capR;
           pa.region_count  = sc.alloc<int32_t>(static_cast<size_t>(S * PD));
           pa.overflow      = d_overflow;
-          pa.out_records   = sc.alloc<uint64_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR) * RU);
+          pa.out_records   = sc.alloc<uint64_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR) * 2);
           pa.wc_granule    = GD;
           pa.cyclic_tiles  = 1;
           pa.use_dense     = 1;
@@ -886,12 +939,52 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           da.region_count = pa.region_count;
           da.region_cap   = capR;
           da.slices       = static_cast<int32_t>(S);
+          int64_t cap2    = 0;
+          part_args pb{};
+          part_args* d_pb = nullptr;
+          if (two_level) {
+            // level 2: work item (g, s) reads level-1 partition g as the strided list of its regions s, s + slices2, ... and appends
+            // to the regions of the global partitions g * P2 + d (the next log2P2 bits); the aggregate walks those
+            int64_t const slices2 = std::max<int64_t>(1, 512 / PD);
+            double const mean2    = static_cast<double>(n) / static_cast<double>(PD * slices2 * P2D);
+            double const sigma2   = std::sqrt(1.0 / std::max(1.0, 0.5 * est_groups / static_cast<double>(PD * P2D)) + 1.0 / std::max(1.0, mean2));
+            cap2                  = (static_cast<int64_t>(mean2 * (1.0 + 6.0 * std::min(sigma2, 1.0)) + 16.0) + 7) / 8 * 8;
+            pb.plan            = p;
+            pb.geom.nseg       = static_cast<int32_t>(PD);
+            pb.geom.slices     = static_cast<int32_t>(slices2);
+            pb.geom.P          = static_cast<int32_t>(P2D);
+            pb.geom.shift      = bits - log2P;  // the log2P2 bits below the level-1 digit
+            pb.geom.block      = 1024;
+            pb.geom.tile_rows  = 5 * 1024;
+            pb.from_columns    = 0;
+            pb.in_records      = pa.out_records;
+            pb.from_regions    = 1;
+            pb.in_region_count = pa.region_count;
+            pb.in_region_cap   = capR;
+            pb.in_slices       = static_cast<int32_t>(S);
+            pb.optimistic      = 1;
+            pb.region_cap      = cap2;
+            size_t const nreg2 = static_cast<size_t>(PD * P2D * slices2);
+            pb.region_count    = sc.alloc<int32_t>(nreg2);
+            pb.overflow        = d_overflow;
+            pb.out_records     = sc.alloc<uint64_t>(nreg2 * static_cast<size_t>(cap2) * 2);
+            pb.wc_granule      = P2D > 512 ? 4 : 8;
+            pb.use_dense       = 1;
+            pb.dense           = dm;
+            d_pb               = sc.alloc<part_args>(1);
+            store_args(pb, d_pb, s);
+            da.records      = pb.out_records;
+            da.region_count = pb.region_count;
+            da.region_cap   = cap2;
+            da.slices       = static_cast<int32_t>(slices2);
+          }
           da.slots        = slots;
           da.image_bytes  = static_cast<int32_t>(image);
           da.occ_acc      = dense_occ_acc(p);
-          da.tables       = sc.alloc<uint64_t>(static_cast<size_t>(PD) * image / 8);
-          nitems          = static_cast<int32_t>(PD);
-          partial         = sc.alloc<uint64_t>(static_cast<size_t>(PD) * slots * PU);
+          da.KU           = dm.nkeys > 0 ? p.KU : 1;
+          nitems          = static_cast<int32_t>(int64_t{1} << log2P);
+          da.tables       = sc.alloc<uint64_t>(nchunks > 1 ? static_cast<size_t>(nitems) * image / 8 : 2);
+          partial         = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * slots * DPU);
           d_count         = sc.alloc<int32_t>(nitems);
           da.out_records  = partial;
           da.out_count    = d_count;
@@ -902,14 +995,15 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           store_args(da, d_da, s);
           for (int64_t c = 0; c < nchunks; ++c) {
             chunk_range const cr{c * C, std::min(n, (c + 1) * C)};
-            launch_partition_scatter(pa, d_pa, s, cr);
+            launch_partition_scatter(pa, d_pa, s, nchunks > 1 ? cr : chunk_range{0, 0});
+            if (two_level) launch_partition_scatter(pb, d_pb, s);
             launch_aggregate_dense(da, d_da, c == 0, c == nchunks - 1, s);
           }
           final_cap          = slots;
           int32_t const h_ov = overflow_and_counts();
           if (env_i64("CUDF_AMD_DEBUG", 0))
-            fprintf(stderr, "[cudf_amd] dense keys: lo=%lld range=%llu bits=%d P=%ld slots=%d image=%zu B chunks=%ld x %ld rows capR=%ld overflow=%d\n",
-                    (long long)lo, (unsigned long long)range, bits, (long)PD, slots, image, (long)nchunks, (long)C, (long)capR, h_ov);
+            fprintf(stderr, "[cudf_amd] dense keys: nkeys=%d lo=%lld range=%llu bits=%d P=%ld x %ld slots=%d image=%zu B chunks=%ld capR=%ld cap2=%ld overflow=%d\n",
+                    dm.nkeys, (long long)dm.lo, (unsigned long long)dm.range, bits, (long)PD, (long)P2D, slots, image, (long)nchunks, (long)capR, (long)cap2, h_ov);
           if (h_ov == 0) break;
           // a region overflowed (skewed or clustered keys) or a key lay outside the sampled range: redo by hash
           allow_dense = false;

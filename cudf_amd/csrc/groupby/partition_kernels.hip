@@ -386,6 +386,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter(part_args const* __r
 constexpr int WC_SRC_SIMPLE = 0;   // plain 8-byte columns
 constexpr int WC_SRC_COLUMNS = 1;  // any fixed-width columns, nulls (records built column-at-a-time)
 constexpr int WC_SRC_RECORDS = 2;  // records: one contiguous range, or a strided list of level-1 regions
+constexpr int WC_SRC_DENSE_COLS = 3;  // composite dense keys: 1-4 integer key columns + one value column -> {index | validity, value}
 // HOT: heavy-hitter keys (part_args::hot_*) are aggregated in a small LDS table and never scattered.
 // DENSE: the partition digit comes from the dense key map (part_args::dense) instead of the key hash.
 // `chunk`: rows [begin, end) of the input columns (end == 0: all rows) - the chunked pipeline partitions one chunk per launch.
@@ -397,6 +398,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   plan_dev const& p  = a.plan;
   int const shift = a.geom.shift, B = blockDim.x;
   static_assert(!HOT || (UT == 2 && SRC == WC_SRC_SIMPLE), "heavy hitters: plain 16-byte records");
+  static_assert(SRC != WC_SRC_DENSE_COLS || (UT == 2 && DENSE), "composite dense keys: 16-byte records");
   constexpr uint64_t HOT_EMPTY = ~uint64_t{0};
   uint64_t* hkeys = reinterpret_cast<uint64_t*>(lds_raw + (HOT ? a.hot_lds_offset : 0));  // [HOT_SLOTS]
   uint64_t* hsum  = hkeys + HOT_SLOTS;
@@ -453,7 +455,90 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
     for (int u = 0; u < UT; ++u) sbase[u] = p.simple_base[u];
   }
   auto load_tile = [&](int64_t tile, uint64_t (&rec)[RPT][UT], bool (&keep)[RPT]) {
-    if constexpr (SRC == WC_SRC_COLUMNS) {
+    if constexpr (SRC == WC_SRC_DENSE_COLS) {
+      // composite dense keys: every key column contributes a digit (value - lo) to the row's mixed-radix index; a row with a
+      // NULL key is dropped (null_policy::EXCLUDE); a value outside its sampled range voids the attempt (overflow bit 2)
+      int64_t row[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        row[k]  = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+        keep[k] = row[k] < sr.end;
+      }
+      bool inrange[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) inrange[k] = keep[k];
+      // the loads of the first two key columns, their validity words, the value and its validity go out before anything is
+      // computed; a third and fourth key column are read one after the other (four columns' worth of rows in registers spilled)
+      // (tried: one wave-wide load of all validity words + cross-lane reads instead of a load per row and mask - 16.0 vs 13.1 ms)
+      constexpr int WIDE = 2;
+      uint64_t raw[WIDE][RPT];
+      uint32_t kmw[WIDE][RPT];
+      int const nk = a.dense.nkeys;
+#pragma unroll
+      for (int c = 0; c < WIDE; ++c) {
+        if (c >= nk) break;
+        device_column const col = p.cols[a.dense.key[c].col];
+        batch_load_bits<RPT>(col, row, inrange, raw[c]);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          kmw[c][k] = 0xffffffffu;
+          if (col.mask != nullptr && inrange[k]) kmw[c][k] = gload(col.mask + ((static_cast<int64_t>(col.offset) + row[k]) >> 5));
+        }
+      }
+      device_column const vcol = p.cols[a.dense.value_col];
+      uint64_t vraw[RPT];
+      uint32_t vmw[RPT];
+      batch_load_bits<RPT>(vcol, row, inrange, vraw);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        vmw[k] = 0xffffffffu;
+        if (vcol.mask != nullptr && inrange[k]) vmw[k] = gload(vcol.mask + ((static_cast<int64_t>(vcol.offset) + row[k]) >> 5));
+      }
+      bool bad = false;
+      uint32_t idx32[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) idx32[k] = 0;
+      auto add_digit = [&](dense_key const& dk, int moff, uint64_t rawv, uint32_t mword, int k) {
+        if (!((mword >> ((moff + row[k]) & 31)) & 1u)) keep[k] = false;  // NULL key: the row is dropped (EXCLUDE)
+        int const sh     = 64 - 8 * dk.width;
+        uint64_t const v = dk.is_signed ? static_cast<uint64_t>(static_cast<int64_t>(rawv << sh) >> sh) : rawv;
+        uint64_t dig     = v - dk.lo;
+        if (dig >= dk.range) {
+          bad = bad || keep[k];
+          dig = 0;
+        }
+        idx32[k] += static_cast<uint32_t>(dig) * dk.stride;  // (< 2^30: 32-bit arithmetic)
+      };
+#pragma unroll
+      for (int c = 0; c < WIDE; ++c) {
+        if (c >= nk) break;
+        dense_key const dk = a.dense.key[c];
+        int const moff     = p.cols[dk.col].offset;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+          if (inrange[k]) add_digit(dk, moff, raw[c][k], kmw[c][k], k);
+      }
+      for (int c = WIDE; c < nk; ++c) {
+        dense_key const dk      = a.dense.key[c];
+        device_column const col = p.cols[dk.col];
+        uint64_t r2[RPT];
+        batch_load_bits<RPT>(col, row, inrange, r2);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          if (!inrange[k]) continue;
+          uint32_t const mw = col.mask != nullptr ? gload(col.mask + ((static_cast<int64_t>(col.offset) + row[k]) >> 5)) : 0xffffffffu;
+          add_digit(dk, col.offset, r2[k], mw, k);
+        }
+      }
+      if (bad) atomicOr(a.overflow, 4);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        if (!inrange[k]) continue;
+        uint64_t const valid = (vmw[k] >> ((vcol.offset + row[k]) & 31)) & 1u;
+        rec[k][0] = static_cast<uint64_t>(idx32[k]) | (valid << 32);
+        rec[k][1] = to_acc_bits(vraw[k], vcol.cls, vcol.width);
+      }
+    } else if constexpr (SRC == WC_SRC_COLUMNS) {
       int64_t row[RPT];
       uint32_t vv[RPT];
 #pragma unroll
@@ -505,15 +590,22 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   };
   [[maybe_unused]] uint64_t const dense_lo = a.dense.lo, dense_range = a.dense.range;
   [[maybe_unused]] uint32_t const dense_mult = a.dense.mult, dense_mask = (1u << a.dense.bits) - 1u;
-  [[maybe_unused]] int const dense_shift = a.dense.bits - a.dense.log2P;
+  // dense digit: bits [shift, shift + log2 P) of the scrambled index (level 1: its top bits; level 2: the next ones)
+  [[maybe_unused]] int const dense_shift = shift;
+  [[maybe_unused]] bool const dense_rec32 = a.dense.nkeys > 0 || SRC == WC_SRC_RECORDS;  // the record holds the index itself
   auto digit_of = [&](uint64_t const (&rec)[UT]) {
     if constexpr (DENSE) {
-      uint64_t idx = rec[0] - dense_lo;
-      if (idx >= dense_range) {  // the sampled key range was wrong: this call is void (redone by hash)
-        atomicOr(a.overflow, 4);
-        idx = 0;
+      uint64_t idx;
+      if (dense_rec32) {
+        idx = rec[0] & 0xffffffffull;
+      } else {
+        idx = rec[0] - dense_lo;
+        if (idx >= dense_range) {  // the sampled key range was wrong: this call is void (redone by hash)
+          atomicOr(a.overflow, 4);
+          idx = 0;
+        }
       }
-      return ((static_cast<uint32_t>(idx) * dense_mult) & dense_mask) >> dense_shift;
+      return (((static_cast<uint32_t>(idx) * dense_mult) & dense_mask) >> dense_shift) & pmask;
     }
     uint64_t h = 0x9e3779b97f4a7c15ull;
 #pragma unroll
@@ -535,7 +627,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   g.region_count = a.region_count + region0;
   g.overflow     = a.overflow;
   g.out          = a.out_records + region0 * a.region_cap * UT;
-  cudf::detail::wc_scatter_slice<RPT, G, UT, SRC != WC_SRC_COLUMNS>(lds_raw, g, load_tile, digit_of);
+  cudf::detail::wc_scatter_slice<RPT, G, UT, SRC != WC_SRC_COLUMNS && SRC != WC_SRC_DENSE_COLS>(lds_raw, g, load_tile, digit_of);
   if constexpr (HOT) {  // this workgroup's heavy-hitter partials: [key | accumulators in plan order]
     __syncthreads();
     int const PU   = p.KU + p.NACC;
@@ -632,7 +724,7 @@ static void launch_scatter_wc_src(part_args const& a, part_args const* d_args, h
     allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SRC, HOT, DENSE>));
     attr_set = true;
   }
-  cudf::detail::prof::scope prof_{"partition_scatter", stream};
+  cudf::detail::prof::scope prof_{a.from_columns ? "partition_scatter" : "partition_scatter_level2", stream};
   hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SRC, HOT, DENSE>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args, chunk);
   CUDF_HIP_TRY(hipGetLastError());
 }
@@ -640,6 +732,10 @@ static void launch_scatter_wc_src(part_args const& a, part_args const* d_args, h
 template <int UT, int RPT, int G>
 static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hipStream_t stream, chunk_range chunk)
 {
+  if constexpr (UT == 2) {
+    if (!a.from_columns && a.use_dense) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_RECORDS, false, true>(a, d_args, stream, chunk);
+    if (a.from_columns && a.use_dense && a.dense.nkeys > 0) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_DENSE_COLS, false, true>(a, d_args, stream, chunk);
+  }
   if (!a.from_columns) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_RECORDS>(a, d_args, stream, chunk);
   if constexpr (UT == 2) {
     if (a.plan.simple && a.use_dense) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_SIMPLE, false, true>(a, d_args, stream, chunk);
@@ -652,9 +748,11 @@ static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hip
 void launch_partition_scatter(part_args const& a, part_args const* d_args, hipStream_t stream, chunk_range chunk)
 {
   CUDF_EXPECTS(chunk.end == 0 || (a.wc_granule != 0 && a.from_columns && a.cyclic_tiles), "chunked scatter: write-combining kernel over the input columns only");
-  CUDF_EXPECTS(!a.use_dense || (a.wc_granule != 0 && a.plan.simple && a.plan.KU + a.plan.NPAY == 2), "dense keys: plain 16-byte records only");
+  CUDF_EXPECTS(!a.use_dense || (a.wc_granule != 0 && (a.dense.nkeys > 0 || !a.from_columns || (a.plan.simple && a.plan.KU + a.plan.NPAY == 2))),
+               "dense keys: 16-byte records only");
   CUDF_EXPECTS(a.geom.P <= 2 * a.geom.block, "partition fan-out exceeds 2x the block size");
-  int const U       = a.plan.KU + a.plan.NPAY;
+  // (composite dense keys and every later level of a dense partition move 16-byte {index, value} records whatever the plan's units)
+  int const U       = (a.use_dense && (a.dense.nkeys > 0 || !a.from_columns)) ? 2 : a.plan.KU + a.plan.NPAY;
   bool const simple = a.plan.simple && a.from_columns;
   if (a.wc_granule != 0) {
     CUDF_EXPECTS(a.optimistic && (a.geom.block == 1024 || a.geom.block == 512) && partition_wc_fits(U, a.geom.P, a.wc_granule, a.geom.block),

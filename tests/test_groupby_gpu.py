@@ -321,6 +321,37 @@ def test_dense_keys_chunked_and_fallbacks(G, oracle, monkeypatch):
     assert G.last_path.name == "PARTITIONED_LDS"
 
 
+@pytest.mark.parametrize("two_level", [False, True])
+@pytest.mark.parametrize("shape", ["c4", "narrow", "three_keys"])
+def test_dense_composite_keys(G, oracle, monkeypatch, shape, two_level):
+    """Composite dense keys: 1-4 integer key columns of any width (rows with a NULL key dropped under EXCLUDE), one value
+    column of any type with nulls; the record is {mixed-radix index | validity, value}. One partition level, and two levels
+    forced (CUDF_AMD_GB_DENSE_LOG2P=11: level 1 on the top 6 bits, level 2 on the next 5). Same call by hash agrees."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(83)
+    n = 4_300_000
+    if shape == "c4":  # BASELINE config 4 in small: (int64, int32 with nulls) keys, float64 value with nulls, MEAN + MIN + MAX
+        keys = [HostColumn(rng.integers(0, 700, n, dtype=np.int64), None, "int64"),
+                HostColumn(rng.integers(-50, 50, n).astype(np.int32), rng.random(n) > 0.1, "int32")]
+        vals, kinds = HostColumn(rng.random(n), rng.random(n) > 0.1, "float64"), ["mean", "min", "max"]
+    elif shape == "narrow":
+        keys = [HostColumn(rng.integers(0, 200, n).astype(np.uint8), None, "uint8"),
+                HostColumn(rng.integers(-300, 300, n).astype(np.int16), None, "int16")]
+        vals, kinds = HostColumn(rng.integers(-100, 100, n).astype(np.int32), rng.random(n) > 0.3, "int32"), ["sum", "count_valid", "count_all", "max"]
+    else:
+        keys = [HostColumn(rng.integers(10**12, 10**12 + 400, n, dtype=np.int64), None, "int64"),
+                HostColumn(rng.integers(0, 30, n).astype(np.int8), rng.random(n) > 0.05, "int8"),
+                HostColumn(rng.integers(0, 25, n).astype(np.uint32), None, "uint32")]
+        vals, kinds = HostColumn(rng.random(n).astype(np.float32), None, "float32"), ["sum", "mean", "min"]
+    if two_level:
+        monkeypatch.setenv("CUDF_AMD_GB_DENSE_LOG2P", "11")
+    _check_against_oracle(G, oracle, keys, [(vals, kinds)], expect_path="DENSE_DIRECT")
+    if not two_level:
+        monkeypatch.setenv("CUDF_AMD_GB_DENSE", "0")
+        _check_against_oracle(G, oracle, keys, [(vals, kinds)])
+        assert G.last_path.name != "DENSE_DIRECT"
+
+
 def test_two_level_partition_forced(G, oracle, monkeypatch):
     """Forces the two-level radix partition (C4's regime) at a size the oracle can check."""
     rng = np.random.default_rng(13)
