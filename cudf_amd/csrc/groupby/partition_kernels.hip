@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
   g.region_count = a.region_count + region0;
   g.overflow     = a.overflow;
   g.out          = a.out_records + region0 * a.region_cap * UT;
-  cudf::detail::wc_scatter_slice<RPT, G, UT, SRC != WC_SRC_COLUMNS && SRC != WC_SRC_DENSE_COLS>(lds_raw, g, load_tile, digit_of);
+  cudf::detail::wc_scatter_slice<RPT, G, UT, SRC != WC_SRC_COLUMNS>(lds_raw, g, load_tile, digit_of);
   if constexpr (HOT) {  // this workgroup's heavy-hitter partials: [key | accumulators in plan order]
     __syncthreads();
     int const PU   = p.KU + p.NACC;
@@ -734,7 +734,8 @@ static void launch_scatter_wc_t(part_args const& a, part_args const* d_args, hip
 {
   if constexpr (UT == 2) {
     if (!a.from_columns && a.use_dense) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_RECORDS, false, true>(a, d_args, stream, chunk);
-    if (a.from_columns && a.use_dense && a.dense.nkeys > 0) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_DENSE_COLS, false, true>(a, d_args, stream, chunk);
+    // (4 rows per thread: with 5 the column loader spilled 21 registers to scratch)
+    if (a.from_columns && a.use_dense && a.dense.nkeys > 0) return launch_scatter_wc_src<UT, 4, G, WC_SRC_DENSE_COLS, false, true>(a, d_args, stream, chunk);
   }
   if (!a.from_columns) return launch_scatter_wc_src<UT, RPT, G, WC_SRC_RECORDS>(a, d_args, stream, chunk);
   if constexpr (UT == 2) {
