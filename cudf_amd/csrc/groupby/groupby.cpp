@@ -507,6 +507,20 @@ bool hot_plan_ok(plan_dev const& p)
   return true;
 }
 
+// Page-locked host staging for the call's small read-backs (overflow flag, group counts, null counts): a hipMemcpyAsync into
+// pageable memory blocks the host until the copy is done, so every read-back was a stream synchronisation of its own.
+int32_t* pinned_ints(std::size_t count)
+{
+  thread_local int32_t* buf   = nullptr;
+  thread_local std::size_t cap = 0;
+  if (count > cap) {
+    if (buf != nullptr) (void)hipHostFree(buf);
+    cap = std::max<std::size_t>(count, 4096);
+    CUDF_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&buf), cap * sizeof(int32_t), hipHostMallocDefault));
+  }
+  return buf;
+}
+
 struct scratch {  // stream-ordered temporaries from the current device resource
   hipStream_t stream;
   rmm::device_async_resource_ref mr;
@@ -614,7 +628,12 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   int64_t final_cap  = 0;        // records per work item in `partial` (0: ag.cap)
   // ---- distinct-count estimate on a strided sample (skipped when n already fits one table)
   double est_groups = static_cast<double>(n);
-  if (n > ag.fill_limit) {
+  // Small inputs skip the estimate (three memsets, three kernels and a stream synchronisation: about a third of a 10K-row call):
+  // they are planned for one table per 16K-row chunk, and a table that overflows sends the call through escalate() - which
+  // counts the keys over all rows - like any other misjudged cardinality.
+  bool const skip_estimate = n < env_i64("CUDF_AMD_GB_ESTIMATE_MIN_ROWS", 1 << 16);
+  if (skip_estimate && n > ag.fill_limit) est_groups = static_cast<double>(ag.fill_limit) / 1.3 - 1.0;
+  if (n > ag.fill_limit && !skip_estimate) {
     // 1M sampled rows for big inputs; small inputs sample 1/16 of their rows (at least 64K): the estimate only picks the
     // strategy, and a 1M-row sample costs more than the aggregation of a 1M-row input
     int64_t const sample = std::min<int64_t>(n, std::clamp<int64_t>(n / 16, int64_t{1} << 16, int64_t{1} << 20));
@@ -699,12 +718,12 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   // one stream synchronisation returns both the overflow flag and the per-item group counts of an attempt
   std::vector<int32_t> h_count;
   auto overflow_and_counts = [&]() -> int32_t {
-    int32_t h_ov = 0;
-    h_count.assign(static_cast<std::size_t>(nitems), 0);
-    CUDF_HIP_TRY(hipMemcpyAsync(&h_ov, d_overflow, 4, hipMemcpyDeviceToHost, s));
-    CUDF_HIP_TRY(hipMemcpyAsync(h_count.data(), d_count, sizeof(int32_t) * static_cast<std::size_t>(nitems), hipMemcpyDeviceToHost, s));
+    int32_t* const pin = pinned_ints(static_cast<std::size_t>(nitems) + 1);
+    CUDF_HIP_TRY(hipMemcpyAsync(pin, d_overflow, 4, hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(pin + 1, d_count, sizeof(int32_t) * static_cast<std::size_t>(nitems), hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipStreamSynchronize(s));
-    return h_ov;
+    h_count.assign(pin + 1, pin + 1 + nitems);
+    return pin[0];
   };
   // Heavy hitters stay in the (first-level) scatter workgroups: `pa` gets the key list and the per-workgroup partial
   // buffers; merge_hot() folds those partials into one more work item behind the tables' items.
@@ -1379,8 +1398,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     res_cols.push_back(std::move(col));
   }
   launch_finalize(fa, sc.alloc<finalize_args>(1), partial, final_cap > 0 ? final_cap : ag.cap, d_prefix, nitems, G, s);
-  std::vector<int32_t> h_nulls(MAX_OUT, 0);
-  CUDF_HIP_TRY(hipMemcpyAsync(h_nulls.data(), d_nulls, sizeof(int32_t) * MAX_OUT, hipMemcpyDeviceToHost, s));
+  int32_t* const h_nulls = pinned_ints(MAX_OUT);
+  CUDF_HIP_TRY(hipMemcpyAsync(h_nulls, d_nulls, sizeof(int32_t) * MAX_OUT, hipMemcpyDeviceToHost, s));
   CUDF_HIP_TRY(hipStreamSynchronize(s));
   int oc = 0;
   for (auto& k : key_cols) k->set_null_count(h_nulls[oc++]);
