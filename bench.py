@@ -30,6 +30,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
 BYTES_PER_ROW = 16     # algorithmic bytes per row of C2: 8 B key + 8 B value
 
 
+def _sources_sha256():
+    """Same hash as bench_micro/summarize_profiles.py: the sources the library is built from."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "cudf_amd", "csrc")
+    for d, _, fs in sorted(os.walk(base)):
+        if os.sep + "build" in d:
+            continue
+        for f in sorted(fs):
+            if f.endswith((".hip", ".cpp", ".hpp", ".inl", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,16 +273,19 @@ def main():
             # merge input: charge all of a step's launches to the step's algorithmic bytes (conservative)
             avg_ms = total_ms / max(launches if launches <= args.steps else args.steps, 1)
             achieved = BYTES_PER_ROW * n / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            try:  # PMC traffic of this kernel at this workload, collected with rocprofv3 (see the file's "how")
-                with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                    pmc = json.load(f)["kernels"]
-                if name in pmc and n == 1_000_000_000 and groups == 1_000_000:
-                    traffic = pmc[name]["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+            traffic, traffic_note = None, None
+            try:  # PMC traffic of this kernel at this workload, collected with rocprofv3 (see the file's "how"): quoted only
+                # if it was taken from the source tree this library is built from - otherwise it is stale and says so
+                with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
+                    doc = json.load(f)
+                if doc.get("sources_sha256") != _sources_sha256():
+                    traffic_note = "profiles/r2_pmc_traffic.json was collected from a different source tree: not quoted"
+                elif name in doc["kernels"] and n == 1_000_000_000 and groups == 1_000_000:
+                    traffic = doc["kernels"][name]["hbm_bytes_per_launch"]
+            except Exception as e:  # noqa: BLE001
+                traffic_note = f"no PMC file: {e!r}"
             roof = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": BYTES_PER_ROW * n,
                     "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items())},
                     "whole_call_frac": BYTES_PER_ROW * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -14,3 +14,5 @@ echo "== stats" && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-f
 echo "== fetch" && timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1 &&
 echo "== write" && timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1 &&
 python3 $ROOT/bench_micro/summarize_profiles.py $OUT
+# C3 / C4 kernel stats of the same build
+for c in c3 c4; do timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o stats -- python3 $ROOT/bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline > $OUT/stats_$c.log 2>&1; done

@@ -3,12 +3,28 @@
 pmc_traffic.json (HBM bytes per launch of the groupby kernels, gfx950 corrections applied)."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sources_sha256():
+    """Hash of the kernel / host sources the library is built from: bench.py quotes the PMC traffic only for a matching tree."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "cudf_amd", "csrc")
+    for d, _, fs in sorted(os.walk(base)):
+        if os.sep + "build" in d:
+            continue
+        for f in sorted(fs):
+            if f.endswith((".hip", ".cpp", ".hpp", ".inl", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def find(sub, pat):
@@ -64,6 +80,7 @@ doc = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in
               "--steps 3 --warmup 1 --no-cpu-baseline` (C2, 1B rows), bench_micro/collect_profiles.sh; per-launch averages. "
               "Units: counter KB (x1024 B). gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests "
               "at 64 B, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is taken as is.",
+       "sources_sha256": sources_sha256(),
        "kernels": res}
 json.dump(doc, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e9, 2) for k, v in res.items()}))

@@ -309,6 +309,7 @@ struct pool_memory_resource::impl {
     uint64_t tick;         // when it was returned (eviction order)
   };
   uint64_t clock{0};
+  int device{-1};  // the HIP device of the first allocation: cached blocks are only valid there
   std::mutex mu;
   std::map<std::size_t, std::vector<block>> free_lists;  // rounded size -> blocks
   std::unordered_map<void*, block> live;
@@ -345,6 +346,17 @@ void pool_memory_resource::trim()
 void* pool_memory_resource::do_allocate(std::size_t bytes, hipStream_t stream)
 {
   std::size_t const sz = round_pool_size(bytes);
+  {
+    // One pool serves one device (one process per GPU): a block cached on another device must never be handed out.
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      std::lock_guard<std::mutex> g{_impl->mu};
+      if (_impl->device < 0) _impl->device = dev;
+      if (_impl->device != dev)
+        throw cudf::logic_error("rmm::mr::pool_memory_resource: the pool belongs to HIP device " + std::to_string(_impl->device) +
+                                ", the calling thread's current device is " + std::to_string(dev) + " (one process per GPU)");
+    }
+  }
   {
     std::lock_guard<std::mutex> g{_impl->mu};
     auto it = _impl->free_lists.find(sz);
