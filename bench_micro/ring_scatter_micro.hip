@@ -447,7 +447,7 @@ int main(int argc, char** argv)
     }
     CK(hipMemset(ov, 0, 4));
   };
-  if (dense && P <= 128) {
+  if (dense && P <= 256) {
     u64* oval; uint32_t* oslot;
     CK(hipMalloc(&oval, static_cast<size_t>(S) * P * cap * 8)); CK(hipMalloc(&oslot, static_cast<size_t>(S) * P * cap * 4));
     auto run_soa = [&](auto kern, int capl, const char* name) {
@@ -483,10 +483,16 @@ int main(int argc, char** argv)
       }
       CK(hipMemset(ov, 0, 4));
     };
-    run_soa(k_scatter_ring_soa<6, 2, 2>, 6, "SoA 12B G=16 CAP=64 D=2 RPT=2");
-    run_soa(k_scatter_ring_soa<6, 3, 2>, 6, "SoA 12B G=16 CAP=64 D=3 RPT=2");
-    run_soa(k_scatter_ring_soa<6, 2, 3>, 6, "SoA 12B G=16 CAP=64 D=2 RPT=3");
-    run_soa(k_scatter_ring_soa<6, 2, 4>, 6, "SoA 12B G=16 CAP=64 D=2 RPT=4");
+    if (P <= 128) {
+      run_soa(k_scatter_ring_soa<6, 2, 2>, 6, "SoA 12B G=16 CAP=64 D=2 RPT=2");
+      run_soa(k_scatter_ring_soa<6, 3, 2>, 6, "SoA 12B G=16 CAP=64 D=3 RPT=2");
+      run_soa(k_scatter_ring_soa<6, 2, 3>, 6, "SoA 12B G=16 CAP=64 D=2 RPT=3");
+      run_soa(k_scatter_ring_soa<6, 2, 4>, 6, "SoA 12B G=16 CAP=64 D=2 RPT=4");
+    } else {
+      run_soa(k_scatter_ring_soa<5, 2, 1>, 5, "SoA 12B G=16 CAP=32 D=2 RPT=1");
+      run_soa(k_scatter_ring_soa<5, 2, 2>, 5, "SoA 12B G=16 CAP=32 D=2 RPT=2");
+      run_soa(k_scatter_ring_soa<5, 4, 1>, 5, "SoA 12B G=16 CAP=32 D=4 RPT=1");
+    }
   }
   if (dense) {
     if (P <= 128) run(k_scatter_ring<8, 6, 2, true, 4>, 6, "ring G=8 CAP=64 D=2 RPT=4 dense");
