@@ -138,24 +138,53 @@ __device__ __forceinline__ int64_t sample_row(int64_t i, int64_t nrows, int64_t 
   uint64_t const span = static_cast<uint64_t>(hi - lo);
   return span <= 1 ? lo : lo + static_cast<int64_t>(mix64(static_cast<uint64_t>(i) + 0x51ed270b35a3c1ull) % span);
 }
+// RANGE: 1 / 2 = the key is one plain 8-byte integer column (signed / unsigned): the pass also takes the minimum and maximum of
+// the sampled keys - per workgroup into blk_range[2 b], [2 b + 1] (k_popcount folds them: same-address global atomics
+// serialise at ~12 ns each); a pass of its own over the same sample took as long as this one.
+template <int RANGE>
 __global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
-                                                  uint32_t* bitmap, int32_t bits_log2, uint32_t* hot_buckets)
+                                                  uint32_t* bitmap, int32_t bits_log2, uint32_t* hot_buckets, uint64_t* blk_range)
 {
   plan_dev const& p = *pp;
   int64_t const i   = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
-  if (i >= sample) return;
-  int64_t const row = sample_row(i, nrows, sample);
   uint64_t key[MAX_KU];
-  uint32_t vv;
-  if (!build_key_units<MAX_KU, false>(p, row, key, vv)) return;
-  uint64_t const h   = hash_key_units<MAX_KU>(p, key);
+  bool live = i < sample;
+  if (live) {
+    uint32_t vv;
+    live = build_key_units<MAX_KU, false>(p, sample_row(i, nrows, sample), key, vv);
+  }
+  if constexpr (RANGE != 0) {
+    using T = std::conditional_t<RANGE == 1, long long, unsigned long long>;
+    __shared__ T s_lo[4], s_hi[4];
+    T lo = live ? static_cast<T>(key[0]) : std::numeric_limits<T>::max(), hi = live ? static_cast<T>(key[0]) : std::numeric_limits<T>::lowest();
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      T const l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_lo[threadIdx.x >> 6] = lo;
+      s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) {
+        lo = s_lo[w] < lo ? s_lo[w] : lo;
+        hi = s_hi[w] > hi ? s_hi[w] : hi;
+      }
+      blk_range[2 * blockIdx.x]     = static_cast<uint64_t>(lo);
+      blk_range[2 * blockIdx.x + 1] = static_cast<uint64_t>(hi);
+    }
+  }
+  uint64_t const h   = live ? hash_key_units<MAX_KU>(p, key) : 0;
   uint32_t const bit = static_cast<uint32_t>(h >> (64 - bits_log2));
   // (same-address global atomics serialise - a constant key column made this pass take 16 ms: set a bit only if it is
   // not seen set, and add to a bucket counter once per distinct bucket of the wave)
-  if (!((gload(bitmap + (bit >> 5)) >> (bit & 31)) & 1u)) atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+  if (live && !((gload(bitmap + (bit >> 5)) >> (bit & 31)) & 1u)) atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
   // heavy-hitter search: rows per hash bucket over every fourth sampled row (scattered global atomics run at 24 G/s:
   // a quarter of the sample keeps this at ~10 us)
-  bool pending = hot_buckets != nullptr && (i & 3) == 0;
+  bool pending = live && hot_buckets != nullptr && (i & 3) == 0;
   uint32_t const bucket = static_cast<uint32_t>(h >> 48);
   for (int round = 0; round < 8; ++round) {  // wave-aggregated: one atomic per distinct bucket, for the first 8 of them
     unsigned long long const todo = __ballot(pending);
@@ -247,13 +276,67 @@ __global__ void __launch_bounds__(256) k_hot_collect(plan_dev const* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) k_popcount(uint32_t const* bitmap, int64_t nwords, uint32_t* out)
+// exclusive prefix of the per-item group counts (one workgroup: thread t sums a contiguous run of items, the runs are scanned
+// through LDS): prefix[i] = counts[0] + ... + counts[i - 1], prefix[nitems] = total. Replaces a host-side scan + upload.
+__global__ void __launch_bounds__(1024) k_count_prefix(int32_t const* __restrict__ counts, int32_t nitems, int64_t* __restrict__ prefix)
+{
+  __shared__ int64_t s_run[1024];
+  int const per = (nitems + 1023) / 1024, b = threadIdx.x * per, e = min(b + per, nitems);
+  int64_t sum = 0;
+  for (int i = b; i < e; ++i) sum += counts[i];
+  s_run[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+    int64_t const add = static_cast<int>(threadIdx.x) >= o ? s_run[threadIdx.x - o] : 0;
+    __syncthreads();
+    s_run[threadIdx.x] += add;
+    __syncthreads();
+  }
+  int64_t run = s_run[threadIdx.x] - sum;
+  for (int i = b; i < e; ++i) {
+    prefix[i] = run;
+    run += counts[i];
+  }
+  if (threadIdx.x == 1023) prefix[nitems] = s_run[1023];
+}
+
+// range_mode 1 / 2: workgroup 0 also folds the per-workgroup key ranges of k_estimate<RANGE> into range_out[0] = min, [1] = max
+__global__ void __launch_bounds__(256) k_popcount(uint32_t const* bitmap, int64_t nwords, uint32_t* out, uint64_t const* blk_range,
+                                                  int nblk, int range_mode, uint64_t* range_out)
 {
   int64_t i     = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   uint32_t acc  = 0;
   for (; i < nwords; i += static_cast<int64_t>(gridDim.x) * blockDim.x) acc += __popc(bitmap[i]);
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+  if (range_mode == 0 || blockIdx.x != 0) return;
+  __shared__ uint64_t s_lo[4], s_hi[4];
+  bool const sg = range_mode == 1;
+  auto less = [sg](uint64_t a, uint64_t b) { return sg ? static_cast<long long>(a) < static_cast<long long>(b) : a < b; };
+  uint64_t lo = sg ? static_cast<uint64_t>(INT64_MAX) : UINT64_MAX, hi = sg ? static_cast<uint64_t>(INT64_MIN) : uint64_t{0};
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+    uint64_t const l = blk_range[2 * b], h = blk_range[2 * b + 1];
+    lo = less(l, lo) ? l : lo;
+    hi = less(hi, h) ? h : hi;
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    uint64_t const l2 = __shfl_xor(static_cast<unsigned long long>(lo), o), h2 = __shfl_xor(static_cast<unsigned long long>(hi), o);
+    lo = less(l2, lo) ? l2 : lo;
+    hi = less(hi, h2) ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_lo[threadIdx.x >> 6] = lo;
+    s_hi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      lo = less(s_lo[w], lo) ? s_lo[w] : lo;
+      hi = less(hi, s_hi[w]) ? s_hi[w] : hi;
+    }
+    range_out[0] = lo;
+    range_out[1] = hi;
+  }
 }
 
 }  // namespace
@@ -293,6 +376,12 @@ void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t con
   CUDF_HIP_TRY(hipGetLastError());
 }
 
+void launch_count_prefix(int32_t const* counts, int32_t nitems, int64_t* prefix, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_count_prefix, dim3(1), dim3(1024), 0, stream, counts, nitems, prefix);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
 void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint32_t min_count, uint32_t* buckets,
                      uint64_t* table_keys, uint32_t* table_counts, hipStream_t stream)
 {
@@ -321,7 +410,8 @@ void launch_distinct_count(plan_dev const& plan, plan_dev* d_plan, int64_t nrows
 }
 
 void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
-                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream)
+                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream, int range_mode,
+                     uint64_t* blk_range, uint64_t* range_out)
 {
   if (hot_buckets != nullptr) CUDF_HIP_TRY(hipMemsetAsync(hot_buckets, 0, HOT_BUCKETS * sizeof(uint32_t), stream));
   int64_t const nwords = (int64_t{1} << bitmap_bits_log2) / 32;
@@ -330,9 +420,12 @@ void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int6
   int const block = 256;
   hipLaunchKernelGGL(k_store_args<plan_dev>, dim3(1), dim3(1), 0, stream, plan, d_plan);
   cudf::detail::prof::scope prof_{"estimate", stream};
-  hipLaunchKernelGGL(k_estimate, dim3(static_cast<unsigned>((sample + block - 1) / block)), dim3(block), 0, stream, d_plan,
-                     nrows, sample, bitmap, bitmap_bits_log2, hot_buckets);
-  hipLaunchKernelGGL(k_popcount, dim3(256), dim3(block), 0, stream, bitmap, nwords, d_bits_set);
+  unsigned const grid = static_cast<unsigned>((sample + block - 1) / block);
+  CUDF_EXPECTS(range_mode == 0 || (plan.simple && plan.KU == 1 && blk_range != nullptr && range_out != nullptr), "estimate: key range of one plain key column");
+  if (range_mode == 1) hipLaunchKernelGGL(k_estimate<1>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range);
+  else if (range_mode == 2) hipLaunchKernelGGL(k_estimate<2>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range);
+  else hipLaunchKernelGGL(k_estimate<0>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range);
+  hipLaunchKernelGGL(k_popcount, dim3(256), dim3(block), 0, stream, bitmap, nwords, d_bits_set, blk_range, static_cast<int>(grid), range_mode, range_out);
   CUDF_HIP_TRY(hipGetLastError());
 }
 

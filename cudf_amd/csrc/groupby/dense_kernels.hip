@@ -138,7 +138,31 @@ __host__ __device__ inline dense_layout make_dense_layout(plan_dev const& p, int
 // SIG: compile-time accumulator signature (device_common.hpp), 0 = descriptors read at run time.
 // One workgroup per partition; wave w walks the regions [w * g, (w + 1) * g) of its partition as ONE virtual record range
 // (a chunk's regions hold 50-400 records each: walked one by one they would be all tail).
-template <uint64_t SIG, int NACCT>
+// The key units of the partial record of dense index `idx` (what k_finalize reads): a single plain key is lo + idx; composite
+// keys are rebuilt from the mixed-radix digits of the index and placed where the plan's key units hold them.
+__device__ __forceinline__ void dense_store_key_units(dense_map const& m, int KU, uint32_t idx, uint64_t* o)
+{
+  if (m.nkeys == 0) {
+    gstore(o, m.lo + idx);
+    return;
+  }
+  uint64_t unit[MAX_KU] = {0, 0, 0, 0};
+  for (int c = 0; c < m.nkeys; ++c) {
+    dense_key const dk   = m.key[c];
+    uint64_t const digit = (idx / dk.stride) % dk.range;
+    uint64_t v           = dk.lo + digit;
+    if (dk.width < 8) v &= (uint64_t{1} << (8 * dk.width)) - 1;  // key units hold the zero-extended raw bits
+#pragma unroll
+    for (int u = 0; u < MAX_KU; ++u)
+      if (u == dk.unit) unit[u] |= dk.half == 1 ? (v << 32) : v;
+  }
+#pragma unroll
+  for (int u = 0; u < MAX_KU; ++u)
+    if (u < KU) gstore(o + u, unit[u]);
+}
+
+// SOA: 12-byte records of the ring scatter (value stream + tag stream) instead of 16-byte {key | value} records.
+template <uint64_t SIG, int NACCT, bool SOA>
 __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args const* __restrict__ ap, int first_chunk, int last_chunk)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -147,7 +171,10 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
   plan_dev const& p       = a.plan;
   constexpr bool STATIC_SIG = SIG != 0;
   int const NACC  = STATIC_SIG ? sig_n(SIG) : p.NACC;
-  int const slots = a.slots, item = blockIdx.x, B = blockDim.x;
+  // work item = (partition, share h of its regions)
+  int const nsplit = a.nsplit > 1 ? a.nsplit : 1;
+  int const slots = a.slots, item = blockIdx.x / nsplit, B = blockDim.x;
+  int const nsl = a.slices / nsplit, sl0 = (static_cast<int>(blockIdx.x) % nsplit) * nsl;
   int const occ_acc = a.occ_acc;
   int acc_op[NACCT], acc_src[NACCT], acc_vbit[NACCT];
   uint32_t acc_off[NACCT];
@@ -173,7 +200,7 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
   auto acc32 = [&](int q) { return reinterpret_cast<uint32_t*>(lds_raw + acc_off[q]); };
 
   // ---- table: identities on the first chunk, the carried image afterwards
-  uint64_t* image = a.tables + static_cast<int64_t>(item) * (a.image_bytes / 8);
+  uint64_t* image = a.tables + static_cast<int64_t>(blockIdx.x) * (a.image_bytes / 8);
   if (first_chunk) {
 #pragma unroll
     for (int q = 0; q < NACCT; ++q) {
@@ -203,12 +230,12 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
   // ---- the partition's regions as virtual record ranges. Many short regions (one per scatter workgroup): wave w walks the
   // regions [w * g, (w + 1) * g) as ONE range. A few long ones (the output of a second partition level): every wave sees all
   // of them as one range and the waves take its batches in turn.
-  bool const shared = a.slices <= 64;
-  int const g       = shared ? a.slices : (a.slices + nwaves - 1) / nwaves;  // regions in this wave's range, <= 64
+  bool const shared = nsl <= 64;
+  int const g       = shared ? nsl : (nsl + nwaves - 1) / nwaves;  // regions in this wave's range, <= 64
   int const r_base  = shared ? 0 : wave * g;
   int32_t cnt       = 0;
-  if (upstream_ok && lane < g && r_base + lane < a.slices)
-    cnt = min(max(a.region_count[static_cast<int64_t>(item) * a.slices + r_base + lane], 0), static_cast<int32_t>(a.region_cap));
+  if (upstream_ok && lane < g && r_base + lane < nsl)
+    cnt = min(max(a.region_count[static_cast<int64_t>(item) * a.slices + sl0 + r_base + lane], 0), static_cast<int32_t>(a.region_cap));
   int32_t pend = cnt;  // inclusive prefix: end of region `lane` in the virtual range
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -216,8 +243,11 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
     if (lane >= o) pend += t;
   }
   int32_t const total = __builtin_amdgcn_readlane(pend, 63);
-  u64x2 const* recs   = reinterpret_cast<u64x2 const*>(a.records) + (static_cast<int64_t>(item) * a.slices + r_base) * a.region_cap;
   int64_t const cap   = a.region_cap;
+  int64_t const rec0  = (static_cast<int64_t>(item) * a.slices + sl0 + r_base) * cap;
+  [[maybe_unused]] u64x2 const* recs       = reinterpret_cast<u64x2 const*>(a.records) + rec0;
+  [[maybe_unused]] uint64_t const* rec_val = a.rec_val + rec0;
+  [[maybe_unused]] uint32_t const* rec_tag = a.rec_tag + rec0;
   int rcur            = 0;  // wave-uniform: first region that may hold the next virtual record
   // record index (relative to `recs`) of virtual record v; v ascends from call to call
   auto locate = [&](int32_t v, bool active) -> int64_t {
@@ -235,9 +265,16 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
     return static_cast<int64_t>(reg) * cap + (v - start);
   };
   auto accumulate = [&](uint64_t key, uint64_t value) {
-    uint32_t const idx   = composite ? static_cast<uint32_t>(key) : static_cast<uint32_t>(key - lo);
-    bool const val_valid = !composite || ((key >> 32) & 1u);  // (a single plain key column comes with a plain value column)
-    uint32_t const s     = (idx * mult) & smask;
+    uint32_t s;
+    bool val_valid;
+    if constexpr (SOA) {  // key = the record's tag: slot | validity of the value << 31
+      s         = static_cast<uint32_t>(key) & smask;
+      val_valid = (static_cast<uint32_t>(key) >> 31) != 0;
+    } else {
+      uint32_t const idx = composite ? static_cast<uint32_t>(key) : static_cast<uint32_t>(key - lo);
+      val_valid          = !composite || ((key >> 32) & 1u);  // (a single plain key column comes with a plain value column)
+      s                  = (idx * mult) & smask;
+    }
 #pragma unroll
     for (int q = 0; q < NACCT; ++q) {
       if (q >= NACC) break;
@@ -255,26 +292,61 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
       if (!(occ[s >> 5] & bit)) atomicOr(&occ[s >> 5], bit);
     }
   };
+  // Batches of R x 64 records; the loads of the next batch are issued before the current one is accumulated (one 1024-thread
+  // workgroup per CU is all a 96 KiB table allows: 16 waves x one batch in flight did not cover the memory latency - C2's
+  // aggregate 2.8 ms against 2.0 ms with two workgroups per CU).
   constexpr int R = 4;
   int32_t const vstep = shared ? R * 64 * nwaves : R * 64;
-  for (int32_t v0 = shared ? wave * R * 64 : 0; v0 < total; v0 += vstep) {
-    u64x2 rec[R];
-    bool act[R];
+  // (the record indices of a batch are resolved first - locate() is loops and cross-lane reads - and its loads then go out
+  // back to back, unconditionally: a lane past the end reads record 0 of the range. With a load inside each row's branch the
+  // compiler waited for the previous load before every new one.)
+  auto load_batch = [&](int32_t v0, u64x2 (&rec)[R], bool (&act)[R]) {
+    int64_t ri[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       int32_t const v = v0 + k * 64 + lane;
       act[k]          = v < total;
+      ri[k]           = 0;
       if (v0 + k * 64 < total) {  // (wave-uniform)
-        int64_t const ri = locate(v, act[k]);
-        if (act[k]) rec[k] = gload(recs + ri);
+        int64_t const r = locate(v, act[k]);
+        ri[k]           = act[k] ? r : 0;
       }
     }
 #pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if constexpr (SOA) {
+        rec[k].y = gload(rec_val + ri[k]);
+        rec[k].x = gload(rec_tag + ri[k]);
+      } else {
+        rec[k] = gload(recs + ri[k]);
+      }
+    }
+  };
+  auto accumulate_batch = [&](u64x2 const (&rec)[R], bool const (&act)[R]) {
+#pragma unroll
     for (int k = 0; k < R; ++k)
       if (act[k]) accumulate(rec[k].x, rec[k].y);
+  };
+  {
+    u64x2 recA[R], recB[R];
+    bool actA[R], actB[R];
+    int32_t v0 = shared ? wave * R * 64 : 0;
+    if (v0 < total) {
+      load_batch(v0, recA, actA);
+      for (;;) {
+        load_batch(v0 + vstep, recB, actB);  // (nothing is loaded past `total`)
+        accumulate_batch(recA, actA);
+        v0 += vstep;
+        if (v0 >= total) break;
+        load_batch(v0 + vstep, recA, actA);
+        accumulate_batch(recB, actB);
+        v0 += vstep;
+        if (v0 >= total) break;
+      }
+    }
   }
   __syncthreads();
-  if (!last_chunk) {
+  if (!last_chunk || nsplit > 1) {  // the image is carried to the next chunk, or merged with the partition's other shares
     for (int i = threadIdx.x; i < a.image_bytes / 16; i += B)
       gstore(reinterpret_cast<u64x2*>(image) + i, reinterpret_cast<u64x2 const*>(lds_raw)[i]);
     return;
@@ -299,24 +371,7 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
     uint32_t const pos = atomicAdd(&s_dump, 1u);
     uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
     uint32_t const idx = ((hi | static_cast<uint32_t>(s)) * a.map.mult_inv) & bmask;
-    if (!composite) {
-      gstore(o, lo + idx);
-    } else {
-      // the key columns' values from the mixed-radix digits of the index, placed where the plan's key units hold them
-      uint64_t unit[MAX_KU] = {0, 0, 0, 0};
-      for (int c = 0; c < a.map.nkeys; ++c) {
-        dense_key const dk   = a.map.key[c];
-        uint64_t const digit = (idx / dk.stride) % dk.range;
-        uint64_t v           = dk.lo + digit;
-        if (dk.width < 8) v &= (uint64_t{1} << (8 * dk.width)) - 1;  // key units hold the zero-extended raw bits
-#pragma unroll
-        for (int u = 0; u < MAX_KU; ++u)
-          if (u == dk.unit) unit[u] |= dk.half == 1 ? (v << 32) : v;
-      }
-#pragma unroll
-      for (int u = 0; u < MAX_KU; ++u)
-        if (u < KU) gstore(o + u, unit[u]);
-    }
+    dense_store_key_units(a.map, KU, idx, o);
 #pragma unroll
     for (int q = 0; q < NACCT; ++q) {
       if (q >= NACC) break;
@@ -325,6 +380,52 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
   }
   __syncthreads();
   if (threadIdx.x == 0) a.out_count[item] = static_cast<int32_t>(s_dump);
+}
+
+// ------------------------------------------------------------------ K_dense_merge_dump
+// nsplit table images per partition (left by k_aggregate_dense) -> partial records. Work item (d, j): slots [j, j + 1) * slots /
+// dsplit of partition d; one thread per slot folds the nsplit images (coalesced reads) and appends the slot's record if occupied.
+__global__ void __launch_bounds__(1024) k_dense_merge_dump(dense_agg_args const* __restrict__ ap, int dsplit)
+{
+  __shared__ uint32_t s_dump;
+  dense_agg_args const& a = *ap;
+  plan_dev const& p       = a.plan;
+  int const NACC = p.NACC, slots = a.slots, nsplit = a.nsplit, B = blockDim.x;
+  int const d = blockIdx.x / dsplit, per = slots / dsplit, s0 = (static_cast<int>(blockIdx.x) % dsplit) * per;
+  dense_layout const L = make_dense_layout(p, slots, a.occ_acc);
+  unsigned char const* images = reinterpret_cast<unsigned char const*>(a.tables) + static_cast<int64_t>(d) * nsplit * a.image_bytes;
+  if (threadIdx.x == 0) s_dump = 0;
+  __syncthreads();
+  int const KU = a.KU, PU = KU + NACC;
+  uint64_t* out       = a.out_records + static_cast<int64_t>(blockIdx.x) * per * PU;
+  uint32_t const hi   = static_cast<uint32_t>(d) << (a.map.bits - a.map.log2P);
+  uint32_t const bmask = (1u << a.map.bits) - 1u;
+  for (int s = s0 + threadIdx.x; s < s0 + per; s += B) {
+    uint64_t acc[MAX_ACC];
+    bool occupied = false;
+    for (int q = 0; q < NACC; ++q) {
+      int const op = p.acc[q].op;
+      bool const narrow = acc_is_narrow(op, p.acc[q].src);
+      uint64_t v = narrow ? 0 : acc_identity(op);
+      for (int h = 0; h < nsplit; ++h) {
+        unsigned char const* img = images + static_cast<int64_t>(h) * a.image_bytes + L.off[q];
+        if (narrow) v += gload(reinterpret_cast<uint32_t const*>(img) + s);
+        else v = combine_values(op, v, gload(reinterpret_cast<uint64_t const*>(img) + s));
+      }
+      acc[q] = v;
+      if (q == a.occ_acc) occupied = v != 0;
+    }
+    if (a.occ_acc < 0)
+      for (int h = 0; h < nsplit; ++h)
+        occupied = occupied || ((gload(reinterpret_cast<uint32_t const*>(images + static_cast<int64_t>(h) * a.image_bytes + L.occ_off) + (s >> 5)) >> (s & 31)) & 1u);
+    if (!occupied) continue;
+    uint32_t const pos = atomicAdd(&s_dump, 1u);
+    uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
+    dense_store_key_units(a.map, KU, ((hi | static_cast<uint32_t>(s)) * a.map.mult_inv) & bmask, o);
+    for (int q = 0; q < NACC; ++q) gstore(o + KU + q, acc[q]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.out_count[blockIdx.x] = static_cast<int32_t>(s_dump);
 }
 
 }  // namespace
@@ -343,17 +444,32 @@ void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t str
   CUDF_HIP_TRY(hipGetLastError());
 }
 
-template <uint64_t SIG, int NACCT>
-static void launch_dense_n(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream)
+template <uint64_t SIG, int NACCT, bool SOA>
+static void launch_dense_t(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate_dense<SIG, NACCT>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate_dense<SIG, NACCT, SOA>));
     attr_set = true;
   }
   cudf::detail::prof::scope prof_{"aggregate", stream};
-  hipLaunchKernelGGL((k_aggregate_dense<SIG, NACCT>), dim3(a.nitems), dim3(a.block), a.image_bytes, stream, d_args,
+  hipLaunchKernelGGL((k_aggregate_dense<SIG, NACCT, SOA>), dim3(a.nitems * std::max(a.nsplit, 1)), dim3(a.block), a.image_bytes, stream, d_args,
                      first_chunk ? 1 : 0, last_chunk ? 1 : 0);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+template <uint64_t SIG, int NACCT>
+static void launch_dense_n(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream)
+{
+  if (a.rec_tag != nullptr) return launch_dense_t<SIG, NACCT, true>(a, d_args, first_chunk, last_chunk, stream);
+  return launch_dense_t<SIG, NACCT, false>(a, d_args, first_chunk, last_chunk, stream);
+}
+
+void launch_dense_merge_dump(dense_agg_args const& a, dense_agg_args const* d_args, int dsplit, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.nsplit >= 1 && dsplit >= 1 && a.slots % dsplit == 0, "dense keys: merge geometry");
+  for (int q = 0; q < a.plan.NACC; ++q) CUDF_EXPECTS(a.plan.acc[q].op != ANY_U64, "dense keys: integer keys only");
+  cudf::detail::prof::scope prof_{"aggregate_merge", stream};
+  hipLaunchKernelGGL(k_dense_merge_dump, dim3(a.nitems * dsplit), dim3(1024), 0, stream, d_args, dsplit);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
@@ -361,7 +477,8 @@ void launch_aggregate_dense(dense_agg_args const& a, dense_agg_args const* d_arg
 {
   CUDF_EXPECTS(a.plan.narg == 0 && (a.map.nkeys > 0 || (a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1)),
                "dense keys: one plain key column and one plain value column, or composite integer keys and one value column");
-  CUDF_EXPECTS(a.block == 1024 && a.slices <= 1024 && a.image_bytes <= 159 * 1024 && (a.slots & (a.slots - 1)) == 0 &&
+  CUDF_EXPECTS(a.nsplit <= 1 || a.slices % a.nsplit == 0, "dense keys: the regions of a partition divide evenly among its workgroups");
+  CUDF_EXPECTS(a.block == 1024 && a.slices / std::max(a.nsplit, 1) <= 1024 && a.image_bytes <= 159 * 1024 && (a.slots & (a.slots - 1)) == 0 &&
                  a.occ_acc == dense_occ_acc(a.plan) && a.image_bytes == static_cast<int32_t>(dense_table_bytes(a.plan, a.slots)),
                "dense keys: table geometry");
   uint64_t const sig = plan_sig(a.plan);

@@ -1,0 +1,364 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 kernel of the RING scatter of the dense-key hash-groupby path (engine.hpp dense_ring_args; measurements:
+// profiles/r2_ring_scatter_microbench.txt, prototype bench_micro/ring_scatter_micro.hip).
+//
+// Every partition owns a ring of CAP record slots in LDS. A row reserves the next virtual position of its partition with ONE
+// returning LDS atomic and writes its record there; after a barrier the owner lanes flush every COMPLETE granule of 16 records
+// to the partition's region (global record index = region base + virtual position: nothing ever moves inside LDS); a second
+// barrier ends the tile. A row that finds its ring full waits one flush round. Two barriers and ~4 LDS operations per row,
+// against seven barriers and ~8 operations for the rank / scan / stage / write-out / carry-move scatter of
+// common/wc_scatter.hpp. Records leave as two streams - granules of 16 values and of 32 tags, both one whole aligned 128-byte
+// line (the tag ring is twice as long as the value ring so that a partition's tags can wait for their 32) - so a row costs
+// 12 bytes in the record buffer instead of 16: the scatter writes, and the aggregate reads, a quarter less.
+// Together with dense_kernels.hip this replaces the reference's global hash-set insert + global atomics
+// (cpp/src/groupby/hash/compute_global_memory_aggs.cuh:74-187, single_pass_functors.cuh:86-157).
+#include "device_common.hpp"
+#include "dense_loader.hpp"
+
+namespace cudf::groupby::detail {
+namespace {
+
+constexpr int RING_SRC_SIMPLE  = 0;  // one plain 8-byte integer key column, one plain 8-byte value column
+constexpr int RING_SRC_COLS    = 1;  // composite dense keys (dense_loader.hpp)
+constexpr int RING_SRC_REGIONS = 2;  // level 2: the regions of a level-1 partition
+
+// The loads of one tile, issued D tiles ahead of their use.
+template <int SRC, int RPT>
+struct ring_tile;
+template <int RPT>
+struct ring_tile<RING_SRC_SIMPLE, RPT> {
+  uint64_t k[RPT], v[RPT];
+};
+template <int RPT>
+struct ring_tile<RING_SRC_COLS, RPT> {
+  dense_raw_tile<RPT> t;
+};
+template <int RPT>
+struct ring_tile<RING_SRC_REGIONS, RPT> {
+  uint64_t v[RPT];
+  uint32_t t[RPT];
+};
+
+template <int SRC, int RPT, int D>
+__global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args const* __restrict__ ap)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int s_pending, s_abort;
+  __shared__ int32_t s_pre[MAX_REGION_LIST + 1];
+  dense_ring_args const& a = *ap;
+  plan_dev const& p        = a.plan;
+  constexpr int B          = 1024;
+  constexpr uint32_t G = 16, GT = 32;  // records per value granule / per tag granule
+  int const P = a.P, capl = a.capl;
+  uint32_t const CAP = 1u << capl, cmask = CAP - 1u, tcmask = 2u * CAP - 1u;
+  uint64_t* rval  = reinterpret_cast<uint64_t*>(lds_raw);                      // [P << capl] = DENSE_RING_SLOTS values
+  uint32_t* rtag  = reinterpret_cast<uint32_t*>(rval + DENSE_RING_SLOTS);     // [P << (capl + 1)] tags
+  uint32_t* tail  = rtag + 2 * DENSE_RING_SLOTS;                               // [P] next virtual position
+  uint32_t* limit = tail + P;                                                  // [P] head + CAP as of the last flush
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
+  int const PW = P / nwaves;  // partitions owned by a wave (1 ... 16): owner lane l < PW holds partition wave * PW + l
+  // owner lanes: values / tags of the partition flushed so far (multiples of G / GT until the final flush; headt <= head < headt + GT)
+  uint32_t head = 0, headt = 0;
+  for (int d = threadIdx.x; d < P; d += B) {
+    tail[d]  = 0;
+    limit[d] = CAP;
+  }
+  if (threadIdx.x == 0) {
+    s_pending = 0;
+    s_abort   = 0;
+  }
+  // ---- this work item's rows and output regions
+  constexpr int64_t T = static_cast<int64_t>(B) * RPT;
+  int item = blockIdx.x, seg = 0;
+  int64_t begin, end, step;
+  int nreg = 0;
+  int64_t rfirst = 0, rstride = 0;
+  if constexpr (SRC == RING_SRC_REGIONS) {
+    // the level-1 regions (seg, w), w = item, item + slices, ... as one virtual row range; s_pre[j] = rows before listed region j
+    seg     = blockIdx.x / a.slices;
+    item    = blockIdx.x % a.slices;
+    nreg    = (a.in_slices - item + a.slices - 1) / a.slices;
+    rfirst  = (static_cast<int64_t>(seg) * a.in_slices + item) * a.in_region_cap;
+    rstride = static_cast<int64_t>(a.slices) * a.in_region_cap;
+    if (threadIdx.x == 0) {
+      int32_t run = 0;
+      for (int j = 0; j < nreg; ++j) {
+        s_pre[j] = run;
+        // (clamped: a level-1 workgroup that gave up left its counts unwritten)
+        int64_t const c = a.in_region_count[static_cast<int64_t>(seg) * a.in_slices + item + static_cast<int64_t>(j) * a.slices];
+        run += static_cast<int32_t>(min(max(c, int64_t{0}), a.in_region_cap));
+      }
+      s_pre[nreg] = run;
+    }
+    __syncthreads();
+    begin = 0;
+    end   = s_pre[nreg];
+    step  = T;
+  } else {
+    // workgroup w takes the row tiles w, w + slices, ...: sorted or clustered keys spread over every workgroup's regions
+    begin = static_cast<int64_t>(item) * T;
+    end   = a.nrows;
+    step  = static_cast<int64_t>(a.slices) * T;
+    __syncthreads();
+  }
+  int64_t const region0     = static_cast<int64_t>(seg) * P * a.slices;
+  uint32_t const region_cap = static_cast<uint32_t>(a.region_cap);
+  uint64_t* const out_val   = a.out_val;
+  uint32_t* const out_tag   = a.out_tag;
+  [[maybe_unused]] uint64_t const dense_lo = a.map.lo, dense_range = a.map.range;
+  [[maybe_unused]] uint32_t const mult = a.map.mult, bmask = (1u << a.map.bits) - 1u;
+  int const shift = a.shift;
+  uint32_t const pmask = static_cast<uint32_t>(P - 1), tmask = (1u << shift) - 1u;
+  [[maybe_unused]] uint64_t const* kbase = p.simple_base[0];
+  [[maybe_unused]] uint64_t const* vbase = p.simple_base[1];
+
+  auto record_of = [&](int64_t v) -> int64_t {  // virtual row of the region list -> record index (binary search in s_pre)
+    int lo = 0, hi = nreg;
+    while (hi - lo > 1) {
+      int const mid = (lo + hi) >> 1;
+      if (s_pre[mid] <= v) lo = mid; else hi = mid;
+    }
+    return rfirst + static_cast<int64_t>(lo) * rstride + (v - s_pre[lo]);
+  };
+  auto issue = [&](int64_t tile, ring_tile<SRC, RPT>& r) {
+    if constexpr (SRC == RING_SRC_COLS) {
+      issue_dense_composite<RPT>(p, a.map, tile, B, end, r.t);
+    } else {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        int64_t const row = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+        if (row < end) {
+          if constexpr (SRC == RING_SRC_SIMPLE) {
+            r.k[k] = gload(kbase + row);
+            r.v[k] = gload(vbase + row);
+          } else {
+            int64_t const ri = record_of(row);
+            r.v[k]           = gload(a.in_val + ri);
+            r.t[k]           = gload(a.in_tag + ri);
+          }
+        }
+      }
+    }
+  };
+  // flush every complete granule of this wave's partitions; final: also the partial last granule
+  auto flush = [&](bool final) {
+    uint32_t nrec = 0, nrect = 0;
+    int ab        = 0;
+    int const dmine = wave * PW + lane;
+    if (lane < PW) {
+      uint32_t const t = tail[dmine], lim = head + CAP;
+      uint32_t const c = static_cast<int32_t>(t - lim) < 0 ? t : lim;  // records that made it into the ring
+      uint32_t const complete = final ? c : (c & ~(G - 1u));
+      nrec  = complete - head;
+      nrect = (final ? c : (c & ~(GT - 1u))) - headt;
+      if (complete > region_cap) {
+        s_abort = 1;
+        ab      = 1;
+      }
+    }
+    // values: 8 lanes per granule (two values = 16 bytes per lane), 8 partitions per batch
+    for (int b = 0; b * 8 < PW; ++b) {
+      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
+      uint32_t const mr = __shfl(nrec, pl), mh = __shfl(head, pl);
+      int const mab     = __shfl(ab, pl);
+      int const d       = wave * PW + pl;
+      int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
+      for (uint32_t g = 0;; ++g) {
+        uint32_t const q = g * G + sub * 2;
+        bool const act   = pl < PW && q < mr && !mab;
+        if (__ballot(act) == 0) break;
+        if (act) {
+          uint32_t const pos = mh + q;
+          u64x2 const v      = *reinterpret_cast<u64x2 const*>(rval + (static_cast<uint32_t>(d) << capl) + (pos & cmask));
+          if (q + 1 < mr) gstore(reinterpret_cast<u64x2*>(out_val + rbase + pos), v);
+          else gstore(out_val + rbase + pos, static_cast<uint64_t>(v.x));
+        }
+      }
+    }
+    // tags: 8 lanes per granule (four tags = 16 bytes per lane), 8 partitions per batch
+    for (int b = 0; b * 8 < PW; ++b) {
+      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
+      uint32_t const mr = __shfl(nrect, pl), mh = __shfl(headt, pl);
+      int const mab     = __shfl(ab, pl);
+      int const d       = wave * PW + pl;
+      int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
+      for (uint32_t g = 0;; ++g) {
+        uint32_t const q = g * GT + sub * 4;
+        bool const act   = pl < PW && q < mr && !mab;
+        if (__ballot(act) == 0) break;
+        if (act) {
+          uint32_t const pos = mh + q;
+          u32x4 const v      = *reinterpret_cast<u32x4 const*>(rtag + (static_cast<uint32_t>(d) << (capl + 1)) + (pos & tcmask));
+          if (q + 3 < mr) {
+            gstore(reinterpret_cast<u32x4*>(out_tag + rbase + pos), v);
+          } else {
+            gstore(out_tag + rbase + pos, v.x);
+            if (q + 1 < mr) gstore(out_tag + rbase + pos + 1, v.y);
+            if (q + 2 < mr) gstore(out_tag + rbase + pos + 2, v.z);
+          }
+        }
+      }
+    }
+    if (lane < PW) {
+      head += nrec;
+      headt += nrect;
+      limit[dmine] = head + CAP;
+    }
+  };
+
+  ring_tile<SRC, RPT> pre[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) issue(begin + j * step, pre[j]);
+  for (int64_t tile = begin; tile < end; tile += D * step) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      int64_t const t0 = tile + j * step;
+      // ---- this tile's rows: partition digit, tag and value (waits for the tile's loads)
+      bool keep[RPT];
+      uint32_t d[RPT], tg[RPT];
+      uint64_t val[RPT];
+      if constexpr (SRC == RING_SRC_COLS) {
+        uint32_t idx32[RPT], valid[RPT];
+        bool bad;
+        if (t0 < end) {  // (uniform)
+          decode_dense_composite<RPT>(p, a.map, B, pre[j].t, keep, idx32, valid, val, bad);
+          if (bad) atomicOr(a.overflow, 4);
+#pragma unroll
+          for (int k = 0; k < RPT; ++k) {
+            uint32_t const x = (idx32[k] * mult) & bmask;
+            d[k]  = (x >> shift) & pmask;
+            tg[k] = (x & tmask) | (valid[k] << 31);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          keep[k] = t0 + static_cast<int64_t>(k) * B + threadIdx.x < end;
+          d[k]    = 0;
+          tg[k]   = 0;
+          val[k]  = pre[j].v[k];
+          if (keep[k]) {
+            if constexpr (SRC == RING_SRC_SIMPLE) {
+              uint64_t idx = pre[j].k[k] - dense_lo;
+              if (idx >= dense_range) {  // the sampled key range was wrong: this call is void (redone by hash)
+                atomicOr(a.overflow, 4);
+                idx = 0;
+              }
+              uint32_t const x = (static_cast<uint32_t>(idx) * mult) & bmask;
+              d[k]  = (x >> shift) & pmask;
+              tg[k] = (x & tmask) | 0x80000000u;
+            } else {
+              uint32_t const x = pre[j].t[k];
+              d[k]  = ((x & 0x7fffffffu) >> shift) & pmask;
+              tg[k] = x & (tmask | 0x80000000u);
+            }
+          }
+        }
+      }
+      issue(t0 + D * step, pre[j]);
+      if (t0 >= end) break;  // (uniform)
+      // ---- reserve ring positions; rows whose position lies beyond the ring wait for the flush
+      uint32_t pos[RPT], lim[RPT];
+      bool pend[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        pos[k] = 0;
+        lim[k] = 0;
+        if (keep[k]) {
+          pos[k] = atomicAdd(&tail[d[k]], 1u);
+          lim[k] = limit[d[k]];
+        }
+      }
+      bool any_pend = false;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        pend[k] = keep[k] && static_cast<int32_t>(pos[k] - lim[k]) >= 0;
+        if (keep[k] && !pend[k]) {
+          uint32_t const w = (d[k] << capl) + (pos[k] & cmask);
+          rval[w] = val[k];
+          rtag[(d[k] << (capl + 1)) + (pos[k] & tcmask)] = tg[k];
+        }
+        any_pend = any_pend || pend[k];
+      }
+      if (any_pend) s_pending = 1;
+      lds_barrier();
+      flush(false);
+      lds_barrier();
+      while (s_pending) {  // a ring was full: its granules are flushed by now, the waiting rows go in
+        lds_barrier();
+        if (threadIdx.x == 0) s_pending = 0;
+        lds_barrier();
+        any_pend = false;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          if (pend[k]) {
+            uint32_t const l2 = limit[d[k]];
+            if (static_cast<int32_t>(pos[k] - l2) < 0) {
+              uint32_t const w = (d[k] << capl) + (pos[k] & cmask);
+              rval[w] = val[k];
+              rtag[(d[k] << (capl + 1)) + (pos[k] & tcmask)] = tg[k];
+              pend[k] = false;
+            } else {
+              any_pend = true;
+            }
+          }
+        }
+        if (any_pend) s_pending = 1;
+        lds_barrier();
+        flush(false);
+        lds_barrier();
+        if (s_abort) break;
+      }
+      if (s_abort) {  // a region would overflow (skewed or clustered keys): the caller redoes the call
+        if (threadIdx.x == 0) atomicOr(a.overflow, 1);
+        return;
+      }
+    }
+  }
+  flush(true);
+  lds_barrier();
+  if (s_abort) {
+    if (threadIdx.x == 0) atomicOr(a.overflow, 1);
+    return;
+  }
+  if (lane < PW) a.region_count[region0 + static_cast<int64_t>(wave * PW + lane) * a.slices + item] = static_cast<int32_t>(head);
+}
+
+template <int SRC, int RPT, int D>
+void launch_ring_t(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
+{
+  static bool attr_set = false;
+  if (!attr_set) {
+    allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D>));
+    attr_set = true;
+  }
+  std::size_t const lds = static_cast<std::size_t>(DENSE_RING_SLOTS) * 16 + static_cast<std::size_t>(a.P) * 8;
+  int const items       = a.from_columns ? a.slices : a.nseg * a.slices;
+  cudf::detail::prof::scope prof_{a.from_columns ? "partition_scatter" : "partition_scatter_level2", stream};
+  hipLaunchKernelGGL((k_dense_ring_scatter<SRC, RPT, D>), dim3(items), dim3(1024), lds, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace
+
+void store_args(dense_ring_args const& a, dense_ring_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<dense_ring_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.P >= 16 && a.P <= 256 && (a.P & (a.P - 1)) == 0 && (a.P << a.capl) == DENSE_RING_SLOTS && a.capl >= 5,
+               "ring scatter: fan-out 16 ... 256, rings of at least two granules");
+  CUDF_EXPECTS(a.region_cap % 32 == 0 && a.shift >= 0 && a.shift < 31 && a.slices >= 1, "ring scatter: region geometry");
+  if (a.from_columns) {
+    if (a.map.nkeys > 0) return launch_ring_t<RING_SRC_COLS, 4, 1>(a, d_args, stream);
+    CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1, "ring scatter: one plain key column and one plain value column");
+    return launch_ring_t<RING_SRC_SIMPLE, 4, 2>(a, d_args, stream);
+  }
+  CUDF_EXPECTS((a.in_slices + a.slices - 1) / a.slices <= MAX_REGION_LIST, "ring scatter: region list too long");
+  return launch_ring_t<RING_SRC_REGIONS, 4, 2>(a, d_args, stream);
+}
+
+}  // namespace cudf::groupby::detail

@@ -280,6 +280,14 @@ struct dense_agg_args {
   plan_dev plan;
   dense_map map;
   uint64_t const* records;
+  // 12-byte records of the ring scatter (dense_ring_args), two streams per region: rec_val[i] = the value, rec_tag[i] = table slot
+  // (low bits) | validity of the value (bit 31). rec_tag == nullptr: 16-byte {key or index | validity, value} records in `records`.
+  uint64_t const* rec_val;
+  uint32_t const* rec_tag;
+  // nsplit > 1: a partition's regions are shared out to nsplit workgroups (work item = partition * nsplit + h takes the regions
+  // [h * slices / nsplit, (h + 1) * slices / nsplit)); every workgroup leaves its table image in `tables` and
+  // launch_dense_merge_dump folds the nsplit images of a partition into the partial records.
+  int32_t nsplit;
   int32_t const* region_count;
   int64_t region_cap;
   int32_t slices;
@@ -298,6 +306,42 @@ std::size_t dense_table_bytes(plan_dev const& plan, int slots);  // LDS image of
 int dense_occ_acc(plan_dev const& plan);                          // dense_agg_args::occ_acc of a plan
 void launch_aggregate_dense(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream);
 void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t stream);
+// nsplit > 1: the nsplit table images of every partition -> partial records. Work item (d, j), j < dsplit, dumps the slots
+// [j * slots / dsplit, (j + 1) * slots / dsplit) of partition d to out_records[(d * dsplit + j) * (slots / dsplit) * PU ...], count in
+// out_count[d * dsplit + j].
+void launch_dense_merge_dump(dense_agg_args const& a, dense_agg_args const* d_args, int dsplit, hipStream_t stream);
+
+// Ring scatter of dense-key rows (dense_ring_kernels.hip): every partition owns a ring of record slots in LDS, a row reserves its
+// position with one returning LDS atomic, and only whole aligned 128-byte granules (16 values, 32 tags) leave the
+// workgroup - two barriers per tile. Records are 12 bytes in two streams per region: value (8 B) and tag (4 B: the bits of the
+// scrambled index below this level's digit | validity of the value in bit 31). Level 1 reads the input columns (workgroup w
+// takes the row tiles w, w + slices, ...), level 2 reads level-1 partition g as the strided list of its regions
+// s, s + slices, ... (work item g * slices + s) and writes the regions of the global partitions g * P + d.
+// Region (q, w) of an output with S slices lies at [(q * S + w) * region_cap, + region_count[q * S + w]) of both streams.
+struct dense_ring_args {
+  plan_dev plan;
+  dense_map map;
+  int32_t from_columns;
+  int64_t nrows;
+  int32_t P;       // fan-out of this level: a power of two, 16 ... 256
+  int32_t capl;    // log2 of the ring capacity per partition: P << capl = 8192 records
+  int32_t shift;   // digit = (x >> shift) & (P - 1), tag = x & ((1 << shift) - 1): x = scrambled index (level 1), input tag (level 2)
+  int32_t slices;
+  int32_t nseg;    // level 2: level-1 partitions
+  uint64_t const* in_val;
+  uint32_t const* in_tag;
+  int32_t const* in_region_count;
+  int64_t in_region_cap;
+  int32_t in_slices;
+  uint64_t* out_val;
+  uint32_t* out_tag;
+  int64_t region_cap;  // a multiple of 32 records
+  int32_t* region_count;
+  int32_t* overflow;   // bit 0: a region overflowed; bit 2: a key outside the dense range
+};
+constexpr int DENSE_RING_SLOTS = 8192;  // value-ring slots of a workgroup (all partitions); the tag rings are twice as long: 128 KiB of LDS
+void store_args(dense_ring_args const& a, dense_ring_args* d_args, hipStream_t stream);
+void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream);
 // Minimum and maximum of a plain 8-byte integer key column over the strided sample of launch_estimate (signed compare
 // for signed keys): out[0] = min, out[1] = max as bit patterns. `out` must hold {max value, min value} of the ordering before.
 void launch_key_range(plan_dev const* d_plan, int64_t nrows, int64_t sample, int is_signed, uint64_t* out, hipStream_t stream);
@@ -322,9 +366,14 @@ struct finalize_args {
 };
 void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t const* records, int64_t cap,
                      int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream);
+// prefix[i] = counts[0] + ... + counts[i - 1] for i <= nitems (the items' group counts -> where each item's groups go in the output)
+void launch_count_prefix(int32_t const* counts, int32_t nitems, int64_t* prefix, hipStream_t stream);
 // Distinct-count estimate on a strided sample (linear counting into a bitmap); result written to *d_bits.
+// range_mode 1 / 2 (one plain 8-byte integer key column, signed / unsigned): the pass also leaves the minimum and maximum of the
+// sampled keys in range_out[0], [1]; blk_range holds 2 x ceil(sample / 256) scratch words.
 void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
-                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream);
+                     int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream, int range_mode = 0,
+                     uint64_t* blk_range = nullptr, uint64_t* range_out = nullptr);
 
 // Distinct-count of the key rows over ALL rows (HyperLogLog, HLL_REGISTERS 32-bit registers holding ranks): the planner
 // runs it after a table overflowed, i.e. when the sample misjudged the group count (skewed key frequencies).

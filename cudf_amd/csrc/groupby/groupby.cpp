@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -521,6 +522,41 @@ int32_t* pinned_ints(std::size_t count)
   return buf;
 }
 
+// The same for the estimate pass's read-backs (bitmap population, key ranges, heavy-hitter table): its own buffer, so that the
+// pointers pinned_ints() hands out stay valid next to it.
+unsigned char* pinned_bytes(std::size_t count)
+{
+  thread_local unsigned char* buf = nullptr;
+  thread_local std::size_t cap    = 0;
+  if (count > cap) {
+    if (buf != nullptr) (void)hipHostFree(buf);
+    cap = std::max<std::size_t>(count, 65536);
+    CUDF_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&buf), cap, hipHostMallocDefault));
+  }
+  return buf;
+}
+
+// CUDF_AMD_GB_TRACE=1: host-side timeline of a call (microseconds since entry at every mark), printed to stderr when the call returns.
+struct call_trace {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  std::string line;
+  call_trace() : on{env_i64("CUDF_AMD_GB_TRACE", 0) != 0}, t0{std::chrono::steady_clock::now()} {}
+  void mark(char const* what)
+  {
+    if (!on) return;
+    auto const us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+    line += std::string(line.empty() ? "" : " | ") + what + " " + std::to_string(us);
+  }
+  ~call_trace()
+  {
+    if (on) {
+      mark("return");
+      fprintf(stderr, "[cudf_amd] groupby trace (us): %s\n", line.c_str());
+    }
+  }
+};
+
 struct scratch {  // stream-ordered temporaries from the current device resource
   hipStream_t stream;
   rmm::device_async_resource_ref mr;
@@ -570,6 +606,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
 
   hipStream_t const s = stream.value();
   auto tmp_mr         = cudf::get_current_device_resource_ref();
+  detail::call_trace trace;
 
   // ---- empty input: typed empty outputs (reference groupby.cu:233, :87-182)
   if (_keys.num_rows() == 0) {
@@ -593,6 +630,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   }
 
   host_plan hp     = build_plan(_keys, _include_null_keys, requests);
+  trace.mark("plan");
   plan_dev const& p = hp.dev;
   int64_t const n   = _keys.num_rows();
   int const RU = p.KU + p.NPAY, PU = p.KU + p.NACC;
@@ -644,17 +682,24 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     bool const hot_eligible = p.simple && RU == 2 && p.KU == 1 && hot_plan_ok(p) && n >= (int64_t{1} << 22) &&
                               env_i64("CUDF_AMD_GB_HOT", 1) != 0;
     uint32_t* hot_buckets = hot_eligible ? sc.alloc<uint32_t>(HOT_BUCKETS) : nullptr;
-    launch_estimate(p, d_plan, n, sample, bitmap, bits_log2, d_set, hot_buckets, s);
+    // (one plain integer key column: the same pass takes the minimum and maximum of the sampled keys for the dense-key test)
+    uint64_t* d_range = dense_candidate ? sc.alloc<uint64_t>(2) : nullptr;
+    uint64_t* d_blk_range = dense_candidate ? sc.alloc<uint64_t>(2 * static_cast<std::size_t>((sample + 255) / 256)) : nullptr;
+    launch_estimate(p, d_plan, n, sample, bitmap, bits_log2, d_set, hot_buckets, s, dense_candidate ? (dense_signed ? 1 : 2) : 0, d_blk_range, d_range);
     // Dense integer keys ("Dense keys"): minimum and maximum of the key column over the same sample
-    uint64_t* d_range = nullptr;
+    // (every read-back of this pass lands in page-locked memory: a copy into pageable memory blocks the host until it is done)
+    unsigned char* const pin = pinned_bytes(64 + 16 + sizeof(h_ranges) + HOT_TABLE * (sizeof(uint64_t) + sizeof(uint32_t)));
+    uint32_t* const pin_set    = reinterpret_cast<uint32_t*>(pin);
+    uint64_t* const pin_range  = reinterpret_cast<uint64_t*>(pin + 64);
+    int64_t* const pin_ranges  = reinterpret_cast<int64_t*>(pin + 64 + 16);
+    uint64_t* const pin_tkeys  = reinterpret_cast<uint64_t*>(pin + 64 + 16 + sizeof(h_ranges));
+    uint32_t* const pin_tcounts = reinterpret_cast<uint32_t*>(pin_tkeys + HOT_TABLE);
     if (dense_candidate) {
-      d_range = sc.alloc<uint64_t>(2);
-      launch_key_range(d_plan, n, sample, dense_signed ? 1 : 0, d_range, s);
-      CUDF_HIP_TRY(hipMemcpyAsync(h_range, d_range, 16, hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipMemcpyAsync(pin_range, d_range, 16, hipMemcpyDeviceToHost, s));
     } else if (dense_composite) {
       int64_t* d_ranges = sc.alloc<int64_t>(2 * MAX_KU);
       launch_key_ranges(d_plan, p.nkeycols, n, sample, d_ranges, s);
-      CUDF_HIP_TRY(hipMemcpyAsync(h_ranges, d_ranges, sizeof(h_ranges), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipMemcpyAsync(pin_ranges, d_ranges, sizeof(h_ranges), hipMemcpyDeviceToHost, s));
     }
     // Heavy hitters (plain int64 key + one plain value, SUM / COUNT): a key above ~0.05 % of the rows overflows its
     // regions of the optimistic partition, and a key with percents of the rows leaves one workgroup aggregating its
@@ -668,14 +713,20 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       uint64_t* tkeys   = sc.alloc<uint64_t>(HOT_TABLE);
       uint32_t* tcounts = sc.alloc<uint32_t>(HOT_TABLE + 1);
       launch_hot_keys(d_plan, n, sample, hot_min_count, buckets, tkeys, tcounts, s);
-      h_tkeys.resize(HOT_TABLE);
-      h_tcounts.resize(HOT_TABLE);
-      CUDF_HIP_TRY(hipMemcpyAsync(h_tkeys.data(), tkeys, HOT_TABLE * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-      CUDF_HIP_TRY(hipMemcpyAsync(h_tcounts.data(), tcounts, HOT_TABLE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipMemcpyAsync(pin_tkeys, tkeys, HOT_TABLE * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipMemcpyAsync(pin_tcounts, tcounts, HOT_TABLE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
-    uint32_t h_set = 0;
-    CUDF_HIP_TRY(hipMemcpyAsync(&h_set, d_set, 4, hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(pin_set, d_set, 4, hipMemcpyDeviceToHost, s));
+    trace.mark("estimate queued");
     CUDF_HIP_TRY(hipStreamSynchronize(s));
+    trace.mark("estimate back");
+    uint32_t const h_set = *pin_set;
+    if (dense_candidate) std::memcpy(h_range, pin_range, 16);
+    if (dense_composite) std::memcpy(h_ranges, pin_ranges, sizeof(h_ranges));
+    if (hot_eligible) {
+      h_tkeys.assign(pin_tkeys, pin_tkeys + HOT_TABLE);
+      h_tcounts.assign(pin_tcounts, pin_tcounts + HOT_TABLE);
+    }
     if (hot_eligible) {  // the most frequent keys first, at most HOT_MAX_KEYS of them
       std::vector<std::pair<uint32_t, uint64_t>> cand;
       for (int i = 0; i < HOT_TABLE; ++i)
@@ -721,7 +772,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     int32_t* const pin = pinned_ints(static_cast<std::size_t>(nitems) + 1);
     CUDF_HIP_TRY(hipMemcpyAsync(pin, d_overflow, 4, hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipMemcpyAsync(pin + 1, d_count, sizeof(int32_t) * static_cast<std::size_t>(nitems), hipMemcpyDeviceToHost, s));
+    trace.mark("attempt queued");
     CUDF_HIP_TRY(hipStreamSynchronize(s));
+    trace.mark("attempt back");
     h_count.assign(pin + 1, pin + 1 + nitems);
     return pin[0];
   };
@@ -889,6 +942,133 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         }
         int bits = 14;
         while (bits < 31 && (uint64_t{1} << bits) < dm.range) ++bits;
+        // ---- ring scatter (dense_ring_kernels.hip): 12-byte records in two streams, one or two levels of fan-out 16 ... 256, the
+        // largest tables that fit (one 1024-thread aggregate workgroup per CU; a partition's regions are shared out to several
+        // workgroups when there are fewer partitions than CUs)
+        if (dense_ok && env_i64("CUDF_AMD_GB_DENSE_RING", 1) != 0 && env_i64("CUDF_AMD_GB_CHUNKED", 0) == 0) {
+          int rlog2P = 7;
+          while (rlog2P < 17 && dense_table_bytes(p, 1 << std::max(bits - rlog2P, 0)) > 150 * 1024) ++rlog2P;
+          if (env_i64("CUDF_AMD_GB_DENSE_LOG2P", 0) > 0) rlog2P = static_cast<int>(env_i64("CUDF_AMD_GB_DENSE_LOG2P", 0));
+          bool const two_level = rlog2P > 8;
+          int const l1 = two_level ? (rlog2P + 1) / 2 : rlog2P, l2 = rlog2P - l1;
+          int const slots         = 1 << std::max(bits - rlog2P, 0);
+          std::size_t const image = dense_table_bytes(p, slots);
+          bool const ring_ok = dm.range <= (uint64_t{1} << bits) && bits <= 30 && bits - rlog2P >= 6 && rlog2P <= 16 && l1 >= 4 && l1 <= 8 &&
+                               (l2 == 0 || (l2 >= 4 && l2 <= 8)) && image <= 150 * 1024 &&
+                               static_cast<double>(dm.range) <= 8.0 * std::max(est_groups, 4096.0);
+          if (ring_ok) {
+            _last_path  = hash_path::DENSE_DIRECT;
+            dm.mult     = 0x9E3779B1u;  // odd: index -> (index * mult) mod 2^bits is a bijection
+            uint32_t inv = dm.mult;     // Newton: inv = mult^-1 mod 2^32
+            for (int it = 0; it < 5; ++it) inv *= 2u - dm.mult * inv;
+            dm.mult_inv = inv;
+            dm.bits     = bits;
+            dm.log2P    = rlog2P;
+            int const DPU      = (dm.nkeys > 0 ? p.KU : 1) + p.NACC;  // units of a dumped partial record
+            int64_t const PD = int64_t{1} << l1, P2D = int64_t{1} << l2, S = 256;
+            auto region_cap_for = [&](double mean, double parts) {
+              double const keys_per_p = std::max(1.0, 0.5 * est_groups / parts);
+              double const rel_sigma  = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, mean));
+              return (static_cast<int64_t>(mean * (1.0 + 6.0 * std::min(rel_sigma, 1.0)) + 32.0) + 31) / 32 * 32;
+            };
+            // (workgroup w takes the 4096-row tiles w, w + S, ...: the busiest workgroup has ceil(tiles / S) of them)
+            int64_t const ring_tile = 4 * 1024, wg_rows = std::min<int64_t>(n, ((n + ring_tile - 1) / ring_tile + S - 1) / S * ring_tile);
+            int64_t const capR = region_cap_for(static_cast<double>(wg_rows) / static_cast<double>(PD), static_cast<double>(PD));
+            dense_ring_args ra{};
+            ra.plan         = p;
+            ra.map          = dm;
+            ra.from_columns = 1;
+            ra.nrows        = n;
+            ra.P            = static_cast<int32_t>(PD);
+            ra.capl         = 13 - l1;
+            ra.shift        = bits - l1;  // level 1: the top l1 bits of the scrambled index
+            ra.slices       = static_cast<int32_t>(S);
+            ra.nseg         = 1;
+            ra.region_cap   = capR;
+            ra.region_count = sc.alloc<int32_t>(static_cast<size_t>(S * PD));
+            ra.overflow     = d_overflow;
+            ra.out_val      = sc.alloc<uint64_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR));
+            ra.out_tag      = sc.alloc<uint32_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR));
+            dense_ring_args* d_ra = sc.alloc<dense_ring_args>(1);
+            store_args(ra, d_ra, s);
+            dense_agg_args da{};
+            da.plan         = p;
+            da.map          = dm;
+            da.rec_val      = ra.out_val;
+            da.rec_tag      = ra.out_tag;
+            da.region_count = ra.region_count;
+            da.region_cap   = capR;
+            da.slices       = static_cast<int32_t>(S);
+            int64_t cap2    = 0;
+            dense_ring_args rb{};
+            dense_ring_args* d_rb = nullptr;
+            if (two_level) {
+              // level 2: work item (g, s) reads level-1 partition g as the strided list of its regions s, s + slices2, ... and appends
+              // to the regions of the global partitions g * P2 + d (the next l2 bits); the aggregate walks those
+              int64_t const slices2 = std::max<int64_t>(1, 512 / PD);
+              cap2 = region_cap_for(static_cast<double>(n) / static_cast<double>(PD * slices2 * P2D), static_cast<double>(PD * P2D));
+              size_t const nreg2 = static_cast<size_t>(PD * P2D * slices2);
+              rb                 = ra;
+              rb.from_columns    = 0;
+              rb.P               = static_cast<int32_t>(P2D);
+              rb.capl            = 13 - l2;
+              rb.shift           = bits - rlog2P;  // the l2 bits below the level-1 digit
+              rb.slices          = static_cast<int32_t>(slices2);
+              rb.nseg            = static_cast<int32_t>(PD);
+              rb.in_val          = ra.out_val;
+              rb.in_tag          = ra.out_tag;
+              rb.in_region_count = ra.region_count;
+              rb.in_region_cap   = capR;
+              rb.in_slices       = static_cast<int32_t>(S);
+              rb.region_cap      = cap2;
+              rb.region_count    = sc.alloc<int32_t>(nreg2);
+              rb.out_val         = sc.alloc<uint64_t>(nreg2 * static_cast<size_t>(cap2));
+              rb.out_tag         = sc.alloc<uint32_t>(nreg2 * static_cast<size_t>(cap2));
+              d_rb               = sc.alloc<dense_ring_args>(1);
+              store_args(rb, d_rb, s);
+              da.rec_val      = rb.out_val;
+              da.rec_tag      = rb.out_tag;
+              da.region_count = rb.region_count;
+              da.region_cap   = cap2;
+              da.slices       = static_cast<int32_t>(slices2);
+            }
+            int32_t const ntables = static_cast<int32_t>(int64_t{1} << rlog2P);
+            int const nsplit      = static_cast<int>(std::clamp<int64_t>(env_i64("CUDF_AMD_GB_DENSE_NSPLIT", 256 / ntables), 1, two_level ? 1 : 16));
+            da.nsplit       = nsplit;
+            da.slots        = slots;
+            da.image_bytes  = static_cast<int32_t>(image);
+            da.occ_acc      = dense_occ_acc(p);
+            da.KU           = dm.nkeys > 0 ? p.KU : 1;
+            nitems          = ntables * nsplit;  // (partial records: partition d's slots in nsplit shares)
+            da.tables       = sc.alloc<uint64_t>(nsplit > 1 ? static_cast<size_t>(nitems) * image / 8 : 2);
+            partial         = sc.alloc<uint64_t>(static_cast<size_t>(ntables) * slots * DPU);
+            d_count         = sc.alloc<int32_t>(nitems);
+            da.out_records  = partial;
+            da.out_count    = d_count;
+            da.overflow     = d_overflow;
+            da.nitems       = ntables;
+            da.block        = 1024;
+            dense_agg_args* d_da = sc.alloc<dense_agg_args>(1);
+            store_args(da, d_da, s);
+            launch_dense_ring_scatter(ra, d_ra, s);
+            if (two_level) launch_dense_ring_scatter(rb, d_rb, s);
+            launch_aggregate_dense(da, d_da, true, true, s);
+            if (nsplit > 1) launch_dense_merge_dump(da, d_da, nsplit, s);
+            final_cap          = slots / nsplit;
+            int32_t const h_ov = overflow_and_counts();
+            if (env_i64("CUDF_AMD_DEBUG", 0))
+              fprintf(stderr, "[cudf_amd] dense keys (ring): nkeys=%d lo=%lld range=%llu bits=%d P=%ld x %ld slots=%d image=%zu B nsplit=%d capR=%ld cap2=%ld overflow=%d\n",
+                      dm.nkeys, (long long)dm.lo, (unsigned long long)dm.range, bits, (long)PD, (long)P2D, slots, image, nsplit, (long)capR, (long)cap2, h_ov);
+            if (h_ov == 0) break;
+            // a region overflowed (skewed or clustered keys) or a key lay outside the sampled range: redo by hash
+            allow_dense = false;
+            final_cap   = 0;
+            sc.bufs.clear();
+            d_overflow = sc.alloc<int32_t>(1);
+            --attempt;
+            continue;
+          }
+        }
         double const unit_bytes = static_cast<double>(dense_table_bytes(p, 4096)) / 4096.0;  // LDS bytes per key of the range
         // One level: tables of ~32 KiB (two 1024-thread workgroups per CU), 256 to 1024 of them. A range that needs more than
         // 1024 tables of 150 KiB takes two levels (P1 x P2) with the largest tables that fit.
@@ -1286,13 +1466,12 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     escalate();
   }
 
-  // ---- group counts -> prefix
-  std::vector<int64_t> h_prefix(nitems + 1, 0);
-  for (int i = 0; i < nitems; ++i) h_prefix[i + 1] = h_prefix[i] + h_count[i];
-  int64_t const G = h_prefix[nitems];
+  // ---- group counts -> prefix (on the device, from the counts the attempt left there: the host only needs the total)
+  int64_t G = 0;
+  for (int i = 0; i < nitems; ++i) G += h_count[i];
   CUDF_EXPECTS(G <= std::numeric_limits<size_type>::max(), "group count exceeds size_type");
   int64_t* d_prefix = sc.alloc<int64_t>(nitems + 1);
-  CUDF_HIP_TRY(hipMemcpyAsync(d_prefix, h_prefix.data(), sizeof(int64_t) * (nitems + 1), hipMemcpyHostToDevice, s));
+  launch_count_prefix(d_count, nitems, d_prefix, s);
 
   // ---- output columns
   finalize_args fa{};
@@ -1398,12 +1577,20 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     res_cols.push_back(std::move(col));
   }
   launch_finalize(fa, sc.alloc<finalize_args>(1), partial, final_cap > 0 ? final_cap : ag.cap, d_prefix, nitems, G, s);
-  int32_t* const h_nulls = pinned_ints(MAX_OUT);
-  CUDF_HIP_TRY(hipMemcpyAsync(h_nulls, d_nulls, sizeof(int32_t) * MAX_OUT, hipMemcpyDeviceToHost, s));
-  CUDF_HIP_TRY(hipStreamSynchronize(s));
-  int oc = 0;
-  for (auto& k : key_cols) k->set_null_count(h_nulls[oc++]);
-  for (std::size_t r = 0; r < res_cols.size(); ++r) res_cols[r]->set_null_count(h_nulls[res_desc[r]]);
+  // the null counts come back with one more synchronisation - only if some output column can hold a null at all (the results are
+  // stream-ordered like every libcudf result: the caller synchronises before it reads them on another stream or on the host)
+  bool any_nullable = false;
+  for (int o = 0; o < fin.nout; ++o) any_nullable = any_nullable || fin.out[o].mask != nullptr;
+  trace.mark("finalize queued");
+  if (any_nullable) {
+    int32_t* const h_nulls = pinned_ints(MAX_OUT);
+    CUDF_HIP_TRY(hipMemcpyAsync(h_nulls, d_nulls, sizeof(int32_t) * MAX_OUT, hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    trace.mark("finalize back");
+    int oc = 0;
+    for (auto& k : key_cols) k->set_null_count(h_nulls[oc++]);
+    for (std::size_t r = 0; r < res_cols.size(); ++r) res_cols[r]->set_null_count(h_nulls[res_desc[r]]);
+  }
 
   // ---- hand results back in request order; every (column, aggregation) pair has its own column, so a
   // repeated pair needs no cache deep copy (reference groupby/common/utils.hpp:39-51 copies instead).

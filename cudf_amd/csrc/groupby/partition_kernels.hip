@@ -1,6 +1,7 @@
 // SPDX-License-Identifier: Apache-2.0
 // gfx950 partition kernels of the hash-groupby engine: histogram, scan, LDS-staged multi-split scatter (engine.hpp).
 #include "device_common.hpp"
+#include "dense_loader.hpp"
 #include "../common/wc_scatter.hpp"
 
 namespace cudf::groupby::detail {
@@ -458,85 +459,15 @@ __global__ void __launch_bounds__(1024) k_partition_scatter_wc(part_args const* 
     if constexpr (SRC == WC_SRC_DENSE_COLS) {
       // composite dense keys: every key column contributes a digit (value - lo) to the row's mixed-radix index; a row with a
       // NULL key is dropped (null_policy::EXCLUDE); a value outside its sampled range voids the attempt (overflow bit 2)
-      int64_t row[RPT];
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        row[k]  = tile + static_cast<int64_t>(k) * B + threadIdx.x;
-        keep[k] = row[k] < sr.end;
-      }
-      bool inrange[RPT];
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) inrange[k] = keep[k];
-      // the loads of the first two key columns, their validity words, the value and its validity go out before anything is
-      // computed; a third and fourth key column are read one after the other (four columns' worth of rows in registers spilled)
-      // (tried: one wave-wide load of all validity words + cross-lane reads instead of a load per row and mask - 16.0 vs 13.1 ms)
-      constexpr int WIDE = 2;
-      uint64_t raw[WIDE][RPT];
-      uint32_t kmw[WIDE][RPT];
-      int const nk = a.dense.nkeys;
-#pragma unroll
-      for (int c = 0; c < WIDE; ++c) {
-        if (c >= nk) break;
-        device_column const col = p.cols[a.dense.key[c].col];
-        batch_load_bits<RPT>(col, row, inrange, raw[c]);
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-          kmw[c][k] = 0xffffffffu;
-          if (col.mask != nullptr && inrange[k]) kmw[c][k] = gload(col.mask + ((static_cast<int64_t>(col.offset) + row[k]) >> 5));
-        }
-      }
-      device_column const vcol = p.cols[a.dense.value_col];
-      uint64_t vraw[RPT];
-      uint32_t vmw[RPT];
-      batch_load_bits<RPT>(vcol, row, inrange, vraw);
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        vmw[k] = 0xffffffffu;
-        if (vcol.mask != nullptr && inrange[k]) vmw[k] = gload(vcol.mask + ((static_cast<int64_t>(vcol.offset) + row[k]) >> 5));
-      }
-      bool bad = false;
-      uint32_t idx32[RPT];
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) idx32[k] = 0;
-      auto add_digit = [&](dense_key const& dk, int moff, uint64_t rawv, uint32_t mword, int k) {
-        if (!((mword >> ((moff + row[k]) & 31)) & 1u)) keep[k] = false;  // NULL key: the row is dropped (EXCLUDE)
-        int const sh     = 64 - 8 * dk.width;
-        uint64_t const v = dk.is_signed ? static_cast<uint64_t>(static_cast<int64_t>(rawv << sh) >> sh) : rawv;
-        uint64_t dig     = v - dk.lo;
-        if (dig >= dk.range) {
-          bad = bad || keep[k];
-          dig = 0;
-        }
-        idx32[k] += static_cast<uint32_t>(dig) * dk.stride;  // (< 2^30: 32-bit arithmetic)
-      };
-#pragma unroll
-      for (int c = 0; c < WIDE; ++c) {
-        if (c >= nk) break;
-        dense_key const dk = a.dense.key[c];
-        int const moff     = p.cols[dk.col].offset;
-#pragma unroll
-        for (int k = 0; k < RPT; ++k)
-          if (inrange[k]) add_digit(dk, moff, raw[c][k], kmw[c][k], k);
-      }
-      for (int c = WIDE; c < nk; ++c) {
-        dense_key const dk      = a.dense.key[c];
-        device_column const col = p.cols[dk.col];
-        uint64_t r2[RPT];
-        batch_load_bits<RPT>(col, row, inrange, r2);
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-          if (!inrange[k]) continue;
-          uint32_t const mw = col.mask != nullptr ? gload(col.mask + ((static_cast<int64_t>(col.offset) + row[k]) >> 5)) : 0xffffffffu;
-          add_digit(dk, col.offset, r2[k], mw, k);
-        }
-      }
+      uint32_t idx32[RPT], valid[RPT];
+      uint64_t vbits[RPT];
+      bool bad;
+      load_dense_composite<RPT>(p, a.dense, tile, B, sr.end, keep, idx32, valid, vbits, bad);
       if (bad) atomicOr(a.overflow, 4);
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
-        if (!inrange[k]) continue;
-        uint64_t const valid = (vmw[k] >> ((vcol.offset + row[k]) & 31)) & 1u;
-        rec[k][0] = static_cast<uint64_t>(idx32[k]) | (valid << 32);
-        rec[k][1] = to_acc_bits(vraw[k], vcol.cls, vcol.width);
+        rec[k][0] = static_cast<uint64_t>(idx32[k]) | (static_cast<uint64_t>(valid[k]) << 32);
+        rec[k][1] = vbits[k];
       }
     } else if constexpr (SRC == WC_SRC_COLUMNS) {
       int64_t row[RPT];

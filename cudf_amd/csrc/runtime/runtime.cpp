@@ -304,8 +304,8 @@ struct pool_memory_resource::impl {
   struct block {
     void* ptr;
     std::size_t size;
-    hipEvent_t freed;      // recorded on `stream` when the block was returned
-    hipStream_t stream;
+    hipEvent_t freed;      // recorded on `stream` only when ANOTHER stream takes the block (see do_allocate)
+    hipStream_t stream;    // the stream the block was last used on
     uint64_t tick;         // when it was returned (eviction order)
   };
   uint64_t clock{0};
@@ -335,7 +335,10 @@ void pool_memory_resource::trim()
   std::lock_guard<std::mutex> g{_impl->mu};
   for (auto& [sz, v] : _impl->free_lists) {
     for (auto& b : v) {
-      (void)hipEventSynchronize(b.freed);
+      if (hipStreamSynchronize(b.stream) != hipSuccess) {  // (work queued on the block's stream may still use it)
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+      }
       (void)hipEventDestroy(b.freed);
       (void)hipFree(b.ptr);
     }
@@ -365,8 +368,17 @@ void* pool_memory_resource::do_allocate(std::size_t bytes, hipStream_t stream)
       it->second.pop_back();
       _impl->cached -= sz;
       if (b.stream != stream) {
-        auto const e = hipStreamWaitEvent(stream, b.freed, 0);
-        if (e != hipSuccess) cudf::detail::throw_hip_error(e, __FILE__, __LINE__);
+        // The block was returned on another stream: everything queued there up to NOW covers its last use (an event recorded
+        // at the time of the return would do too, but a record per returned block cost 2-5 us on every deallocation of every
+        // call, and blocks almost always come back to the stream that returned them). If that stream is gone, wait for the device.
+        if (hipEventRecord(b.freed, b.stream) == hipSuccess) {
+          auto const e = hipStreamWaitEvent(stream, b.freed, 0);
+          if (e != hipSuccess) cudf::detail::throw_hip_error(e, __FILE__, __LINE__);
+        } else {
+          (void)hipGetLastError();
+          auto const e = hipDeviceSynchronize();
+          if (e != hipSuccess) cudf::detail::throw_hip_error(e, __FILE__, __LINE__);
+        }
       }
       b.stream           = stream;
       _impl->live[b.ptr] = b;
@@ -400,7 +412,6 @@ void pool_memory_resource::do_deallocate(void* p, std::size_t, hipStream_t strea
   auto b   = it->second;
   b.stream = stream;
   _impl->live.erase(it);
-  (void)hipEventRecord(b.freed, stream);
   b.tick = ++_impl->clock;
   _impl->free_lists[b.size].push_back(b);
   _impl->cached += b.size;
@@ -426,7 +437,10 @@ void pool_memory_resource::do_deallocate(void* p, std::size_t, hipStream_t strea
     if (oldest_list == nullptr) break;
     auto const blk = (*oldest_list)[oldest_idx];
     oldest_list->erase(oldest_list->begin() + static_cast<std::ptrdiff_t>(oldest_idx));
-    (void)hipEventSynchronize(blk.freed);
+    if (hipStreamSynchronize(blk.stream) != hipSuccess) {  // (work queued on the block's stream may still use it)
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+    }
     (void)hipEventDestroy(blk.freed);
     (void)hipFree(blk.ptr);
     _impl->cached -= blk.size;

@@ -286,10 +286,13 @@ def test_optimistic_partition_and_its_fallback(G, oracle):
     _check_against_oracle(G, oracle, [k2], [(v, ["sum", "count_all", "max"])], expect_path="PARTITIONED_LDS")
 
 
+@pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("lo,groups,vt", [(0, 1_000_000, "float64"), (-5_000_000_000, 300_000, "int64"), (2**62, 60_000, "float64")])
-def test_dense_keys_direct_address(G, oracle, monkeypatch, lo, groups, vt):
+def test_dense_keys_direct_address(G, oracle, monkeypatch, lo, groups, vt, ring):
     """One plain int64 key column spanning a small range, n >= 4M: direct-address LDS tables (no hash, no probe, keys
-    rebuilt from the slot index). Same call with CUDF_AMD_GB_DENSE=0 must take the hash tables and agree."""
+    rebuilt from the slot index), through the ring scatter (12-byte records in two streams) and through the write-combining
+    scatter (16-byte records). Same call with CUDF_AMD_GB_DENSE=0 must take the hash tables and agree."""
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE_RING", ring)
     rng = np.random.default_rng(71)
     n = 4_500_000
     k = rng.integers(0, groups, n, dtype=np.int64) + lo
@@ -321,9 +324,36 @@ def test_dense_keys_chunked_and_fallbacks(G, oracle, monkeypatch):
     assert G.last_path.name == "PARTITIONED_LDS"
 
 
+@pytest.mark.parametrize("log2p,nsplit,groups", [(4, 16, 40_000), (5, 8, 60_000), (6, 1, 200_000), (7, 2, 500_000), (8, 4, 1_000_000),
+                                                 (9, 1, 1_000_000), (12, 1, 1_000_000), (16, 1, 4_000_000)])
+def test_dense_ring_geometries(G, oracle, monkeypatch, log2p, nsplit, groups):
+    """Ring scatter: every fan-out of one level (16 ... 256 partitions, a partition's regions shared out to 1 ... 16 aggregate
+    workgroups whose table images are merged) and two levels (32 x 16, 64 x 64, 256 x 256)."""
+    rng = np.random.default_rng(1000 + log2p)
+    n = 4_400_000
+    k = rng.integers(0, groups, n, dtype=np.int64) - 123_456_789
+    v = rng.random(n)
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE_LOG2P", str(log2p))
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE_NSPLIT", str(nsplit))
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_valid", "min", "max", "mean"])], expect_path="DENSE_DIRECT")
+
+
+def test_dense_ring_key_outside_the_sampled_range(G, oracle):
+    """One key the sample will not see lies outside the dense range: the ring scatter voids the attempt (overflow bit 2) and the
+    call is redone by hash."""
+    rng = np.random.default_rng(73)
+    n = 5_000_000
+    k = rng.integers(0, 400_000, n, dtype=np.int64)
+    k[n // 3 + 777] = -(10**13)
+    v = rng.random(n)
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all"])], expect_path="PARTITIONED_LDS")
+    assert G.last_path.name == "PARTITIONED_LDS"
+
+
+@pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("two_level", [False, True])
 @pytest.mark.parametrize("shape", ["c4", "narrow", "three_keys"])
-def test_dense_composite_keys(G, oracle, monkeypatch, shape, two_level):
+def test_dense_composite_keys(G, oracle, monkeypatch, shape, two_level, ring):
     """Composite dense keys: 1-4 integer key columns of any width (rows with a NULL key dropped under EXCLUDE), one value
     column of any type with nulls; the record is {mixed-radix index | validity, value}. One partition level, and two levels
     forced (CUDF_AMD_GB_DENSE_LOG2P=11: level 1 on the top 6 bits, level 2 on the next 5). Same call by hash agrees."""
@@ -343,6 +373,7 @@ def test_dense_composite_keys(G, oracle, monkeypatch, shape, two_level):
                 HostColumn(rng.integers(0, 30, n).astype(np.int8), rng.random(n) > 0.05, "int8"),
                 HostColumn(rng.integers(0, 25, n).astype(np.uint32), None, "uint32")]
         vals, kinds = HostColumn(rng.random(n).astype(np.float32), None, "float32"), ["sum", "mean", "min"]
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE_RING", ring)
     if two_level:
         monkeypatch.setenv("CUDF_AMD_GB_DENSE_LOG2P", "11")
     _check_against_oracle(G, oracle, keys, [(vals, kinds)], expect_path="DENSE_DIRECT")
