@@ -161,7 +161,7 @@ __device__ __forceinline__ void dense_store_key_units(dense_map const& m, int KU
     if (u < KU) gstore(o + u, unit[u]);
 }
 
-// SOA: 12-byte records of the ring scatter (value stream + tag stream) instead of 16-byte {key | value} records.
+// SOA: 10-byte records of the ring scatter (value stream + 16-bit tag stream) instead of 16-byte {key | value} records.
 template <uint64_t SIG, int NACCT, bool SOA>
 __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args const* __restrict__ ap, int first_chunk, int last_chunk)
 {
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
   int64_t const rec0  = (static_cast<int64_t>(item) * a.slices + sl0 + r_base) * cap;
   [[maybe_unused]] u64x2 const* recs       = reinterpret_cast<u64x2 const*>(a.records) + rec0;
   [[maybe_unused]] uint64_t const* rec_val = a.rec_val + rec0;
-  [[maybe_unused]] uint32_t const* rec_tag = a.rec_tag + rec0;
+  [[maybe_unused]] uint16_t const* rec_tag = a.rec_tag + rec0;
   int rcur            = 0;  // wave-uniform: first region that may hold the next virtual record
   // record index (relative to `recs`) of virtual record v; v ascends from call to call
   auto locate = [&](int32_t v, bool active) -> int64_t {
@@ -267,9 +267,9 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
   auto accumulate = [&](uint64_t key, uint64_t value) {
     uint32_t s;
     bool val_valid;
-    if constexpr (SOA) {  // key = the record's tag: slot | validity of the value << 31
+    if constexpr (SOA) {  // key = the record's tag: slot | validity of the value << 15
       s         = static_cast<uint32_t>(key) & smask;
-      val_valid = (static_cast<uint32_t>(key) >> 31) != 0;
+      val_valid = (static_cast<uint32_t>(key) >> 15) != 0;
     } else {
       uint32_t const idx = composite ? static_cast<uint32_t>(key) : static_cast<uint32_t>(key - lo);
       val_valid          = !composite || ((key >> 32) & 1u);  // (a single plain key column comes with a plain value column)

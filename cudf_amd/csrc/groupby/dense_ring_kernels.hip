@@ -7,9 +7,10 @@
 // to the partition's region (global record index = region base + virtual position: nothing ever moves inside LDS); a second
 // barrier ends the tile. A row that finds its ring full waits one flush round. Two barriers and ~4 LDS operations per row,
 // against seven barriers and ~8 operations for the rank / scan / stage / write-out / carry-move scatter of
-// common/wc_scatter.hpp. Records leave as two streams - granules of 16 values and of 32 tags, both one whole aligned 128-byte
-// line (the tag ring is twice as long as the value ring so that a partition's tags can wait for their 32) - so a row costs
-// 12 bytes in the record buffer instead of 16: the scatter writes, and the aggregate reads, a quarter less.
+// common/wc_scatter.hpp. Records leave as two streams - granules of 16 values and of 64 16-bit tags (32 32-bit tags on the
+// first of two levels), both one whole aligned 128-byte line (the tag ring is four / two times as long as the value ring so that a
+// partition's tags can wait for their granule) - so a row costs 10 bytes in the record buffer instead of 16 (12 on the first of
+// two levels): the scatter writes, and the aggregate reads, three eighths less.
 // Together with dense_kernels.hip this replaces the reference's global hash-set insert + global atomics
 // (cpp/src/groupby/hash/compute_global_memory_aggs.cuh:74-187, single_pass_functors.cuh:86-157).
 #include "device_common.hpp"
@@ -39,7 +40,9 @@ struct ring_tile<RING_SRC_REGIONS, RPT> {
   uint32_t t[RPT];
 };
 
-template <int SRC, int RPT, int D>
+// TAG: uint16_t for the last level (a table has at most 2^15 slots: slot | validity << 15), uint32_t for the first of two levels
+// (the bits of the scrambled index below its digit | validity << 31).
+template <int SRC, int RPT, int D, typename TAG>
 __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -48,12 +51,15 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
   dense_ring_args const& a = *ap;
   plan_dev const& p        = a.plan;
   constexpr int B          = 1024;
-  constexpr uint32_t G = 16, GT = 32;  // records per value granule / per tag granule
+  constexpr uint32_t G = 16, GT = 128 / sizeof(TAG);  // records per value granule / per tag granule (both 128 bytes)
+  constexpr int TL      = sizeof(TAG) == 2 ? 2 : 1;   // log2(tag ring length / value ring length): 8 bytes of tags per value slot
+  constexpr uint32_t TPL = 16 / sizeof(TAG);          // tags per lane of a flush (16 bytes)
+  constexpr int VBIT    = 8 * sizeof(TAG) - 1;        // validity bit of an output tag
   int const P = a.P, capl = a.capl;
-  uint32_t const CAP = 1u << capl, cmask = CAP - 1u, tcmask = 2u * CAP - 1u;
+  uint32_t const CAP = 1u << capl, cmask = CAP - 1u, tcmask = (CAP << TL) - 1u;
   uint64_t* rval  = reinterpret_cast<uint64_t*>(lds_raw);                      // [P << capl] = DENSE_RING_SLOTS values
-  uint32_t* rtag  = reinterpret_cast<uint32_t*>(rval + DENSE_RING_SLOTS);     // [P << (capl + 1)] tags
-  uint32_t* tail  = rtag + 2 * DENSE_RING_SLOTS;                               // [P] next virtual position
+  TAG* rtag       = reinterpret_cast<TAG*>(rval + DENSE_RING_SLOTS);          // [P << (capl + TL)] tags: 8 * DENSE_RING_SLOTS bytes
+  uint32_t* tail  = reinterpret_cast<uint32_t*>(rval + 2 * DENSE_RING_SLOTS); // [P] next virtual position
   uint32_t* limit = tail + P;                                                  // [P] head + CAP as of the last flush
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
   int const PW = P / nwaves;  // partitions owned by a wave (1 ... 16): owner lane l < PW holds partition wave * PW + l
@@ -104,7 +110,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
   int64_t const region0     = static_cast<int64_t>(seg) * P * a.slices;
   uint32_t const region_cap = static_cast<uint32_t>(a.region_cap);
   uint64_t* const out_val   = a.out_val;
-  uint32_t* const out_tag   = a.out_tag;
+  TAG* const out_tag        = static_cast<TAG*>(a.out_tag);
   [[maybe_unused]] uint64_t const dense_lo = a.map.lo, dense_range = a.map.range;
   [[maybe_unused]] uint32_t const mult = a.map.mult, bmask = (1u << a.map.bits) - 1u;
   int const shift = a.shift;
@@ -175,7 +181,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
         }
       }
     }
-    // tags: 8 lanes per granule (four tags = 16 bytes per lane), 8 partitions per batch
+    // tags: 8 lanes per granule (16 bytes = 4 or 8 tags per lane), 8 partitions per batch
     for (int b = 0; b * 8 < PW; ++b) {
       int const pl = b * 8 + (lane >> 3), sub = lane & 7;
       uint32_t const mr = __shfl(nrect, pl), mh = __shfl(headt, pl);
@@ -183,18 +189,16 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
       int const d       = wave * PW + pl;
       int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
       for (uint32_t g = 0;; ++g) {
-        uint32_t const q = g * GT + sub * 4;
+        uint32_t const q = g * GT + sub * TPL;
         bool const act   = pl < PW && q < mr && !mab;
         if (__ballot(act) == 0) break;
         if (act) {
           uint32_t const pos = mh + q;
-          u32x4 const v      = *reinterpret_cast<u32x4 const*>(rtag + (static_cast<uint32_t>(d) << (capl + 1)) + (pos & tcmask));
-          if (q + 3 < mr) {
-            gstore(reinterpret_cast<u32x4*>(out_tag + rbase + pos), v);
-          } else {
-            gstore(out_tag + rbase + pos, v.x);
-            if (q + 1 < mr) gstore(out_tag + rbase + pos + 1, v.y);
-            if (q + 2 < mr) gstore(out_tag + rbase + pos + 2, v.z);
+          TAG const* src     = rtag + (static_cast<uint32_t>(d) << (capl + TL)) + (pos & tcmask);
+          if (q + TPL <= mr) {
+            gstore(reinterpret_cast<u32x4*>(out_tag + rbase + pos), *reinterpret_cast<u32x4 const*>(src));
+          } else {  // (the partial tail of the final flush)
+            for (uint32_t e = 0; q + e < mr; ++e) gstore(out_tag + rbase + pos + e, src[e]);
           }
         }
       }
@@ -227,7 +231,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
           for (int k = 0; k < RPT; ++k) {
             uint32_t const x = (idx32[k] * mult) & bmask;
             d[k]  = (x >> shift) & pmask;
-            tg[k] = (x & tmask) | (valid[k] << 31);
+            tg[k] = (x & tmask) | (valid[k] << VBIT);
           }
         }
       } else {
@@ -246,11 +250,11 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
               }
               uint32_t const x = (static_cast<uint32_t>(idx) * mult) & bmask;
               d[k]  = (x >> shift) & pmask;
-              tg[k] = (x & tmask) | 0x80000000u;
+              tg[k] = (x & tmask) | (1u << VBIT);
             } else {
               uint32_t const x = pre[j].t[k];
               d[k]  = ((x & 0x7fffffffu) >> shift) & pmask;
-              tg[k] = x & (tmask | 0x80000000u);
+              tg[k] = (x & tmask) | ((x >> 31) << VBIT);
             }
           }
         }
@@ -276,7 +280,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
         if (keep[k] && !pend[k]) {
           uint32_t const w = (d[k] << capl) + (pos[k] & cmask);
           rval[w] = val[k];
-          rtag[(d[k] << (capl + 1)) + (pos[k] & tcmask)] = tg[k];
+          rtag[(d[k] << (capl + TL)) + (pos[k] & tcmask)] = static_cast<TAG>(tg[k]);
         }
         any_pend = any_pend || pend[k];
       }
@@ -296,7 +300,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
             if (static_cast<int32_t>(pos[k] - l2) < 0) {
               uint32_t const w = (d[k] << capl) + (pos[k] & cmask);
               rval[w] = val[k];
-              rtag[(d[k] << (capl + 1)) + (pos[k] & tcmask)] = tg[k];
+              rtag[(d[k] << (capl + TL)) + (pos[k] & tcmask)] = static_cast<TAG>(tg[k]);
               pend[k] = false;
             } else {
               any_pend = true;
@@ -324,19 +328,26 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
   if (lane < PW) a.region_count[region0 + static_cast<int64_t>(wave * PW + lane) * a.slices + item] = static_cast<int32_t>(head);
 }
 
-template <int SRC, int RPT, int D>
-void launch_ring_t(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
+template <int SRC, int RPT, int D, typename TAG>
+void launch_ring_tag(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D, TAG>));
     attr_set = true;
   }
   std::size_t const lds = static_cast<std::size_t>(DENSE_RING_SLOTS) * 16 + static_cast<std::size_t>(a.P) * 8;
   int const items       = a.from_columns ? a.slices : a.nseg * a.slices;
   cudf::detail::prof::scope prof_{a.from_columns ? "partition_scatter" : "partition_scatter_level2", stream};
-  hipLaunchKernelGGL((k_dense_ring_scatter<SRC, RPT, D>), dim3(items), dim3(1024), lds, stream, d_args);
+  hipLaunchKernelGGL((k_dense_ring_scatter<SRC, RPT, D, TAG>), dim3(items), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
+}
+template <int SRC, int RPT, int D>
+void launch_ring_t(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
+{
+  if (a.tag16) return launch_ring_tag<SRC, RPT, D, uint16_t>(a, d_args, stream);
+  if constexpr (SRC != RING_SRC_REGIONS) return launch_ring_tag<SRC, RPT, D, uint32_t>(a, d_args, stream);
+  CUDF_FAIL("ring scatter: the last level writes 16-bit tags");
 }
 
 }  // namespace
@@ -351,7 +362,7 @@ void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* 
 {
   CUDF_EXPECTS(a.P >= 16 && a.P <= 256 && (a.P & (a.P - 1)) == 0 && (a.P << a.capl) == DENSE_RING_SLOTS && a.capl >= 5,
                "ring scatter: fan-out 16 ... 256, rings of at least two granules");
-  CUDF_EXPECTS(a.region_cap % 32 == 0 && a.shift >= 0 && a.shift < 31 && a.slices >= 1, "ring scatter: region geometry");
+  CUDF_EXPECTS(a.region_cap % 64 == 0 && a.shift >= 0 && a.shift < 31 && a.slices >= 1 && (!a.tag16 || a.shift <= 15), "ring scatter: region geometry");
   if (a.from_columns) {
     if (a.map.nkeys > 0) return launch_ring_t<RING_SRC_COLS, 4, 1>(a, d_args, stream);
     CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1, "ring scatter: one plain key column and one plain value column");

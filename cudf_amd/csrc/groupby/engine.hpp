@@ -280,10 +280,10 @@ struct dense_agg_args {
   plan_dev plan;
   dense_map map;
   uint64_t const* records;
-  // 12-byte records of the ring scatter (dense_ring_args), two streams per region: rec_val[i] = the value, rec_tag[i] = table slot
-  // (low bits) | validity of the value (bit 31). rec_tag == nullptr: 16-byte {key or index | validity, value} records in `records`.
+  // 10-byte records of the ring scatter (dense_ring_args), two streams per region: rec_val[i] = the value, rec_tag[i] = table slot
+  // (low bits) | validity of the value (bit 15). rec_tag == nullptr: 16-byte {key or index | validity, value} records in `records`.
   uint64_t const* rec_val;
-  uint32_t const* rec_tag;
+  uint16_t const* rec_tag;
   // nsplit > 1: a partition's regions are shared out to nsplit workgroups (work item = partition * nsplit + h takes the regions
   // [h * slices / nsplit, (h + 1) * slices / nsplit)); every workgroup leaves its table image in `tables` and
   // launch_dense_merge_dump folds the nsplit images of a partition into the partial records.
@@ -312,9 +312,9 @@ void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t str
 void launch_dense_merge_dump(dense_agg_args const& a, dense_agg_args const* d_args, int dsplit, hipStream_t stream);
 
 // Ring scatter of dense-key rows (dense_ring_kernels.hip): every partition owns a ring of record slots in LDS, a row reserves its
-// position with one returning LDS atomic, and only whole aligned 128-byte granules (16 values, 32 tags) leave the
-// workgroup - two barriers per tile. Records are 12 bytes in two streams per region: value (8 B) and tag (4 B: the bits of the
-// scrambled index below this level's digit | validity of the value in bit 31). Level 1 reads the input columns (workgroup w
+// position with one returning LDS atomic, and only whole aligned 128-byte granules (16 values, 64 or 32 tags) leave the
+// workgroup - two barriers per tile. Records are two streams per region: value (8 B) and tag (the bits of the scrambled index
+// below this level's digit | validity of the value in the top bit: 2 B on the last level, 4 B on the first of two). Level 1 reads the input columns (workgroup w
 // takes the row tiles w, w + slices, ...), level 2 reads level-1 partition g as the strided list of its regions
 // s, s + slices, ... (work item g * slices + s) and writes the regions of the global partitions g * P + d.
 // Region (q, w) of an output with S slices lies at [(q * S + w) * region_cap, + region_count[q * S + w]) of both streams.
@@ -334,8 +334,9 @@ struct dense_ring_args {
   int64_t in_region_cap;
   int32_t in_slices;
   uint64_t* out_val;
-  uint32_t* out_tag;
-  int64_t region_cap;  // a multiple of 32 records
+  void* out_tag;       // uint16_t (tag16) or uint32_t per record
+  int32_t tag16;       // the last level: 16-bit tags = table slot | validity << 15; else 32-bit: low index bits | validity << 31
+  int64_t region_cap;  // a multiple of 64 records
   int32_t* region_count;
   int32_t* overflow;   // bit 0: a region overflowed; bit 2: a key outside the dense range
 };

@@ -969,7 +969,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
             auto region_cap_for = [&](double mean, double parts) {
               double const keys_per_p = std::max(1.0, 0.5 * est_groups / parts);
               double const rel_sigma  = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, mean));
-              return (static_cast<int64_t>(mean * (1.0 + 6.0 * std::min(rel_sigma, 1.0)) + 32.0) + 31) / 32 * 32;
+              return (static_cast<int64_t>(mean * (1.0 + 6.0 * std::min(rel_sigma, 1.0)) + 64.0) + 63) / 64 * 64;
             };
             // (workgroup w takes the 4096-row tiles w, w + S, ...: the busiest workgroup has ceil(tiles / S) of them)
             int64_t const ring_tile = 4 * 1024, wg_rows = std::min<int64_t>(n, ((n + ring_tile - 1) / ring_tile + S - 1) / S * ring_tile);
@@ -988,14 +988,15 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
             ra.region_count = sc.alloc<int32_t>(static_cast<size_t>(S * PD));
             ra.overflow     = d_overflow;
             ra.out_val      = sc.alloc<uint64_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR));
-            ra.out_tag      = sc.alloc<uint32_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR));
+            ra.tag16        = two_level ? 0 : 1;
+            ra.out_tag      = sc.alloc<uint16_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR) * (two_level ? 2 : 1));
             dense_ring_args* d_ra = sc.alloc<dense_ring_args>(1);
             store_args(ra, d_ra, s);
             dense_agg_args da{};
             da.plan         = p;
             da.map          = dm;
             da.rec_val      = ra.out_val;
-            da.rec_tag      = ra.out_tag;
+            da.rec_tag      = static_cast<uint16_t const*>(ra.out_tag);
             da.region_count = ra.region_count;
             da.region_cap   = capR;
             da.slices       = static_cast<int32_t>(S);
@@ -1016,18 +1017,19 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
               rb.slices          = static_cast<int32_t>(slices2);
               rb.nseg            = static_cast<int32_t>(PD);
               rb.in_val          = ra.out_val;
-              rb.in_tag          = ra.out_tag;
+              rb.in_tag          = static_cast<uint32_t const*>(ra.out_tag);
               rb.in_region_count = ra.region_count;
               rb.in_region_cap   = capR;
               rb.in_slices       = static_cast<int32_t>(S);
               rb.region_cap      = cap2;
               rb.region_count    = sc.alloc<int32_t>(nreg2);
               rb.out_val         = sc.alloc<uint64_t>(nreg2 * static_cast<size_t>(cap2));
-              rb.out_tag         = sc.alloc<uint32_t>(nreg2 * static_cast<size_t>(cap2));
+              rb.tag16           = 1;
+              rb.out_tag         = sc.alloc<uint16_t>(nreg2 * static_cast<size_t>(cap2));
               d_rb               = sc.alloc<dense_ring_args>(1);
               store_args(rb, d_rb, s);
               da.rec_val      = rb.out_val;
-              da.rec_tag      = rb.out_tag;
+              da.rec_tag      = static_cast<uint16_t const*>(rb.out_tag);
               da.region_count = rb.region_count;
               da.region_cap   = cap2;
               da.slices       = static_cast<int32_t>(slices2);
