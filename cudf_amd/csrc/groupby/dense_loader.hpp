@@ -17,69 +17,80 @@ namespace {
 template <int RPT>
 struct dense_raw_tile {
   static constexpr int WIDE = 2;
-  int64_t tile;
-  int64_t end;
   uint64_t raw[WIDE][RPT];
   uint32_t kmw[WIDE][RPT];
   uint64_t vraw[RPT];
   uint32_t vmw[RPT];
 };
 
-template <int RPT>
+// raw element bits of one row of a column (zero-extended); the width test is wave-uniform
+__device__ __forceinline__ uint64_t load_bits_row(device_column const& col, int64_t row)
+{
+  int64_t const at = col.offset + row;
+  switch (col.width) {
+    case 1: return gload(static_cast<uint8_t const*>(col.head) + at);
+    case 2: return gload(static_cast<uint16_t const*>(col.head) + at);
+    case 4: return gload(static_cast<uint32_t const*>(col.head) + at);
+    default: return gload(static_cast<uint64_t const*>(col.head) + at);
+  }
+}
+
+// Rows K0 <= k < K1 of the tile only: a caller that decodes one half of a tile and at once issues the same half of the tile after
+// next keeps loads in flight through the decode phase without a second set of registers.
+template <int RPT, int K0 = 0, int K1 = RPT>
 __device__ __forceinline__ void issue_dense_composite(plan_dev const& p, dense_map const& dm, int64_t tile, int B, int64_t end,
                                                       dense_raw_tile<RPT>& t)
 {
   constexpr int WIDE = dense_raw_tile<RPT>::WIDE;
-  t.tile = tile;
-  t.end  = end;
-  int64_t row[RPT];
-  bool inrange[RPT];
-#pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    row[k]     = tile + static_cast<int64_t>(k) * B + threadIdx.x;
-    inrange[k] = row[k] < end;
-  }
   int const nk = dm.nkeys;
 #pragma unroll
   for (int c = 0; c < WIDE; ++c) {
     if (c >= nk) break;
     device_column const col = p.cols[dm.key[c].col];
-    batch_load_bits<RPT>(col, row, inrange, t.raw[c]);
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      t.kmw[c][k] = 0xffffffffu;
-      if (col.mask != nullptr && inrange[k]) t.kmw[c][k] = gload(col.mask + ((static_cast<int64_t>(col.offset) + row[k]) >> 5));
+    for (int k = K0; k < K1; ++k) {
+      int64_t const row = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+      t.raw[c][k]       = 0;
+      t.kmw[c][k]       = 0xffffffffu;
+      if (row < end) {
+        t.raw[c][k] = load_bits_row(col, row);
+        if (col.mask != nullptr) t.kmw[c][k] = gload(col.mask + ((static_cast<int64_t>(col.offset) + row) >> 5));
+      }
     }
   }
   device_column const vcol = p.cols[dm.value_col];
-  batch_load_bits<RPT>(vcol, row, inrange, t.vraw);
 #pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    t.vmw[k] = 0xffffffffu;
-    if (vcol.mask != nullptr && inrange[k]) t.vmw[k] = gload(vcol.mask + ((static_cast<int64_t>(vcol.offset) + row[k]) >> 5));
+  for (int k = K0; k < K1; ++k) {
+    int64_t const row = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+    t.vraw[k]         = 0;
+    t.vmw[k]          = 0xffffffffu;
+    if (row < end) {
+      t.vraw[k] = load_bits_row(vcol, row);
+      if (vcol.mask != nullptr) t.vmw[k] = gload(vcol.mask + ((static_cast<int64_t>(vcol.offset) + row) >> 5));
+    }
   }
 }
 
 // keep[k]: the row exists and no key of it is NULL; idx32: the mixed-radix index of its key; valid / vbits: validity of its value
 // and the value as its 8-byte accumulator class; bad: some key of a kept row lay outside its sampled range (the attempt is
 // void: overflow bit 2).
-template <int RPT>
-__device__ __forceinline__ void decode_dense_composite(plan_dev const& p, dense_map const& dm, int B, dense_raw_tile<RPT> const& t,
-                                                       bool (&keep)[RPT], uint32_t (&idx32)[RPT], uint32_t (&valid)[RPT],
-                                                       uint64_t (&vbits)[RPT], bool& bad)
+// (bad is OR-ed into: the caller clears it before the first part of a tile)
+template <int RPT, int K0 = 0, int K1 = RPT>
+__device__ __forceinline__ void decode_dense_composite(plan_dev const& p, dense_map const& dm, int64_t tile, int B, int64_t end,
+                                                       dense_raw_tile<RPT> const& t, bool (&keep)[RPT], uint32_t (&idx32)[RPT],
+                                                       uint32_t (&valid)[RPT], uint64_t (&vbits)[RPT], bool& bad)
 {
   constexpr int WIDE = dense_raw_tile<RPT>::WIDE;
   int64_t row[RPT];
   bool inrange[RPT];
 #pragma unroll
-  for (int k = 0; k < RPT; ++k) {
-    row[k]     = t.tile + static_cast<int64_t>(k) * B + threadIdx.x;
-    keep[k]    = row[k] < t.end;
+  for (int k = K0; k < K1; ++k) {
+    row[k]     = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+    keep[k]    = row[k] < end;
     inrange[k] = keep[k];
     idx32[k]   = 0;
   }
   int const nk = dm.nkeys;
-  bad          = false;
   auto add_digit = [&](dense_key const& dk, int moff, uint64_t rawv, uint32_t mword, int k) {
     if (!((mword >> ((moff + row[k]) & 31)) & 1u)) keep[k] = false;  // NULL key: the row is dropped (EXCLUDE)
     int const sh     = 64 - 8 * dk.width;
@@ -97,16 +108,17 @@ __device__ __forceinline__ void decode_dense_composite(plan_dev const& p, dense_
     dense_key const dk = dm.key[c];
     int const moff     = p.cols[dk.col].offset;
 #pragma unroll
-    for (int k = 0; k < RPT; ++k)
+    for (int k = K0; k < K1; ++k)
       if (inrange[k]) add_digit(dk, moff, t.raw[c][k], t.kmw[c][k], k);
   }
   for (int c = WIDE; c < nk; ++c) {
     dense_key const dk      = dm.key[c];
     device_column const col = p.cols[dk.col];
     uint64_t r2[RPT];
-    batch_load_bits<RPT>(col, row, inrange, r2);
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
+    for (int k = K0; k < K1; ++k) r2[k] = inrange[k] ? load_bits_row(col, row[k]) : 0;
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
       if (!inrange[k]) continue;
       uint32_t const mw = col.mask != nullptr ? gload(col.mask + ((static_cast<int64_t>(col.offset) + row[k]) >> 5)) : 0xffffffffu;
       add_digit(dk, col.offset, r2[k], mw, k);
@@ -114,12 +126,149 @@ __device__ __forceinline__ void decode_dense_composite(plan_dev const& p, dense_
   }
   device_column const vcol = p.cols[dm.value_col];
 #pragma unroll
-  for (int k = 0; k < RPT; ++k) {
+  for (int k = K0; k < K1; ++k) {
     valid[k] = 0;
     vbits[k] = 0;
     if (!inrange[k]) continue;
     valid[k] = (t.vmw[k] >> ((vcol.offset + row[k]) & 31)) & 1u;
     vbits[k] = to_acc_bits(t.vraw[k], vcol.cls, vcol.width);
+  }
+}
+
+// ---- the same loader with the descriptors of the first two key columns and of the value column resolved ONCE into locals
+// (wave-uniform: scalar registers): read through the plan pointer they were re-fetched after every barrier (the barrier's memory
+// clobber), 99 scalar instructions per row against 32 on the plain path. Loads are unconditional - a row past the end reads the
+// last row, a column without a validity mask reads word 0 of an all-ones dummy - so that a tile's loads go out back to back.
+struct dense_col_local {
+  unsigned char const* head;  // element (offset + row) at head + (offset + row) * width
+  uint32_t const* mask;       // validity words; the all-ones dummy if the column has none
+  int64_t offset;
+  int64_t mask_on;            // -1: the column has a mask, 0: it has none (word index & mask_on)
+  int32_t width;
+};
+struct dense_local {
+  dense_col_local kc[2], vc;
+  uint64_t lo[2];
+  uint32_t range[2], stride[2];
+  int32_t sh[2];  // 64 - 8 * width
+  bool is_signed[2];
+  int32_t nk, vcls;
+};
+__device__ __forceinline__ dense_col_local make_col_local(device_column const& c, uint32_t const* ones)
+{
+  dense_col_local l;
+  l.head    = static_cast<unsigned char const*>(c.head);
+  l.mask    = c.mask != nullptr ? c.mask : ones;
+  l.offset  = c.offset;
+  l.mask_on = c.mask != nullptr ? int64_t{-1} : int64_t{0};
+  l.width   = c.width;
+  return l;
+}
+__device__ __forceinline__ dense_local make_dense_local(plan_dev const& p, dense_map const& dm, uint32_t const* ones)
+{
+  dense_local L;
+  L.nk = dm.nkeys;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    dense_key const dk = dm.key[c < dm.nkeys ? c : 0];
+    L.kc[c]        = make_col_local(p.cols[dk.col], ones);
+    L.lo[c]        = dk.lo;
+    L.range[c]     = dk.range;
+    L.stride[c]    = c < dm.nkeys ? dk.stride : 0;  // (a missing second key contributes nothing)
+    L.sh[c]        = 64 - 8 * dk.width;
+    L.is_signed[c] = dk.is_signed != 0;
+  }
+  L.vc   = make_col_local(p.cols[dm.value_col], ones);
+  L.vcls = p.cols[dm.value_col].cls;
+  return L;
+}
+template <int RPT>
+__device__ __forceinline__ void load_col_local(dense_col_local const& c, int64_t const (&rowc)[RPT], uint64_t (&bits)[RPT], uint32_t (&mw)[RPT])
+{
+  switch (c.width) {
+    case 1:
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) bits[k] = gload(c.head + c.offset + rowc[k]);
+      break;
+    case 2:
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) bits[k] = gload(reinterpret_cast<uint16_t const*>(c.head) + c.offset + rowc[k]);
+      break;
+    case 4:
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) bits[k] = gload(reinterpret_cast<uint32_t const*>(c.head) + c.offset + rowc[k]);
+      break;
+    default:
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) bits[k] = gload(reinterpret_cast<uint64_t const*>(c.head) + c.offset + rowc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) mw[k] = gload(c.mask + (((c.offset + rowc[k]) >> 5) & c.mask_on));
+}
+template <int RPT>
+__device__ __forceinline__ void issue_dense_local(dense_local const& L, int64_t tile, int B, int64_t end, dense_raw_tile<RPT>& t)
+{
+  int64_t rowc[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) rowc[k] = min(tile + static_cast<int64_t>(k) * B + threadIdx.x, end - 1);
+  load_col_local<RPT>(L.kc[0], rowc, t.raw[0], t.kmw[0]);
+  if (L.nk > 1) load_col_local<RPT>(L.kc[1], rowc, t.raw[1], t.kmw[1]);
+  load_col_local<RPT>(L.vc, rowc, t.vraw, t.vmw);
+}
+template <int RPT>
+__device__ __forceinline__ void decode_dense_local(plan_dev const& p, dense_map const& dm, dense_local const& L, int64_t tile, int B,
+                                                   int64_t end, dense_raw_tile<RPT> const& t, bool (&keep)[RPT], uint32_t (&idx32)[RPT],
+                                                   uint32_t (&valid)[RPT], uint64_t (&vbits)[RPT], bool& bad)
+{
+  int64_t row[RPT];
+  bool inrange[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    row[k]     = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+    inrange[k] = row[k] < end;
+    keep[k]    = inrange[k];
+    idx32[k]   = 0;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c >= L.nk) break;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      uint32_t const bit = (t.kmw[c][k] >> ((L.kc[c].offset + row[k]) & 31)) & 1u;
+      uint64_t const raw = t.raw[c][k];
+      uint64_t const v   = L.is_signed[c] ? static_cast<uint64_t>(static_cast<int64_t>(raw << L.sh[c]) >> L.sh[c]) : raw;
+      uint64_t const dig = v - L.lo[c];
+      bool const out     = dig >= L.range[c];
+      keep[k]            = keep[k] && bit != 0;  // NULL key: the row is dropped (EXCLUDE)
+      bad                = bad || (out && keep[k]);
+      idx32[k] += out ? 0u : static_cast<uint32_t>(dig) * L.stride[c];  // (< 2^30: 32-bit arithmetic)
+    }
+  }
+  if (L.nk > 2) {  // a third and fourth key column: read here, one after the other
+    for (int c = 2; c < L.nk; ++c) {
+      dense_key const dk      = dm.key[c];
+      device_column const col = p.cols[dk.col];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        if (!inrange[k]) continue;
+        uint64_t const rawv = load_bits_row(col, row[k]);
+        uint32_t const mw   = col.mask != nullptr ? gload(col.mask + ((static_cast<int64_t>(col.offset) + row[k]) >> 5)) : 0xffffffffu;
+        if (!((mw >> ((col.offset + row[k]) & 31)) & 1u)) keep[k] = false;
+        int const sh     = 64 - 8 * dk.width;
+        uint64_t const v = dk.is_signed ? static_cast<uint64_t>(static_cast<int64_t>(rawv << sh) >> sh) : rawv;
+        uint64_t dig     = v - dk.lo;
+        if (dig >= dk.range) {
+          bad = bad || keep[k];
+          dig = 0;
+        }
+        idx32[k] += static_cast<uint32_t>(dig) * dk.stride;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    valid[k] = inrange[k] ? (t.vmw[k] >> ((L.vc.offset + row[k]) & 31)) & 1u : 0u;
+    vbits[k] = to_acc_bits(t.vraw[k], L.vcls, L.vc.width);
   }
 }
 
@@ -130,7 +279,8 @@ __device__ __forceinline__ void load_dense_composite(plan_dev const& p, dense_ma
 {
   dense_raw_tile<RPT> t;
   issue_dense_composite<RPT>(p, dm, tile, B, end, t);
-  decode_dense_composite<RPT>(p, dm, B, t, keep, idx32, valid, vbits, bad);
+  bad = false;
+  decode_dense_composite<RPT>(p, dm, tile, B, end, t, keep, idx32, valid, vbits, bad);
 }
 
 }  // namespace

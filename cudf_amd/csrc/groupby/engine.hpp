@@ -339,6 +339,7 @@ struct dense_ring_args {
   int64_t region_cap;  // a multiple of 64 records
   int32_t* region_count;
   int32_t* overflow;   // bit 0: a region overflowed; bit 2: a key outside the dense range
+  uint32_t const* ones;  // composite keys: one all-ones word, read in place of the validity word of a column without a mask
 };
 constexpr int DENSE_RING_SLOTS = 8192;  // value-ring slots of a workgroup (all partitions); the tag rings are twice as long: 128 KiB of LDS
 void store_args(dense_ring_args const& a, dense_ring_args* d_args, hipStream_t stream);

@@ -990,6 +990,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
             ra.out_val      = sc.alloc<uint64_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR));
             ra.tag16        = two_level ? 0 : 1;
             ra.out_tag      = sc.alloc<uint16_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR) * (two_level ? 2 : 1));
+            if (dm.nkeys > 0) {
+              uint32_t* ones = sc.alloc<uint32_t>(16);
+              CUDF_HIP_TRY(hipMemsetAsync(ones, 0xff, 64, s));
+              ra.ones = ones;
+            }
             dense_ring_args* d_ra = sc.alloc<dense_ring_args>(1);
             store_args(ra, d_ra, s);
             dense_agg_args da{};
