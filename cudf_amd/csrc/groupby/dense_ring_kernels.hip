@@ -120,13 +120,14 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
   [[maybe_unused]] uint64_t const* kbase = p.simple_base[0];
   [[maybe_unused]] uint64_t const* vbase = p.simple_base[1];
 
-  auto record_of = [&](int64_t v) -> int64_t {  // virtual row of the region list -> record index (binary search in s_pre)
-    int lo = 0, hi = nreg;
-    while (hi - lo > 1) {
-      int const mid = (lo + hi) >> 1;
-      if (s_pre[mid] <= v) lo = mid; else hi = mid;
-    }
-    return rfirst + static_cast<int64_t>(lo) * rstride + (v - s_pre[lo]);
+  // virtual row of the region list -> record index. A thread's rows ascend from tile to tile, so the listed region of its k-th
+  // row only moves forward: a hint per k and a walk of usually zero steps (a binary search per row: five dependent LDS reads).
+  [[maybe_unused]] int reg_hint[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) reg_hint[k] = 0;
+  auto record_of = [&](int64_t v, int& reg) -> int64_t {
+    while (reg + 1 < nreg && s_pre[reg + 1] <= v) ++reg;
+    return rfirst + static_cast<int64_t>(reg) * rstride + (v - s_pre[reg]);
   };
   [[maybe_unused]] dense_local const L = SRC == RING_SRC_COLS ? make_dense_local(p, a.map, a.ones) : dense_local{};
   auto issue = [&](int64_t tile, ring_tile<SRC, RPT>& r) {
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
             r.k[k] = gload(kbase + row);
             r.v[k] = gload(vbase + row);
           } else {
-            int64_t const ri = record_of(row);
+            int64_t const ri = record_of(row, reg_hint[k]);
             r.v[k]           = gload(a.in_val + ri);
             r.t[k]           = gload(a.in_tag + ri);
           }
