@@ -44,11 +44,15 @@ struct ring_tile<RING_SRC_REGIONS, RPT> {
 
 // TAG: uint16_t for the last level (a table has at most 2^15 slots: slot | validity << 15), uint32_t for the first of two levels
 // (the bits of the scrambled index below its digit | validity << 31).
-template <int SRC, int RPT, int D, typename TAG>
+// HOT: heavy-hitter keys are aggregated in a small LDS table behind the rings and leave the scatter (a key with percents of the
+// rows would overflow its partition's regions and leave one aggregate workgroup with its rows alone).
+template <int SRC, int RPT, int D, typename TAG, bool HOT = false>
 __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args const* __restrict__ ap)
 {
+  static_assert(!HOT || SRC == RING_SRC_SIMPLE, "heavy hitters: one plain key column and one plain value column");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int s_pending, s_abort;
+  __shared__ uint32_t s_hot_dumped;
   __shared__ int32_t s_pre[MAX_REGION_LIST + 1];
   dense_ring_args const& a = *ap;
   plan_dev const& p        = a.plan;
@@ -72,8 +76,29 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
     limit[d] = CAP;
   }
   if (threadIdx.x == 0) {
-    s_pending = 0;
-    s_abort   = 0;
+    s_pending    = 0;
+    s_abort      = 0;
+    s_hot_dumped = 0;
+  }
+  // ---- heavy hitters: open-addressing table [HOT_SLOTS] of key / sum / count behind the rings and their counters
+  constexpr uint64_t HOT_EMPTY = ~uint64_t{0};
+  [[maybe_unused]] uint64_t* hkeys = reinterpret_cast<uint64_t*>(lds_raw + static_cast<std::size_t>(DENSE_RING_SLOTS) * 16 + 2048);
+  [[maybe_unused]] uint64_t* hsum  = hkeys + HOT_SLOTS;
+  [[maybe_unused]] uint32_t* hcnt  = reinterpret_cast<uint32_t*>(hsum + HOT_SLOTS);
+  [[maybe_unused]] bool hot_float  = false;
+  if constexpr (HOT) {
+    for (int q = 0; q < p.NACC; ++q) hot_float = hot_float || p.acc[q].op == ADD_F64;
+    for (int t = threadIdx.x; t < HOT_SLOTS; t += B) {
+      hkeys[t] = HOT_EMPTY;
+      hsum[t]  = 0;
+      hcnt[t]  = 0;
+    }
+    __syncthreads();
+    if (static_cast<int>(threadIdx.x) < a.hot_n) {
+      uint64_t const key = a.hot_keys[threadIdx.x];
+      uint32_t slot      = static_cast<uint32_t>(mix64(0x9e3779b97f4a7c15ull ^ key) >> 20) & (HOT_SLOTS - 1);
+      while (atomicCAS(reinterpret_cast<unsigned long long*>(hkeys + slot), HOT_EMPTY, key) != HOT_EMPTY) slot = (slot + 1) & (HOT_SLOTS - 1);
+    }
   }
   // ---- this work item's rows and output regions
   constexpr int64_t T = static_cast<int64_t>(B) * RPT;
@@ -248,6 +273,24 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
           d[k]    = 0;
           tg[k]   = 0;
           val[k]  = pre[j].v[k];
+          if constexpr (HOT) {  // a heavy hitter is accumulated here and leaves the scatter
+            if (keep[k]) {
+              uint64_t const key = pre[j].k[k];
+              uint32_t slot      = static_cast<uint32_t>(mix64(0x9e3779b97f4a7c15ull ^ key) >> 20) & (HOT_SLOTS - 1);
+              for (;;) {
+                uint64_t const kk = hkeys[slot];
+                if (kk == key) {
+                  if (hot_float) atomicAdd(reinterpret_cast<double*>(hsum + slot), __longlong_as_double(static_cast<long long>(val[k])));
+                  else atomicAdd(reinterpret_cast<unsigned long long*>(hsum + slot), static_cast<unsigned long long>(val[k]));
+                  atomicAdd(hcnt + slot, 1u);
+                  keep[k] = false;
+                  break;
+                }
+                if (kk == HOT_EMPTY) break;
+                slot = (slot + 1) & (HOT_SLOTS - 1);
+              }
+            }
+          }
           if (keep[k]) {
             if constexpr (SRC == RING_SRC_SIMPLE) {
               uint64_t idx = pre[j].k[k] - dense_lo;
@@ -333,20 +376,34 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
     return;
   }
   if (lane < PW) a.region_count[region0 + static_cast<int64_t>(wave * PW + lane) * a.slices + item] = static_cast<int32_t>(head);
+  if constexpr (HOT) {  // this workgroup's heavy-hitter partials: [key | accumulators in plan order]
+    int const PU  = 1 + p.NACC;
+    uint64_t* out = a.hot_out + static_cast<int64_t>(blockIdx.x) * HOT_SLOTS * PU;
+    for (int t = threadIdx.x; t < HOT_SLOTS; t += B) {
+      if (hcnt[t] == 0) continue;
+      uint32_t const at = atomicAdd(&s_hot_dumped, 1u);
+      gstore(out + static_cast<int64_t>(at) * PU, hkeys[t]);
+      for (int q = 0; q < p.NACC; ++q)
+        gstore(out + static_cast<int64_t>(at) * PU + 1 + q, p.acc[q].src == SRC_VALUE ? hsum[t] : static_cast<uint64_t>(hcnt[t]));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.hot_count[blockIdx.x] = static_cast<int32_t>(s_hot_dumped);
+  }
 }
 
-template <int SRC, int RPT, int D, typename TAG>
+template <int SRC, int RPT, int D, typename TAG, bool HOT = false>
 void launch_ring_tag(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
 {
   static bool attr_set = false;
   if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D, TAG>));
+    allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D, TAG, HOT>));
     attr_set = true;
   }
-  std::size_t const lds = static_cast<std::size_t>(DENSE_RING_SLOTS) * 16 + static_cast<std::size_t>(a.P) * 8;
+  // rings (values + tags), 2 KiB for the ring counters of up to 256 partitions, then the heavy-hitter table
+  std::size_t const lds = static_cast<std::size_t>(DENSE_RING_SLOTS) * 16 + 2048 + (HOT ? static_cast<std::size_t>(HOT_SLOTS) * (8 + 8 + 4) : 0);
   int const items       = a.from_columns ? a.slices : a.nseg * a.slices;
   cudf::detail::prof::scope prof_{a.from_columns ? "partition_scatter" : "partition_scatter_level2", stream};
-  hipLaunchKernelGGL((k_dense_ring_scatter<SRC, RPT, D, TAG>), dim3(items), dim3(1024), lds, stream, d_args);
+  hipLaunchKernelGGL((k_dense_ring_scatter<SRC, RPT, D, TAG, HOT>), dim3(items), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 template <int SRC, int RPT, int D>
@@ -367,6 +424,7 @@ void store_args(dense_ring_args const& a, dense_ring_args* d_args, hipStream_t s
 
 void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
 {
+  CUDF_EXPECTS(a.hot_n == 0 || a.from_columns, "ring scatter: heavy hitters are taken out on the first level");
   CUDF_EXPECTS(a.P >= 16 && a.P <= 256 && (a.P & (a.P - 1)) == 0 && (a.P << a.capl) == DENSE_RING_SLOTS && a.capl >= 5,
                "ring scatter: fan-out 16 ... 256, rings of at least two granules");
   CUDF_EXPECTS(a.region_cap % 64 == 0 && a.shift >= 0 && a.shift < 31 && a.slices >= 1 && (!a.tag16 || a.shift <= 15), "ring scatter: region geometry");
@@ -380,6 +438,10 @@ void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* 
       return launch_ring_t<RING_SRC_COLS, 4, 1>(a, d_args, stream);
     }
     CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1, "ring scatter: one plain key column and one plain value column");
+    if (a.hot_n > 0) {
+      CUDF_EXPECTS(a.tag16 && a.hot_n <= HOT_MAX_KEYS, "ring scatter: heavy hitters on a single level");
+      return launch_ring_tag<RING_SRC_SIMPLE, 4, 2, uint16_t, true>(a, d_args, stream);
+    }
     return launch_ring_t<RING_SRC_SIMPLE, 4, 2>(a, d_args, stream);
   }
   CUDF_EXPECTS((a.in_slices + a.slices - 1) / a.slices <= MAX_REGION_LIST, "ring scatter: region list too long");

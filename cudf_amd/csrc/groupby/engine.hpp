@@ -340,6 +340,14 @@ struct dense_ring_args {
   int32_t* region_count;
   int32_t* overflow;   // bit 0: a region overflowed; bit 2: a key outside the dense range
   uint32_t const* ones;  // composite keys: one all-ones word, read in place of the validity word of a column without a mask
+  // Heavy hitters (one plain key, SUM / COUNT plans: hot_plan_ok): rows whose key is one of hot_keys[0 .. hot_n) are aggregated
+  // (SUM of the value, row COUNT) in an LDS table of HOT_SLOTS entries behind the rings and never scattered; workgroup w writes
+  // its non-empty entries as partial records [key | accumulators in plan order] to hot_out[w * HOT_SLOTS ...], their number to
+  // hot_count[w] (the same hand-over as part_args::hot_*).
+  int32_t hot_n;
+  uint64_t const* hot_keys;
+  uint64_t* hot_out;
+  int32_t* hot_count;
 };
 constexpr int DENSE_RING_SLOTS = 8192;  // value-ring slots of a workgroup (all partitions); the tag rings are twice as long: 128 KiB of LDS
 void store_args(dense_ring_args const& a, dense_ring_args* d_args, hipStream_t stream);

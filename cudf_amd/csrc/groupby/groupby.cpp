@@ -888,7 +888,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     } else {
       // ---------------- path D: dense integer keys -> direct-address LDS tables (no hash, no probe, no key words)
       final_cap = 0;
-      if (allow_dense && forced_p == 0 && hot_keys.empty() && !forced_exact) {
+      // (heavy hitters in the sample: only the single-level ring scatter of one plain key takes them out of the partition)
+      bool const ring_env = env_i64("CUDF_AMD_GB_DENSE_RING", 1) != 0 && env_i64("CUDF_AMD_GB_CHUNKED", 0) == 0;
+      if (allow_dense && forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !forced_exact) {
         dense_map dm{};
         bool dense_ok = false;
         if (dense_candidate) {
@@ -945,7 +947,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         // ---- ring scatter (dense_ring_kernels.hip): 12-byte records in two streams, one or two levels of fan-out 16 ... 256, the
         // largest tables that fit (one 1024-thread aggregate workgroup per CU; a partition's regions are shared out to several
         // workgroups when there are fewer partitions than CUs)
-        if (dense_ok && env_i64("CUDF_AMD_GB_DENSE_RING", 1) != 0 && env_i64("CUDF_AMD_GB_CHUNKED", 0) == 0) {
+        if (dense_ok && ring_env) {
           int rlog2P = 7;
           while (rlog2P < 17 && dense_table_bytes(p, 1 << std::max(bits - rlog2P, 0)) > 150 * 1024) ++rlog2P;
           if (env_i64("CUDF_AMD_GB_DENSE_LOG2P", 0) > 0) rlog2P = static_cast<int>(env_i64("CUDF_AMD_GB_DENSE_LOG2P", 0));
@@ -953,7 +955,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           int const l1 = two_level ? (rlog2P + 1) / 2 : rlog2P, l2 = rlog2P - l1;
           int const slots         = 1 << std::max(bits - rlog2P, 0);
           std::size_t const image = dense_table_bytes(p, slots);
-          bool const ring_ok = dm.range <= (uint64_t{1} << bits) && bits <= 30 && bits - rlog2P >= 6 && rlog2P <= 16 && l1 >= 4 && l1 <= 8 &&
+          int32_t const ntables = static_cast<int32_t>(int64_t{1} << rlog2P);
+          int const nsplit      = static_cast<int>(std::clamp<int64_t>(env_i64("CUDF_AMD_GB_DENSE_NSPLIT", 256 / ntables), 1, two_level ? 1 : 16));
+          // (heavy hitters: one level, and their merged item - at most HOT_MAX_KEYS groups - must fit the stride of the items)
+          bool const ring_ok = (hot_keys.empty() || (!two_level && slots / nsplit >= HOT_MAX_KEYS)) &&
+                               dm.range <= (uint64_t{1} << bits) && bits <= 30 && bits - rlog2P >= 6 && rlog2P <= 16 && l1 >= 4 && l1 <= 8 &&
                                (l2 == 0 || (l2 >= 4 && l2 <= 8)) && image <= 150 * 1024 &&
                                static_cast<double>(dm.range) <= 8.0 * std::max(est_groups, 4096.0);
           if (ring_ok) {
@@ -990,6 +996,15 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
             ra.out_val      = sc.alloc<uint64_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR));
             ra.tag16        = two_level ? 0 : 1;
             ra.out_tag      = sc.alloc<uint16_t>(static_cast<size_t>(S * PD) * static_cast<size_t>(capR) * (two_level ? 2 : 1));
+            bool const ring_hot = !hot_keys.empty();
+            if (ring_hot) {  // (hot_eligible: one plain key, SUM / COUNT accumulators)
+              uint64_t* d_hot = sc.alloc<uint64_t>(HOT_MAX_KEYS);
+              CUDF_HIP_TRY(hipMemcpyAsync(d_hot, hot_keys.data(), hot_keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+              ra.hot_n     = static_cast<int32_t>(hot_keys.size());
+              ra.hot_keys  = d_hot;
+              ra.hot_out   = sc.alloc<uint64_t>(static_cast<size_t>(S) * HOT_SLOTS * PU);
+              ra.hot_count = sc.alloc<int32_t>(static_cast<size_t>(S));
+            }
             if (dm.nkeys > 0) {
               uint32_t* ones = sc.alloc<uint32_t>(16);
               CUDF_HIP_TRY(hipMemsetAsync(ones, 0xff, 64, s));
@@ -1039,8 +1054,6 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
               da.region_cap   = cap2;
               da.slices       = static_cast<int32_t>(slices2);
             }
-            int32_t const ntables = static_cast<int32_t>(int64_t{1} << rlog2P);
-            int const nsplit      = static_cast<int>(std::clamp<int64_t>(env_i64("CUDF_AMD_GB_DENSE_NSPLIT", 256 / ntables), 1, two_level ? 1 : 16));
             da.nsplit       = nsplit;
             da.slots        = slots;
             da.image_bytes  = static_cast<int32_t>(image);
@@ -1048,8 +1061,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
             da.KU           = dm.nkeys > 0 ? p.KU : 1;
             nitems          = ntables * nsplit;  // (partial records: partition d's slots in nsplit shares)
             da.tables       = sc.alloc<uint64_t>(nsplit > 1 ? static_cast<size_t>(nitems) * image / 8 : 2);
-            partial         = sc.alloc<uint64_t>(static_cast<size_t>(ntables) * slots * DPU);
-            d_count         = sc.alloc<int32_t>(nitems);
+            // (+ one item of the same stride for the merged heavy hitters)
+            partial         = sc.alloc<uint64_t>((static_cast<size_t>(ntables) * slots + static_cast<size_t>(slots / nsplit)) * DPU);
+            d_count         = sc.alloc<int32_t>(nitems + 1);
             da.out_records  = partial;
             da.out_count    = d_count;
             da.overflow     = d_overflow;
@@ -1062,6 +1076,25 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
             launch_aggregate_dense(da, d_da, true, true, s);
             if (nsplit > 1) launch_dense_merge_dump(da, d_da, nsplit, s);
             final_cap          = slots / nsplit;
+            if (ring_hot) {  // the workgroups' heavy-hitter partials -> one more item behind the tables' (hash-table merge kernel)
+              CUDF_EXPECTS(final_cap >= HOT_MAX_KEYS, "dense keys: heavy-hitter item");
+              agg_args hm{};
+              hm.plan        = p;
+              hm.geom        = ag;
+              hm.overflow    = d_overflow;
+              hm.input       = IN_PARTIAL_RECORDS;
+              hm.seg         = SEG_STRIDED;
+              hm.records     = ra.hot_out;
+              hm.src_count   = ra.hot_count;
+              hm.src_stride  = HOT_SLOTS;
+              hm.fan         = static_cast<int32_t>(S);
+              hm.nsrc        = static_cast<int32_t>(S);
+              hm.out_records = partial + static_cast<size_t>(nitems) * final_cap * DPU;
+              hm.out_count   = d_count + nitems;
+              hm.nitems      = 1;
+              launch_aggregate(hm, sc.alloc<agg_args>(1), s);
+              nitems += 1;
+            }
             int32_t const h_ov = overflow_and_counts();
             if (env_i64("CUDF_AMD_DEBUG", 0))
               fprintf(stderr, "[cudf_amd] dense keys (ring): nkeys=%d lo=%lld range=%llu bits=%d P=%ld x %ld slots=%d image=%zu B nsplit=%d capR=%ld cap2=%ld overflow=%d\n",
