@@ -143,15 +143,43 @@ __device__ __forceinline__ int64_t sample_row(int64_t i, int64_t nrows, int64_t 
 // serialise at ~12 ns each); a pass of its own over the same sample took as long as this one.
 template <int RANGE>
 __global__ void __launch_bounds__(256) k_estimate(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
-                                                  uint32_t* bitmap, int32_t bits_log2, uint32_t* hot_buckets, uint64_t* blk_range)
+                                                  uint32_t* bitmap, int32_t bits_log2, uint32_t* hot_buckets, uint64_t* blk_range,
+                                                  uint32_t* blk_adj)
 {
   plan_dev const& p = *pp;
   int64_t const i   = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   uint64_t key[MAX_KU];
   bool live = i < sample;
+  bool pair = false, pair_equal = false;
   if (live) {
     uint32_t vv;
-    live = build_key_units<MAX_KU, false>(p, sample_row(i, nrows, sample), key, vv);
+    int64_t const row = sample_row(i, nrows, sample);
+    live = build_key_units<MAX_KU, false>(p, row, key, vv);
+    // clustering: does the NEXT row carry the same key? (sorted / clustered inputs: the planner aggregates row chunks locally
+    // first - blk_adj[2 b], [2 b + 1] = pairs looked at, pairs with equal keys, per workgroup; k_popcount folds them)
+    if (blk_adj != nullptr && live && row + 1 < nrows) {
+      uint64_t key2[MAX_KU];
+      if (build_key_units<MAX_KU, false>(p, row + 1, key2, vv)) {
+        pair       = true;
+        pair_equal = true;
+#pragma unroll
+        for (int u = 0; u < MAX_KU; ++u)
+          if (u < p.KU) pair_equal = pair_equal && key[u] == key2[u];
+      }
+    }
+  }
+  if (blk_adj != nullptr) {
+    __shared__ uint32_t s_pairs[4], s_equal[4];
+    uint32_t const np = static_cast<uint32_t>(__popcll(__ballot(pair))), ne = static_cast<uint32_t>(__popcll(__ballot(pair && pair_equal)));
+    if ((threadIdx.x & 63) == 0) {
+      s_pairs[threadIdx.x >> 6] = np;
+      s_equal[threadIdx.x >> 6] = ne;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      blk_adj[2 * blockIdx.x]     = s_pairs[0] + s_pairs[1] + s_pairs[2] + s_pairs[3];
+      blk_adj[2 * blockIdx.x + 1] = s_equal[0] + s_equal[1] + s_equal[2] + s_equal[3];
+    }
   }
   if constexpr (RANGE != 0) {
     using T = std::conditional_t<RANGE == 1, long long, unsigned long long>;
@@ -300,15 +328,49 @@ __global__ void __launch_bounds__(1024) k_count_prefix(int32_t const* __restrict
   if (threadIdx.x == 1023) prefix[nitems] = s_run[1023];
 }
 
+// item i's records [i * cap, i * cap + (prefix[i + 1] - prefix[i])) of `units` words each -> out[prefix[i] ...]: one workgroup per item
+__global__ void __launch_bounds__(256) k_compact_records(uint64_t const* __restrict__ records, int64_t cap, int64_t const* __restrict__ prefix,
+                                                         int units, uint64_t* __restrict__ out)
+{
+  int64_t const b = prefix[blockIdx.x], words = (prefix[blockIdx.x + 1] - b) * units;
+  uint64_t const* src = records + static_cast<int64_t>(blockIdx.x) * cap * units;
+  uint64_t* dst       = out + b * units;
+  for (int64_t i = threadIdx.x; i < words; i += blockDim.x) gstore(dst + i, gload(src + i));
+}
+struct i64x2_pod { int64_t a, b; };
+
 // range_mode 1 / 2: workgroup 0 also folds the per-workgroup key ranges of k_estimate<RANGE> into range_out[0] = min, [1] = max
+// blk_adj != nullptr: workgroup 1 folds the per-workgroup adjacent-pair counts into adj_out[0] = pairs, [1] = equal pairs
 __global__ void __launch_bounds__(256) k_popcount(uint32_t const* bitmap, int64_t nwords, uint32_t* out, uint64_t const* blk_range,
-                                                  int nblk, int range_mode, uint64_t* range_out)
+                                                  int nblk, int range_mode, uint64_t* range_out, uint32_t const* blk_adj, uint32_t* adj_out)
 {
   int64_t i     = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   uint32_t acc  = 0;
   for (; i < nwords; i += static_cast<int64_t>(gridDim.x) * blockDim.x) acc += __popc(bitmap[i]);
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+  if (blk_adj != nullptr && blockIdx.x == 1) {
+    __shared__ uint32_t s_p[4], s_e[4];
+    uint32_t np = 0, ne = 0;
+    for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+      np += blk_adj[2 * b];
+      ne += blk_adj[2 * b + 1];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      np += __shfl_down(np, o);
+      ne += __shfl_down(ne, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_p[threadIdx.x >> 6] = np;
+      s_e[threadIdx.x >> 6] = ne;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      adj_out[0] = s_p[0] + s_p[1] + s_p[2] + s_p[3];
+      adj_out[1] = s_e[0] + s_e[1] + s_e[2] + s_e[3];
+    }
+    return;
+  }
   if (range_mode == 0 || blockIdx.x != 0) return;
   __shared__ uint64_t s_lo[4], s_hi[4];
   bool const sg = range_mode == 1;
@@ -376,6 +438,18 @@ void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t con
   CUDF_HIP_TRY(hipGetLastError());
 }
 
+void launch_compact_records(uint64_t const* records, int64_t cap, int64_t const* prefix, int32_t nitems, int units, uint64_t* out, hipStream_t stream)
+{
+  if (nitems == 0) return;
+  hipLaunchKernelGGL(k_compact_records, dim3(nitems), dim3(256), 0, stream, records, cap, prefix, units, out);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+void launch_store_i64x2(int64_t a, int64_t b, int64_t* dst, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<i64x2_pod>, dim3(1), dim3(1), 0, stream, i64x2_pod{a, b}, reinterpret_cast<i64x2_pod*>(dst));
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
 void launch_count_prefix(int32_t const* counts, int32_t nitems, int64_t* prefix, hipStream_t stream)
 {
   hipLaunchKernelGGL(k_count_prefix, dim3(1), dim3(1024), 0, stream, counts, nitems, prefix);
@@ -411,7 +485,7 @@ void launch_distinct_count(plan_dev const& plan, plan_dev* d_plan, int64_t nrows
 
 void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
                      int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream, int range_mode,
-                     uint64_t* blk_range, uint64_t* range_out)
+                     uint64_t* blk_range, uint64_t* range_out, uint32_t* blk_adj, uint32_t* adj_out)
 {
   if (hot_buckets != nullptr) CUDF_HIP_TRY(hipMemsetAsync(hot_buckets, 0, HOT_BUCKETS * sizeof(uint32_t), stream));
   int64_t const nwords = (int64_t{1} << bitmap_bits_log2) / 32;
@@ -422,10 +496,12 @@ void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int6
   cudf::detail::prof::scope prof_{"estimate", stream};
   unsigned const grid = static_cast<unsigned>((sample + block - 1) / block);
   CUDF_EXPECTS(range_mode == 0 || (plan.simple && plan.KU == 1 && blk_range != nullptr && range_out != nullptr), "estimate: key range of one plain key column");
-  if (range_mode == 1) hipLaunchKernelGGL(k_estimate<1>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range);
-  else if (range_mode == 2) hipLaunchKernelGGL(k_estimate<2>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range);
-  else hipLaunchKernelGGL(k_estimate<0>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range);
-  hipLaunchKernelGGL(k_popcount, dim3(256), dim3(block), 0, stream, bitmap, nwords, d_bits_set, blk_range, static_cast<int>(grid), range_mode, range_out);
+  CUDF_EXPECTS((blk_adj == nullptr) == (adj_out == nullptr), "estimate: adjacent-pair counts need their scratch and their output");
+  if (range_mode == 1) hipLaunchKernelGGL(k_estimate<1>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range, blk_adj);
+  else if (range_mode == 2) hipLaunchKernelGGL(k_estimate<2>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range, blk_adj);
+  else hipLaunchKernelGGL(k_estimate<0>, dim3(grid), dim3(block), 0, stream, d_plan, nrows, sample, bitmap, bitmap_bits_log2, hot_buckets, blk_range, blk_adj);
+  hipLaunchKernelGGL(k_popcount, dim3(256), dim3(block), 0, stream, bitmap, nwords, d_bits_set, blk_range, static_cast<int>(grid), range_mode, range_out,
+                     blk_adj, adj_out);
   CUDF_HIP_TRY(hipGetLastError());
 }
 

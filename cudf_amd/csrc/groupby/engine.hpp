@@ -378,12 +378,17 @@ void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t con
                      int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream);
 // prefix[i] = counts[0] + ... + counts[i - 1] for i <= nitems (the items' group counts -> where each item's groups go in the output)
 void launch_count_prefix(int32_t const* counts, int32_t nitems, int64_t* prefix, hipStream_t stream);
+// item i's records [i * cap, i * cap + prefix[i + 1] - prefix[i]) of `units` 8-byte units each -> out[prefix[i] ...] (contiguous)
+void launch_compact_records(uint64_t const* records, int64_t cap, int64_t const* prefix, int32_t nitems, int units, uint64_t* out, hipStream_t stream);
+void launch_store_i64x2(int64_t a, int64_t b, int64_t* dst, hipStream_t stream);  // dst[0] = a, dst[1] = b, stream-ordered
 // Distinct-count estimate on a strided sample (linear counting into a bitmap); result written to *d_bits.
 // range_mode 1 / 2 (one plain 8-byte integer key column, signed / unsigned): the pass also leaves the minimum and maximum of the
 // sampled keys in range_out[0], [1]; blk_range holds 2 x ceil(sample / 256) scratch words.
 void launch_estimate(plan_dev const& plan, plan_dev* d_plan, int64_t nrows, int64_t sample, uint32_t* bitmap,
                      int32_t bitmap_bits_log2, uint32_t* d_bits_set, uint32_t* hot_buckets, hipStream_t stream, int range_mode = 0,
-                     uint64_t* blk_range = nullptr, uint64_t* range_out = nullptr);
+                     uint64_t* blk_range = nullptr, uint64_t* range_out = nullptr, uint32_t* blk_adj = nullptr, uint32_t* adj_out = nullptr);
+// (blk_adj: 2 x ceil(sample / 256) scratch words; adj_out[0] = sampled rows whose successor row was looked at, adj_out[1] = those
+// whose successor carries the same key - sorted and clustered inputs show up here)
 
 // Distinct-count of the key rows over ALL rows (HyperLogLog, HLL_REGISTERS 32-bit registers holding ranks): the planner
 // runs it after a table overflowed, i.e. when the sample misjudged the group count (skewed key frequencies).

@@ -664,6 +664,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   uint64_t h_range[2] = {0, 0};  // sample minimum / maximum of the key column (bit patterns)
   int64_t h_ranges[2 * MAX_KU] = {0};  // composite: per key column, as int64
   int64_t final_cap  = 0;        // records per work item in `partial` (0: ag.cap)
+  double adjacent_equal = 0.0;   // share of the sampled rows whose successor row carries the same key
   // ---- distinct-count estimate on a strided sample (skipped when n already fits one table)
   double est_groups = static_cast<double>(n);
   // Small inputs skip the estimate (three memsets, three kernels and a stream synchronisation: about a third of a 10K-row call):
@@ -685,7 +686,12 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     // (one plain integer key column: the same pass takes the minimum and maximum of the sampled keys for the dense-key test)
     uint64_t* d_range = dense_candidate ? sc.alloc<uint64_t>(2) : nullptr;
     uint64_t* d_blk_range = dense_candidate ? sc.alloc<uint64_t>(2 * static_cast<std::size_t>((sample + 255) / 256)) : nullptr;
-    launch_estimate(p, d_plan, n, sample, bitmap, bits_log2, d_set, hot_buckets, s, dense_candidate ? (dense_signed ? 1 : 2) : 0, d_blk_range, d_range);
+    // (and how often a row's successor carries the same key: sorted / clustered inputs are aggregated in row chunks first)
+    bool const want_adj = n >= (int64_t{1} << 22) && p.narg == 0 && env_i64("CUDF_AMD_GB_PREAGG", 1) != 0;
+    uint32_t* d_blk_adj = want_adj ? sc.alloc<uint32_t>(2 * static_cast<std::size_t>((sample + 255) / 256)) : nullptr;
+    uint32_t* d_adj     = want_adj ? sc.alloc<uint32_t>(2) : nullptr;
+    launch_estimate(p, d_plan, n, sample, bitmap, bits_log2, d_set, hot_buckets, s, dense_candidate ? (dense_signed ? 1 : 2) : 0, d_blk_range, d_range,
+                    d_blk_adj, d_adj);
     // Dense integer keys ("Dense keys"): minimum and maximum of the key column over the same sample
     // (every read-back of this pass lands in page-locked memory: a copy into pageable memory blocks the host until it is done)
     unsigned char* const pin = pinned_bytes(64 + 16 + sizeof(h_ranges) + HOT_TABLE * (sizeof(uint64_t) + sizeof(uint32_t)));
@@ -717,10 +723,12 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       CUDF_HIP_TRY(hipMemcpyAsync(pin_tcounts, tcounts, HOT_TABLE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     CUDF_HIP_TRY(hipMemcpyAsync(pin_set, d_set, 4, hipMemcpyDeviceToHost, s));
+    if (want_adj) CUDF_HIP_TRY(hipMemcpyAsync(pin_set + 2, d_adj, 8, hipMemcpyDeviceToHost, s));
     trace.mark("estimate queued");
     CUDF_HIP_TRY(hipStreamSynchronize(s));
     trace.mark("estimate back");
     uint32_t const h_set = *pin_set;
+    if (want_adj && pin_set[2] >= 1024) adjacent_equal = static_cast<double>(pin_set[3]) / static_cast<double>(pin_set[2]);
     if (dense_candidate) std::memcpy(h_range, pin_range, 16);
     if (dense_composite) std::memcpy(h_ranges, pin_ranges, sizeof(h_ranges));
     if (hot_eligible) {
@@ -833,6 +841,64 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     }
     d_overflow = sc.alloc<int32_t>(1);
   };
+  // Exact pipeline (histogram, scan, scatter with exact offsets, one or two levels, then one table per partition) over the rows
+  // `pa` describes: the plan's columns, or `nrec` records of `units` 8-byte units each (raw records, or - in_mode ==
+  // IN_PARTIAL_RECORDS - partial records of a local pre-aggregation; the partition kernels only hash the key units, `pplan` is
+  // the plan as they shall see it). Leaves partial / d_count / nitems for the finalize step.
+  auto exact_pipeline = [&](part_args& pa, part_args* d_pa, plan_dev const& pplan, int64_t nrec, int units, agg_input in_mode, int64_t P1,
+                            int64_t P2, int log2P1, int log2P2, agg_args& aa) {
+    size_t const items1 = static_cast<size_t>(pa.geom.nseg) * static_cast<size_t>(pa.geom.slices);
+    pa.counts       = sc.alloc<uint32_t>(items1 * P1);
+    pa.item_base    = sc.alloc<int64_t>(items1 * P1);
+    pa.out_offsets  = sc.alloc<int64_t>(P1 + 1);
+    uint64_t* recA  = sc.alloc<uint64_t>(static_cast<size_t>(nrec) * units);
+    pa.out_records  = recA;
+    store_args(pa, d_pa, s);
+    launch_partition_hist(pa, d_pa, s);
+    launch_partition_scan(pa, d_pa, s);
+    launch_partition_scatter(pa, d_pa, s);
+    int64_t const* offsets = pa.out_offsets;
+    uint64_t const* recs   = recA;
+    int64_t nparts         = P1;
+    if (P2 > 1) {
+      part_args pb{};
+      pb.plan         = pplan;
+      pb.geom.nseg    = static_cast<int32_t>(P1);
+      pb.geom.slices  = static_cast<int32_t>(std::max<int64_t>(1, 1024 / P1));
+      pb.geom.P       = static_cast<int32_t>(P2);
+      pb.geom.shift   = 64 - log2P1 - log2P2;
+      pb.geom.block   = 1024;
+      pb.from_columns = 0;
+      pb.in_records   = recA;
+      pb.seg_offsets  = pa.out_offsets;
+      size_t const items2 = static_cast<size_t>(pb.geom.nseg) * pb.geom.slices;
+      pb.counts       = sc.alloc<uint32_t>(items2 * P2);
+      pb.item_base    = sc.alloc<int64_t>(items2 * P2);
+      pb.out_offsets  = sc.alloc<int64_t>(P1 * P2 + 1);
+      uint64_t* recB  = sc.alloc<uint64_t>(static_cast<size_t>(nrec) * units);
+      pb.out_records  = recB;
+      part_args* d_pb = sc.alloc<part_args>(1);
+      store_args(pb, d_pb, s);
+      launch_partition_hist(pb, d_pb, s);
+      launch_partition_scan(pb, d_pb, s);
+      launch_partition_scatter(pb, d_pb, s);
+      offsets = pb.out_offsets;
+      recs    = recB;
+      nparts  = P1 * P2;
+    }
+    nitems         = static_cast<int32_t>(nparts);
+    partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);
+    d_count        = sc.alloc<int32_t>(nitems);
+    aa.input       = in_mode;
+    aa.seg         = SEG_OFFSETS;
+    aa.offsets     = offsets;
+    aa.records     = recs;
+    aa.out_records = partial;
+    aa.out_count   = d_count;
+    aa.nitems      = nitems;
+    launch_aggregate(aa, sc.alloc<agg_args>(1), s);
+  };
+  bool pre_failed = false;  // the local pre-aggregation of this call overflowed a chunk's table: not tried again
   for (int attempt = 0;; ++attempt) {
     CUDF_EXPECTS(attempt < 4, "hash groupby: could not fit the groups into LDS tables (pathological key distribution).");
     CUDF_HIP_TRY(hipMemsetAsync(d_overflow, 0, 4, s));
@@ -886,8 +952,86 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         nitems  = next;
       }
     } else {
-      // ---------------- path D: dense integer keys -> direct-address LDS tables (no hash, no probe, no key words)
       final_cap = 0;
+      // ---------------- path A: sorted / clustered keys (most rows are followed by a row of the same key). Every partition
+      // scheme here gives a workgroup whole keys instead of a share of every key - regions overflow, rings stall, a wave's 64 rows
+      // meet in one table slot (1B sorted rows on 1M groups: 74 ms against 7 ms uniform). Row chunks small enough to hold few
+      // distinct keys are aggregated straight from the columns into one LDS table each (the single-pass kernel, wave-combined
+      // accumulate); their partial records - about one per run of equal keys - then take the exact partition pipeline and are
+      // merged. Reference: none (its global hash set does not care about row order).
+      if (adjacent_equal >= 0.01 * static_cast<double>(env_i64("CUDF_AMD_GB_PREAGG_MIN_PCT", 90)) && !pre_failed && forced_p == 0 && p.narg == 0) {
+        double const run_starts = std::max(1.0 - adjacent_equal, 1e-6);  // distinct keys of a chunk <= its run starts
+        int64_t const chunk_rows = std::clamp<int64_t>(static_cast<int64_t>(static_cast<double>(ag.fill_limit) / 1.5 / run_starts), int64_t{1} << 14, int64_t{1} << 22);
+        int64_t const items      = (n + chunk_rows - 1) / chunk_rows;
+        if (static_cast<double>(items) * ag.cap * PU * 8.0 <= 16.0 * 1024 * 1024 * 1024) {
+          _last_path         = hash_path::PARTITIONED_LDS;
+          uint64_t* partial1 = sc.alloc<uint64_t>(static_cast<size_t>(items) * ag.cap * PU);
+          int32_t* d_count1  = sc.alloc<int32_t>(static_cast<size_t>(items));
+          agg_args a1        = aa;
+          a1.input           = IN_COLUMNS;
+          a1.seg             = SEG_ROW_CHUNKS;
+          a1.nrows           = n;
+          a1.chunk           = chunk_rows;
+          a1.out_records     = partial1;
+          a1.out_count       = d_count1;
+          a1.nitems          = static_cast<int32_t>(items);
+          launch_aggregate(a1, sc.alloc<agg_args>(1), s);
+          nitems  = static_cast<int32_t>(items);
+          d_count = d_count1;
+          int32_t const ov1 = overflow_and_counts();
+          int64_t n2 = 0;
+          for (int32_t c : h_count) n2 += c;
+          if (env_i64("CUDF_AMD_DEBUG", 0))
+            fprintf(stderr, "[cudf_amd] pre-aggregation: %.1f %% of the rows repeat their predecessor's key, %ld chunks of %ld rows -> %ld partial records, overflow=%d\n",
+                    100.0 * adjacent_equal, (long)items, (long)chunk_rows, (long)n2, ov1);
+          if (ov1 != 0 || n2 * 2 > n) {  // a chunk held too many keys, or nothing was gained: the ordinary paths
+            pre_failed = true;
+            sc.bufs.clear();
+            d_overflow = sc.alloc<int32_t>(1);
+            --attempt;
+            continue;
+          }
+          // chunks' partial records -> one contiguous run (the partition kernels read segments of one buffer)
+          int64_t* d_prefix1 = sc.alloc<int64_t>(static_cast<size_t>(items) + 1);
+          launch_count_prefix(d_count1, static_cast<int32_t>(items), d_prefix1, s);
+          uint64_t* compact = sc.alloc<uint64_t>(static_cast<size_t>(std::max<int64_t>(n2, 1)) * PU);
+          launch_compact_records(partial1, ag.cap, d_prefix1, static_cast<int32_t>(items), PU, compact, s);
+          int64_t* d_seg = sc.alloc<int64_t>(2);
+          launch_store_i64x2(0, n2, d_seg, s);
+          // tables for the merged groups
+          double const need2 = std::min(est_groups * safety, static_cast<double>(n2)) / std::max(1.0, ag.cap * 0.25);
+          auto pow2_up = [](double x) { int64_t v = 1; while (static_cast<double>(v) < x) v <<= 1; return v; };
+          int64_t Q1 = std::clamp<int64_t>(pow2_up(need2), 16, 1024), Q2 = 1;
+          if (need2 > 1024.0) {
+            int64_t const tot = pow2_up(need2);
+            Q1 = std::min<int64_t>(pow2_up(std::sqrt(static_cast<double>(tot))), 1024);
+            Q2 = std::clamp<int64_t>(tot / Q1, 2, 1024);
+          }
+          int lq1 = 0, lq2 = 0;
+          while ((int64_t{1} << lq1) < Q1) ++lq1;
+          while ((int64_t{1} << lq2) < Q2) ++lq2;
+          plan_dev p2 = p;  // what the partition kernels see: records of KU key units + NACC accumulator units
+          p2.NPAY     = p.NACC;
+          p2.simple   = 0;
+          part_args pq{};
+          pq.plan         = p2;
+          pq.geom.nseg    = 1;
+          pq.geom.slices  = static_cast<int32_t>(std::clamp<int64_t>(n2 / 16384, 16, 512));
+          pq.geom.P       = static_cast<int32_t>(Q1);
+          pq.geom.shift   = 64 - lq1;
+          pq.geom.block   = 1024;
+          pq.geom.tile_rows = 8 * 1024;
+          pq.from_columns = 0;
+          pq.in_records   = compact;
+          pq.seg_offsets  = d_seg;
+          exact_pipeline(pq, sc.alloc<part_args>(1), p2, n2, PU, IN_PARTIAL_RECORDS, Q1, Q2, lq1, lq2, aa);
+          int32_t const ov2 = overflow_and_counts();
+          if (ov2 == 0) break;
+          escalate();  // a merged table overflowed: more tables (the chunks are aggregated again)
+          continue;
+        }
+      }
+      // ---------------- path D: dense integer keys -> direct-address LDS tables (no hash, no probe, no key words)
       // (heavy hitters in the sample: only the single-level ring scatter of one plain key takes them out of the partition)
       bool const ring_env = env_i64("CUDF_AMD_GB_DENSE_RING", 1) != 0 && env_i64("CUDF_AMD_GB_CHUNKED", 0) == 0;
       if (allow_dense && forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !forced_exact) {
@@ -1452,55 +1596,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
           continue;
         }
       }
-      pa.counts       = sc.alloc<uint32_t>(items1 * P1);
-      pa.item_base    = sc.alloc<int64_t>(items1 * P1);
-      pa.out_offsets  = sc.alloc<int64_t>(P1 + 1);
-      recA            = sc.alloc<uint64_t>(static_cast<size_t>(n) * RU);
-      pa.out_records  = recA;
-      store_args(pa, d_pa, s);
-      launch_partition_hist(pa, d_pa, s);
-      launch_partition_scan(pa, d_pa, s);
-      launch_partition_scatter(pa, d_pa, s);
-      int64_t const* offsets = pa.out_offsets;
-      uint64_t const* recs   = recA;
-      int64_t nparts         = P1;
-      if (P2 > 1) {
-        part_args pb{};
-        pb.plan         = p;
-        pb.geom.nseg    = static_cast<int32_t>(P1);
-        pb.geom.slices  = static_cast<int32_t>(std::max<int64_t>(1, 1024 / P1));
-        pb.geom.P       = static_cast<int32_t>(P2);
-        pb.geom.shift   = 64 - log2P1 - log2P2;
-        pb.geom.block   = 1024;
-        pb.from_columns = 0;
-        pb.in_records   = recA;
-        pb.seg_offsets  = pa.out_offsets;
-        size_t const items2 = static_cast<size_t>(pb.geom.nseg) * pb.geom.slices;
-        pb.counts       = sc.alloc<uint32_t>(items2 * P2);
-        pb.item_base    = sc.alloc<int64_t>(items2 * P2);
-        pb.out_offsets  = sc.alloc<int64_t>(P1 * P2 + 1);
-        uint64_t* recB  = sc.alloc<uint64_t>(static_cast<size_t>(n) * RU);
-        pb.out_records  = recB;
-        part_args* d_pb = sc.alloc<part_args>(1);
-        store_args(pb, d_pb, s);
-        launch_partition_hist(pb, d_pb, s);
-        launch_partition_scan(pb, d_pb, s);
-        launch_partition_scatter(pb, d_pb, s);
-        offsets = pb.out_offsets;
-        recs    = recB;
-        nparts  = P1 * P2;
-      }
-      nitems         = static_cast<int32_t>(nparts);
-      partial        = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * ag.cap * PU);
-      d_count        = sc.alloc<int32_t>(nitems);
-      aa.input       = IN_RAW_RECORDS;
-      aa.seg         = SEG_OFFSETS;
-      aa.offsets     = offsets;
-      aa.records     = recs;
-      aa.out_records = partial;
-      aa.out_count   = d_count;
-      aa.nitems      = nitems;
-      launch_aggregate(aa, sc.alloc<agg_args>(1), s);
+      exact_pipeline(pa, d_pa, p, n, RU, IN_RAW_RECORDS, P1, P2, log2P1, log2P2, aa);
     }
     if (overflow_and_counts() == 0) break;
     escalate();

@@ -595,6 +595,35 @@ def test_heavy_hitters(G, oracle, vt, hot_fraction):
     _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), ["sum", "count_valid", "mean"])], expect_path="PARTITIONED_LDS")
 
 
+@pytest.mark.parametrize("shape", ["sorted", "clustered", "sorted_nulls_two_keys", "float_keys"])
+def test_sorted_and_clustered_keys_are_preaggregated(G, oracle, monkeypatch, shape):
+    """Most rows are followed by a row of the same key (the estimate pass measures it): row chunks are aggregated locally first and
+    their partial records take the exact partition pipeline (path A of groupby.cpp). Same call with CUDF_AMD_GB_PREAGG=0 agrees."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(91)
+    n = 4_600_000
+    i = np.arange(n, dtype=np.int64)
+    if shape == "sorted":
+        keys = [i // 37 - 1000]
+        vals = HostColumn(rng.random(n), None, "float64")
+    elif shape == "clustered":  # runs of 24 equal keys, every key recurs about 20 times
+        keys = [((i // 24) * 2654435761) % 9_973]
+        vals = HostColumn(rng.integers(-1000, 1000, n).astype(np.int32), rng.random(n) > 0.2, "int32")
+    elif shape == "sorted_nulls_two_keys":
+        keys = [HostColumn(i // 4000, None, "int64"), HostColumn(((i // 40) % 100).astype(np.int16), (i // 40) % 7 != 0, "int16")]
+        vals = HostColumn(rng.random(n), rng.random(n) > 0.1, "float64")
+    else:  # float keys: +0.0 / -0.0 and NaNs meet, the output key is a representative input row
+        f = (i // 50).astype(np.float64)
+        f[(i // 50) % 11 == 0] = np.nan
+        f[(i // 50) % 13 == 0] = -0.0
+        keys = [HostColumn(f, None, "float64")]
+        vals = HostColumn(rng.random(n), None, "float64")
+    kinds = ["sum", "count_valid", "count_all", "min", "max", "mean"]
+    _check_against_oracle(G, oracle, keys, [(vals, kinds)], expect_path="PARTITIONED_LDS")
+    monkeypatch.setenv("CUDF_AMD_GB_PREAGG", "0")
+    _check_against_oracle(G, oracle, keys, [(vals, kinds)])
+
+
 @pytest.mark.parametrize("vt", ["float64", "int64"])
 @pytest.mark.parametrize("hot_fraction", [0.01, 0.3, 0.9])
 def test_heavy_hitters_dense_keys(G, oracle, vt, hot_fraction):
