@@ -651,12 +651,15 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   std::vector<uint64_t> hot_keys;  // heavy hitters found in the sample (aggregated inside the scatter workgroups)
   // Dense-key candidate: one plain 8-byte integer key column, one plain 8-byte value column, no ARGMIN / ARGMAX
   bool const dense_signed    = p.cols[0].cls == cudf::detail::CLS_SINT;
-  bool const dense_candidate = p.simple && p.KU == 1 && p.NPAY == 1 && p.narg == 0 && n >= (int64_t{1} << 22) &&
+  // (the dense-key, heavy-hitter and pre-aggregation paths are for big inputs; CUDF_AMD_GB_BIG_MIN_ROWS lets the fuzz tests walk
+  // them at sizes a CPU checker can follow)
+  int64_t const big_rows     = env_i64("CUDF_AMD_GB_BIG_MIN_ROWS", int64_t{1} << 22);
+  bool const dense_candidate = p.simple && p.KU == 1 && p.NPAY == 1 && p.narg == 0 && n >= big_rows &&
                                env_i64("CUDF_AMD_GB_DENSE", 1) != 0;
   // Composite dense keys: 1-4 integer key columns of any width (rows with a NULL key are dropped: no nullable key under
   // null_policy::INCLUDE), exactly one value column, no ARGMIN / ARGMAX
   bool dense_composite = !dense_candidate && p.nkeycols <= DENSE_MAX_KEYS && hp.value_cols.size() == 1 && p.narg == 0 &&
-                         hp.keynulls_unit < 0 && n >= (int64_t{1} << 22) && env_i64("CUDF_AMD_GB_DENSE", 1) != 0 &&
+                         hp.keynulls_unit < 0 && n >= big_rows && env_i64("CUDF_AMD_GB_DENSE", 1) != 0 &&
                          env_i64("CUDF_AMD_GB_DENSE_COMPOSITE", 1) != 0;
   for (int c = 0; c < p.nkeycols && dense_composite; ++c)
     dense_composite = p.cols[c].cls == cudf::detail::CLS_SINT || p.cols[c].cls == cudf::detail::CLS_UINT;
@@ -680,14 +683,14 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     uint32_t* bitmap     = sc.alloc<uint32_t>((size_t{1} << bits_log2) / 32);
     uint32_t* d_set      = sc.alloc<uint32_t>(1);
     plan_dev* d_plan = sc.alloc<plan_dev>(1);
-    bool const hot_eligible = p.simple && RU == 2 && p.KU == 1 && hot_plan_ok(p) && n >= (int64_t{1} << 22) &&
+    bool const hot_eligible = p.simple && RU == 2 && p.KU == 1 && hot_plan_ok(p) && n >= big_rows &&
                               env_i64("CUDF_AMD_GB_HOT", 1) != 0;
     uint32_t* hot_buckets = hot_eligible ? sc.alloc<uint32_t>(HOT_BUCKETS) : nullptr;
     // (one plain integer key column: the same pass takes the minimum and maximum of the sampled keys for the dense-key test)
     uint64_t* d_range = dense_candidate ? sc.alloc<uint64_t>(2) : nullptr;
     uint64_t* d_blk_range = dense_candidate ? sc.alloc<uint64_t>(2 * static_cast<std::size_t>((sample + 255) / 256)) : nullptr;
     // (and how often a row's successor carries the same key: sorted / clustered inputs are aggregated in row chunks first)
-    bool const want_adj = n >= (int64_t{1} << 22) && p.narg == 0 && env_i64("CUDF_AMD_GB_PREAGG", 1) != 0;
+    bool const want_adj = n >= big_rows && p.narg == 0 && env_i64("CUDF_AMD_GB_PREAGG", 1) != 0;
     uint32_t* d_blk_adj = want_adj ? sc.alloc<uint32_t>(2 * static_cast<std::size_t>((sample + 255) / 256)) : nullptr;
     uint32_t* d_adj     = want_adj ? sc.alloc<uint32_t>(2) : nullptr;
     launch_estimate(p, d_plan, n, sample, bitmap, bits_log2, d_set, hot_buckets, s, dense_candidate ? (dense_signed ? 1 : 2) : 0, d_blk_range, d_range,

@@ -513,6 +513,14 @@ def test_fuzz_against_oracle(G, oracle, seed, monkeypatch):
     n = int(rng.choice([0, 1, 37, 5_000, 80_000, 700_000]))
     if seed % 4 == 3:
         monkeypatch.setenv("CUDF_AMD_GB_LDS_KB", str(int(rng.choice([16, 24, 32]))))  # small tables: partition paths at small n
+    # a third of the seeds: the big-input paths (dense keys through the ring scatter, heavy hitters, local pre-aggregation of
+    # sorted keys) at sizes the oracle can check; half of those with the rows sorted by key
+    big_paths = seed % 3 == 1
+    if big_paths:
+        monkeypatch.setenv("CUDF_AMD_GB_BIG_MIN_ROWS", "1000")
+        n = int(rng.choice([80_000, 300_000, 700_000]))
+        if seed % 4 != 3:
+            monkeypatch.setenv("CUDF_AMD_GB_LDS_KB", str(int(rng.choice([16, 32, 159]))))  # (the groups must not fit one table)
 
     def column(tname, distinct, nullable, offset):
         npt = NP_OF_TYPE_ID[TYPE_ID[tname]]
@@ -527,16 +535,32 @@ def test_fuzz_against_oracle(G, oracle, seed, monkeypatch):
         valid = (rng.random(m) > 0.15) if nullable else None
         return HostColumn(data, valid, tname, offset=offset) if offset else HostColumn(data[:n] if offset == 0 else data, valid, tname)
 
-    nkeys = int(rng.integers(1, 4))
-    spread = int(rng.choice([3, 40, 3000]))
-    keys = [column(str(rng.choice(_FUZZ_KEY_TYPES)), spread, bool(rng.random() < 0.4), int(rng.choice([0, 0, 5]))) for _ in range(nkeys)]
+    if os.environ.get("CUDF_AMD_FUZZ_LDS_KB"):  # (reproduce a seed under another table size)
+        monkeypatch.setenv("CUDF_AMD_GB_LDS_KB", os.environ["CUDF_AMD_FUZZ_LDS_KB"])
+    # (half of the big-path seeds keep to what the dense tables take: integer keys, one value column, no ARGMIN / ARGMAX, EXCLUDE)
+    dense_shape = big_paths and seed % 6 == 1
+    nkeys = int(rng.integers(1, 3)) if dense_shape else int(rng.integers(1, 4))
+    spread = int(rng.choice([40, 3000, 60_000])) if big_paths else int(rng.choice([3, 40, 3000]))
+    key_types = [t for t in _FUZZ_KEY_TYPES if not dense_shape or t.startswith(("int", "uint"))]
+    keys = [column(str(rng.choice(key_types)), spread, bool(rng.random() < 0.4), int(rng.choice([0, 0, 5]))) for _ in range(nkeys)]
     requests = []
-    for _ in range(int(rng.integers(1, 3))):
+    for _ in range(1 if dense_shape else int(rng.integers(1, 3))):
         vt = str(rng.choice(_FUZZ_VAL_TYPES))
         vals = column(vt, 9, bool(rng.random() < 0.5), int(rng.choice([0, 0, 3])))
-        kinds = [str(k) for k in rng.choice(_FUZZ_AGGS, size=int(rng.integers(1, 5)), replace=False)]
+        aggs = [a for a in _FUZZ_AGGS if not dense_shape or not a.startswith("arg")]
+        kinds = [str(k) for k in rng.choice(aggs, size=int(rng.integers(1, 5)), replace=False)]
         requests.append((vals, kinds))
-    include = bool(rng.random() < 0.5)
+    include = bool(rng.random() < 0.5) and not dense_shape
+    if big_paths and seed % 2 == 0 and n > 1:  # rows sorted by key (runs of equal keys): the pre-aggregation path
+        order = np.lexsort([k.data[k.offset:k.offset + n] for k in keys][::-1], axis=0)
+        type_name = {v: k for k, v in TYPE_ID.items()}
+
+        def take(c):
+            d = c.data[c.offset:c.offset + n][order]
+            v = None if c.valid is None else c.valid[c.offset:c.offset + n][order]
+            return HostColumn(d, v, type_name[c.type_id])
+        keys = [take(k) for k in keys]
+        requests = [(take(v), kinds) for v, kinds in requests]
     try:
         got = kat.sort_groups(*G.groupby(keys, requests, include_null_keys=include))
     except Exception as e:  # the engine's documented per-call limits are not what is fuzzed here
