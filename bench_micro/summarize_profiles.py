@@ -33,7 +33,10 @@ def find(sub, pat):
 
 
 def short(name):
-    for key, label in (("k_partition_scatter", "partition_scatter"), ("k_partition_hist", "partition_hist"),
+    if "k_dense_ring_scatter<2" in name:  # (the level that reads level-1 regions)
+        return "partition_scatter_level2"
+    for key, label in (("k_dense_ring_scatter", "partition_scatter"), ("k_dense_merge_dump", "aggregate_merge"),
+                       ("k_partition_scatter", "partition_scatter"), ("k_partition_hist", "partition_hist"),
                        ("k_aggregate", "aggregate"), ("k_finalize", "finalize"), ("k_estimate", "estimate")):
         if key in name:
             return label
