@@ -840,6 +840,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       est_groups = std::min<double>(static_cast<double>(n), std::max(est_groups * 1.5, counted * 1.05));
       sc.bufs.clear();
     } else {
+      // (an estimate already at the row count cannot grow: the planned load drops instead - tables of a few hundred slots,
+      // CUDF_AMD_GB_LDS_KB=8 in the fuzz tests, overflowed at 4 sigma of an all-distinct key column and the same plan was redone)
+      if (est_groups >= static_cast<double>(n)) safety *= 2.0;
       est_groups = std::min<double>(static_cast<double>(n), std::max(est_groups, static_cast<double>(ag.fill_limit)) * 8);
     }
     d_overflow = sc.alloc<int32_t>(1);
@@ -911,7 +914,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     // (C2: 8.3 -> 7.1 ms) than the fuller tables cost the aggregate (3.1 -> 3.7 ms), so plan for 0.45/safety = 0.35.
     bool const wc_eligible = (RU == 2 || RU == 3) && p.KU == 1 && env_i64("CUDF_AMD_GB_WC", 1) != 0;
     double const plan_fill = std::max(1.0, ag.cap * 0.01 * static_cast<double>(env_i64("CUDF_AMD_GB_PLAN_LOAD_PCT", wc_eligible ? 45 : 25)));
-    double const need = std::min(est_groups * safety, static_cast<double>(n)) / plan_fill;
+    // (groups <= rows, and the safety factor rides on top of that bound: more than `safety` x n / plan_fill tables are never needed
+    // for the tables' MEAN load, but without it an all-distinct key column was planned at the full load with no slack)
+    double const need = std::min(est_groups, static_cast<double>(n)) * (est_groups >= static_cast<double>(n) ? safety : std::min(safety, static_cast<double>(n) / est_groups)) / plan_fill;
     agg_args aa{};
     aa.plan     = p;
     aa.geom     = ag;
@@ -1604,7 +1609,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       }
       exact_pipeline(pa, d_pa, p, n, RU, IN_RAW_RECORDS, P1, P2, log2P1, log2P2, aa);
     }
-    if (overflow_and_counts() == 0) break;
+    int32_t const h_ov_exact = overflow_and_counts();
+    if (h_ov_exact == 0) break;
+    if (env_i64("CUDF_AMD_DEBUG", 0))
+      fprintf(stderr, "[cudf_amd] attempt %d: overflow flag %d with %d tables of %d slots (fill limit %d) for an estimate of %.0f groups in %ld rows\n",
+              attempt, h_ov_exact, nitems, ag.cap, ag.fill_limit, est_groups, (long)n);
     escalate();
   }
 
