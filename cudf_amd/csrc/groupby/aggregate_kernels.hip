@@ -267,16 +267,27 @@ __device__ __forceinline__ bool hot_sample_key(plan_dev const& p, int64_t nrows,
   h   = mix64(0x9e3779b97f4a7c15ull ^ key);
   return true;
 }
-__global__ void __launch_bounds__(256) k_hot_any(uint32_t const* buckets, uint32_t min_count, uint32_t* crowded)
+// The threshold a key's sample count must reach: min_count, and at least 8x the mean count of a key of the sample (bits_set =
+// distinct keys of the sample, left by k_popcount): in a column of few keys EVERY key is frequent (5000 groups: all of them
+// passed min_count, the collect pass pushed the whole sample through its 4096-entry table - 0.34 ms - and the planner got 256
+// ordinary keys as heavy hitters).
+__host__ __device__ inline uint32_t hot_threshold(uint32_t min_count, int64_t counted_rows, uint32_t bits_set)
+{
+  uint64_t const mean8 = 8ull * static_cast<uint64_t>(counted_rows) / (bits_set > 0 ? bits_set : 1u);
+  return static_cast<uint32_t>(mean8 > min_count ? (mean8 > 0xffffffffull ? 0xffffffffull : mean8) : min_count);
+}
+__global__ void __launch_bounds__(256) k_hot_any(uint32_t const* buckets, uint32_t min_count, int64_t counted_rows, uint32_t const* bits_set,
+                                                 uint32_t* crowded)
 {
   int const i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < HOT_BUCKETS && buckets[i] >= min_count) *crowded = 1;
+  if (i < HOT_BUCKETS && buckets[i] >= hot_threshold(min_count, counted_rows, *bits_set)) *crowded = 1;
 }
 __global__ void __launch_bounds__(256) k_hot_collect(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
-                                                     uint32_t const* buckets, uint32_t const* crowded, uint32_t min_count,
-                                                     uint64_t* tkeys, uint32_t* tcounts)
+                                                     uint32_t const* buckets, uint32_t const* crowded, uint32_t min_count_in,
+                                                     uint32_t const* bits_set, uint64_t* tkeys, uint32_t* tcounts)
 {
   if (*crowded == 0) return;  // no bucket reached the threshold: nothing to collect
+  uint32_t const min_count = hot_threshold(min_count_in, (sample + 3) / 4, *bits_set);
   uint64_t key = 0, h = 0;
   bool pending = hot_sample_key(*pp, nrows, sample, key, h) && buckets[h >> 48] >= min_count && key != HOT_SENTINEL;
   uint32_t mine = 1;  // rows this lane inserts for (wave-aggregated: the first lane of each distinct key of the wave)
@@ -456,7 +467,9 @@ void launch_count_prefix(int32_t const* counts, int32_t nitems, int64_t* prefix,
   CUDF_HIP_TRY(hipGetLastError());
 }
 
-void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint32_t min_count, uint32_t* buckets,
+uint32_t hot_keys_threshold(uint32_t min_count, int64_t sample, uint32_t bits_set) { return hot_threshold(min_count, (sample + 3) / 4, bits_set); }
+
+void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint32_t min_count, uint32_t* buckets, uint32_t const* d_bits_set,
                      uint64_t* table_keys, uint32_t* table_counts, hipStream_t stream)
 {
   // table_counts holds HOT_TABLE counters followed by the one-word "some bucket is crowded" flag
@@ -465,10 +478,10 @@ void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint
   uint32_t* crowded   = table_counts + HOT_TABLE;
   unsigned const grid = static_cast<unsigned>(((sample + 3) / 4 + 255) / 256);
   cudf::detail::prof::scope prof_{"estimate", stream};
-  hipLaunchKernelGGL(k_hot_any, dim3(HOT_BUCKETS / 256), dim3(256), 0, stream, buckets, min_count, crowded);
+  hipLaunchKernelGGL(k_hot_any, dim3(HOT_BUCKETS / 256), dim3(256), 0, stream, buckets, min_count, (sample + 3) / 4, d_bits_set, crowded);
   // a bucket holds sample / 4 / 65536 counted keys on average (4 of a 1M-row sample): only crowded ones can hide a
   // heavy hitter, and their keys are counted exactly
-  hipLaunchKernelGGL(k_hot_collect, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, buckets, crowded, min_count, table_keys,
+  hipLaunchKernelGGL(k_hot_collect, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, buckets, crowded, min_count, d_bits_set, table_keys,
                      table_counts);
   CUDF_HIP_TRY(hipGetLastError());
 }

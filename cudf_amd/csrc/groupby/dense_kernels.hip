@@ -428,6 +428,68 @@ __global__ void __launch_bounds__(1024) k_dense_merge_dump(dense_agg_args const*
   if (threadIdx.x == 0) a.out_count[blockIdx.x] = static_cast<int32_t>(s_dump);
 }
 
+// The same for MANY images of one table (the one-table path: a.nsplit = hundreds of workgroups): work item b = slots [64 b, 64 b + 64);
+// wave w of the workgroup folds the images w, w + 16, ... for its 64 slots (coalesced 512-byte reads), the sixteen partial
+// results meet in LDS one accumulator at a time. (One thread per slot walking all images: 0.4 ms for 512 images.)
+__global__ void __launch_bounds__(1024) k_dense_merge_dump_wide(dense_agg_args const* __restrict__ ap)
+{
+  __shared__ uint64_t s_part[16][64];
+  __shared__ uint32_t s_dump;
+  dense_agg_args const& a = *ap;
+  plan_dev const& p       = a.plan;
+  int const NACC = p.NACC, slots = a.slots, nimg = a.nsplit;
+  int const ls = threadIdx.x & 63, hy = threadIdx.x >> 6;
+  int const s  = static_cast<int>(blockIdx.x) * 64 + ls;
+  bool const in = s < slots;
+  dense_layout const L = make_dense_layout(p, slots, a.occ_acc);
+  unsigned char const* images = reinterpret_cast<unsigned char const*>(a.tables);
+  if (threadIdx.x == 0) s_dump = 0;
+  uint64_t acc[MAX_ACC];
+  bool occupied = false;
+  for (int q = 0; q < NACC; ++q) {
+    int const op      = p.acc[q].op;
+    bool const narrow = acc_is_narrow(op, p.acc[q].src);
+    uint64_t v        = narrow ? 0 : acc_identity(op);
+    if (in)
+      for (int h = hy; h < nimg; h += 16) {
+        unsigned char const* img = images + static_cast<int64_t>(h) * a.image_bytes + L.off[q];
+        if (narrow) v += gload(reinterpret_cast<uint32_t const*>(img) + s);
+        else v = combine_values(op, v, gload(reinterpret_cast<uint64_t const*>(img) + s));
+      }
+    __syncthreads();  // (s_part of the previous accumulator has been read)
+    s_part[hy][ls] = v;
+    __syncthreads();
+    if (hy == 0) {
+      for (int w = 1; w < 16; ++w) v = narrow ? v + s_part[w][ls] : combine_values(op, v, s_part[w][ls]);
+      acc[q] = v;
+      if (q == a.occ_acc) occupied = v != 0;
+    }
+  }
+  if (a.occ_acc < 0) {
+    uint64_t bit = 0;
+    if (in)
+      for (int h = hy; h < nimg; h += 16)
+        bit |= (gload(reinterpret_cast<uint32_t const*>(images + static_cast<int64_t>(h) * a.image_bytes + L.occ_off) + (s >> 5)) >> (s & 31)) & 1u;
+    __syncthreads();
+    s_part[hy][ls] = bit;
+    __syncthreads();
+    if (hy == 0)
+      for (int w = 0; w < 16; ++w) occupied = occupied || s_part[w][ls] != 0;
+  }
+  __syncthreads();
+  int const KU = a.KU, PU = KU + NACC;
+  uint64_t* out        = a.out_records + static_cast<int64_t>(blockIdx.x) * 64 * PU;
+  uint32_t const bmask = (1u << a.map.bits) - 1u;
+  if (hy == 0 && in && occupied) {
+    uint32_t const pos = atomicAdd(&s_dump, 1u);
+    uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
+    dense_store_key_units(a.map, KU, (static_cast<uint32_t>(s) * a.map.mult_inv) & bmask, o);
+    for (int q = 0; q < NACC; ++q) gstore(o + KU + q, acc[q]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.out_count[blockIdx.x] = static_cast<int32_t>(s_dump);
+}
+
 }  // namespace
 
 int dense_occ_acc(plan_dev const& plan)
@@ -462,6 +524,15 @@ static void launch_dense_n(dense_agg_args const& a, dense_agg_args const* d_args
 {
   if (a.rec_tag != nullptr) return launch_dense_t<SIG, NACCT, true>(a, d_args, first_chunk, last_chunk, stream);
   return launch_dense_t<SIG, NACCT, false>(a, d_args, first_chunk, last_chunk, stream);
+}
+
+void launch_dense_merge_dump_wide(dense_agg_args const& a, dense_agg_args const* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.nitems == 1 && a.nsplit >= 1 && a.map.log2P == 0 && a.slots % 64 == 0, "dense keys: one table, its images");
+  for (int q = 0; q < a.plan.NACC; ++q) CUDF_EXPECTS(a.plan.acc[q].op != ANY_U64, "dense keys: integer keys only");
+  cudf::detail::prof::scope prof_{"aggregate_merge", stream};
+  hipLaunchKernelGGL(k_dense_merge_dump_wide, dim3(a.slots / 64), dim3(1024), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
 }
 
 void launch_dense_merge_dump(dense_agg_args const& a, dense_agg_args const* d_args, int dsplit, hipStream_t stream)

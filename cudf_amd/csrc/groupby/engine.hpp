@@ -301,6 +301,9 @@ struct dense_agg_args {
   int32_t* overflow;
   int32_t nitems;
   int32_t block;
+  // launch_aggregate_dense_columns (one table is all the key range needs): rows of the plan's columns, a dummy validity word
+  int64_t nrows;
+  uint32_t const* ones;
 };
 std::size_t dense_table_bytes(plan_dev const& plan, int slots);  // LDS image of one table (multiple of 16)
 int dense_occ_acc(plan_dev const& plan);                          // dense_agg_args::occ_acc of a plan
@@ -310,6 +313,13 @@ void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t str
 // [j * slots / dsplit, (j + 1) * slots / dsplit) of partition d to out_records[(d * dsplit + j) * (slots / dsplit) * PU ...], count in
 // out_count[d * dsplit + j].
 void launch_dense_merge_dump(dense_agg_args const& a, dense_agg_args const* d_args, int dsplit, hipStream_t stream);
+// The whole key range fits ONE direct-address table (low cardinality): a.nsplit workgroups aggregate the row tiles w, w + nsplit, ...
+// straight from the plan's columns (a.nrows rows), each into a table of its own, and leave the images in a.tables for
+// launch_dense_merge_dump (nitems = 1). A key outside the range raises bit 2 of *a.overflow. Replaces, for such keys, the
+// reference's shared-memory aggregation path (compute_shared_memory_aggs.cu:260-353) and the hash tables of aggregate_kernels.hip.
+void launch_aggregate_dense_columns(dense_agg_args const& a, dense_agg_args const* d_args, hipStream_t stream);
+// ... and the fold of those images: work item b dumps the slots [64 b, 64 b + 64) to out_records[b * 64 * PU ...], count in out_count[b]
+void launch_dense_merge_dump_wide(dense_agg_args const& a, dense_agg_args const* d_args, hipStream_t stream);
 
 // Ring scatter of dense-key rows (dense_ring_kernels.hip): every partition owns a ring of record slots in LDS, a row reserves its
 // position with one returning LDS atomic, and only whole aligned 128-byte granules (16 values, 64 or 32 tags) leave the
@@ -399,8 +409,11 @@ void launch_distinct_count(plan_dev const& plan, plan_dev* d_plan, int64_t nrows
 // (HOT_BUCKETS counters, filled by launch_estimate's pass over the sample), then exact sample counts of the keys of the buckets with at least `min_count` rows, in an
 // open-addressing table of HOT_TABLE (key, count) entries (empty key = all ones) that the host reads back and sorts.
 constexpr int HOT_BUCKETS = 65536, HOT_TABLE = 4096, HOT_MAX_KEYS = 256, HOT_SLOTS = 512;
-void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint32_t min_count, uint32_t* buckets,
+// (d_bits_set: the distinct keys of the sample as launch_estimate left them; a key counts as frequent from
+// hot_keys_threshold(min_count, sample, bits_set) = max(min_count, 8x the mean count of a key of the sample) rows)
+void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint32_t min_count, uint32_t* buckets, uint32_t const* d_bits_set,
                      uint64_t* table_keys, uint32_t* table_counts, hipStream_t stream);
+uint32_t hot_keys_threshold(uint32_t min_count, int64_t sample, uint32_t bits_set);
 
 std::size_t aggregate_lds_bytes(plan_dev const& plan, agg_geom const& g);
 // LDS bytes of one table slot: key units, accumulators (4 bytes for counts), state word

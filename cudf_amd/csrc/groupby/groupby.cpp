@@ -668,6 +668,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   int64_t h_ranges[2 * MAX_KU] = {0};  // composite: per key column, as int64
   int64_t final_cap  = 0;        // records per work item in `partial` (0: ag.cap)
   double adjacent_equal = 0.0;   // share of the sampled rows whose successor row carries the same key
+  bool ranges_known     = false; // the estimate pass ran and left the sampled key ranges in h_range / h_ranges
   // ---- distinct-count estimate on a strided sample (skipped when n already fits one table)
   double est_groups = static_cast<double>(n);
   // Small inputs skip the estimate (three memsets, three kernels and a stream synchronisation: about a third of a 10K-row call):
@@ -721,7 +722,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       uint32_t* buckets = hot_buckets;
       uint64_t* tkeys   = sc.alloc<uint64_t>(HOT_TABLE);
       uint32_t* tcounts = sc.alloc<uint32_t>(HOT_TABLE + 1);
-      launch_hot_keys(d_plan, n, sample, hot_min_count, buckets, tkeys, tcounts, s);
+      launch_hot_keys(d_plan, n, sample, hot_min_count, buckets, d_set, tkeys, tcounts, s);
       CUDF_HIP_TRY(hipMemcpyAsync(pin_tkeys, tkeys, HOT_TABLE * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
       CUDF_HIP_TRY(hipMemcpyAsync(pin_tcounts, tcounts, HOT_TABLE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
@@ -734,6 +735,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     if (want_adj && pin_set[2] >= 1024) adjacent_equal = static_cast<double>(pin_set[3]) / static_cast<double>(pin_set[2]);
     if (dense_candidate) std::memcpy(h_range, pin_range, 16);
     if (dense_composite) std::memcpy(h_ranges, pin_ranges, sizeof(h_ranges));
+    ranges_known = dense_candidate || dense_composite;
     if (hot_eligible) {
       h_tkeys.assign(pin_tkeys, pin_tkeys + HOT_TABLE);
       h_tcounts.assign(pin_tcounts, pin_tcounts + HOT_TABLE);
@@ -741,7 +743,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     if (hot_eligible) {  // the most frequent keys first, at most HOT_MAX_KEYS of them
       std::vector<std::pair<uint32_t, uint64_t>> cand;
       for (int i = 0; i < HOT_TABLE; ++i)
-        if (h_tkeys[i] != ~uint64_t{0} && h_tcounts[i] >= hot_min_count) cand.emplace_back(h_tcounts[i], h_tkeys[i]);
+        if (h_tkeys[i] != ~uint64_t{0} && h_tcounts[i] >= hot_keys_threshold(hot_min_count, sample, h_set)) cand.emplace_back(h_tcounts[i], h_tkeys[i]);
       std::sort(cand.begin(), cand.end(), [](auto const& a, auto const& b) { return a.first > b.first; });
       if (cand.size() > HOT_MAX_KEYS) cand.resize(HOT_MAX_KEYS);
       for (auto const& c : cand) hot_keys.push_back(c.second);
@@ -904,6 +906,63 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     aa.nitems      = nitems;
     launch_aggregate(aa, sc.alloc<agg_args>(1), s);
   };
+  // The dense map of the key columns from the sampled ranges (h_range / h_ranges): lo, range, the mixed-radix digits of composite
+  // keys. False if the keys are not dense-eligible or span too much.
+  auto dense_map_from_sample = [&](dense_map& dm, bool tight = false) -> bool {
+    bool dense_ok = false;
+    if (!ranges_known) return false;
+    if (dense_candidate) {
+      // one plain 8-byte key: range from the sample, widened by a margin (the sample's extremes of a dense column miss the
+      // true ones by about range / sample); a key outside [lo, lo + range) voids the attempt (overflow bit 2): redone by hash
+      uint64_t const width  = h_range[1] - h_range[0];  // exact in two's complement for either ordering
+      // (tight: a handful of groups, every one of them sampled hundreds of times - the one-table path wants a small table)
+      uint64_t const margin = tight ? std::max<uint64_t>(width / 32, 64) : std::clamp<uint64_t>(width / 64, 4096, uint64_t{1} << 26);
+      uint64_t lo, hi;
+      if (dense_signed) {
+        int64_t const l = static_cast<int64_t>(h_range[0]), h = static_cast<int64_t>(h_range[1]);
+        lo = static_cast<uint64_t>(l < INT64_MIN + static_cast<int64_t>(margin) ? INT64_MIN : l - static_cast<int64_t>(margin));
+        hi = static_cast<uint64_t>(h > INT64_MAX - static_cast<int64_t>(margin) ? INT64_MAX : h + static_cast<int64_t>(margin));
+      } else {
+        lo = h_range[0] < margin ? 0 : h_range[0] - margin;
+        hi = h_range[1] > UINT64_MAX - margin ? UINT64_MAX : h_range[1] + margin;
+      }
+      dm.lo    = lo;
+      dm.range = hi - lo + 1;  // (0 if the keys span the whole type: fails the test below)
+      dense_ok = width <= (uint64_t{1} << 30) && dm.range != 0;
+    } else {
+      // composite: every key column contributes the digit (value - lo_c) of a mixed-radix index, last column fastest
+      double total = 1.0;
+      dense_ok     = true;
+      for (int c = 0; c < p.nkeycols; ++c) {
+        int64_t const l = h_ranges[2 * c], h = h_ranges[2 * c + 1];
+        if (l > h || static_cast<double>(h) - static_cast<double>(l) > 1e9) { dense_ok = false; break; }  // (no valid sampled value / wide)
+        int64_t const width  = h - l;
+        int64_t const margin = width / 64 + (width >= 64 ? 2 : 0);
+        dense_key& dk = dm.key[c];
+        dk.lo        = static_cast<uint64_t>(l - margin);
+        dk.range     = static_cast<uint32_t>(width + 2 * margin + 1);
+        dk.col       = static_cast<int8_t>(c);
+        dk.unit      = static_cast<int8_t>(hp.key_unit[c]);
+        dk.half      = static_cast<int8_t>(hp.key_half[c]);
+        dk.is_signed = p.cols[c].cls == cudf::detail::CLS_SINT;
+        dk.width     = p.cols[c].width;
+        total *= static_cast<double>(dk.range);
+      }
+      dense_ok = dense_ok && total <= static_cast<double>(uint64_t{1} << 30);
+      if (dense_ok) {
+        uint64_t stride = 1;
+        for (int c = p.nkeycols - 1; c >= 0; --c) {
+          dm.key[c].stride = static_cast<uint32_t>(stride);
+          stride *= dm.key[c].range;
+        }
+        dm.range          = stride;
+        dm.nkeys          = p.nkeycols;
+        dm.value_col      = p.nkeycols;
+        dm.value_nullable = p.cols[p.nkeycols].mask != nullptr;
+      }
+    }
+    return dense_ok;
+  };
   bool pre_failed = false;  // the local pre-aggregation of this call overflowed a chunk's table: not tried again
   for (int attempt = 0;; ++attempt) {
     CUDF_EXPECTS(attempt < 4, "hash groupby: could not fit the groups into LDS tables (pathological key distribution).");
@@ -923,6 +982,68 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     aa.overflow = d_overflow;
 
     bool const fits_one_table = std::min(est_groups * safety, static_cast<double>(n)) <= ag.fill_limit;
+    // ---------------- path T: a key range small enough for ONE direct-address table (up to 8192 groups for SUM + COUNT, whatever
+    // the hash tables would hold): every workgroup aggregates its row tiles straight from the columns into a table of its own
+    // (no hash, no probe, no key compare, no partition pass) and k_dense_merge_dump_wide folds the images.
+    if (forced_p == 0 && allow_dense && env_i64("CUDF_AMD_GB_DENSE_ONE_TABLE", 1) != 0) {
+      dense_map dm{};
+      bool ok = dense_map_from_sample(dm, true);
+      int bits = 6;
+      while (bits < 30 && (uint64_t{1} << bits) < dm.range) ++bits;
+      int const slots         = 1 << bits;
+      std::size_t const image = ok ? dense_table_bytes(p, slots) : 0;
+      ok = ok && dm.range <= static_cast<uint64_t>(slots) && image <= 96 * 1024;
+      if (ok) {
+        _last_path   = hash_path::DENSE_DIRECT;
+        dm.mult      = 1;
+        dm.mult_inv  = 1;
+        dm.bits      = bits;
+        dm.log2P     = 0;
+        int const DPU    = (dm.nkeys > 0 ? p.KU : 1) + p.NACC;
+        int const nwg    = static_cast<int>(std::clamp<int64_t>(n / 65536, 1, image <= 48 * 1024 ? 512 : 256));
+        int const dsplit = slots / 64;  // (items of the image fold: 64 slots each)
+        dense_agg_args da{};
+        da.plan        = p;
+        da.map         = dm;
+        da.nsplit      = nwg;
+        da.slots       = slots;
+        da.image_bytes = static_cast<int32_t>(image);
+        da.occ_acc     = dense_occ_acc(p);
+        da.KU          = dm.nkeys > 0 ? p.KU : 1;
+        da.tables      = sc.alloc<uint64_t>(static_cast<size_t>(nwg) * image / 8);
+        partial        = sc.alloc<uint64_t>(static_cast<size_t>(slots) * DPU);
+        d_count        = sc.alloc<int32_t>(dsplit);
+        da.out_records = partial;
+        da.out_count   = d_count;
+        da.overflow    = d_overflow;
+        da.nitems      = 1;
+        da.block       = 1024;
+        da.nrows       = n;
+        if (dm.nkeys > 0) {
+          uint32_t* ones = sc.alloc<uint32_t>(16);
+          CUDF_HIP_TRY(hipMemsetAsync(ones, 0xff, 64, s));
+          da.ones = ones;
+        }
+        dense_agg_args* d_da = sc.alloc<dense_agg_args>(1);
+        store_args(da, d_da, s);
+        launch_aggregate_dense_columns(da, d_da, s);
+        launch_dense_merge_dump_wide(da, d_da, s);
+        nitems    = dsplit;
+        final_cap = 64;
+        int32_t const h_ov = overflow_and_counts();
+        if (env_i64("CUDF_AMD_DEBUG", 0))
+          fprintf(stderr, "[cudf_amd] dense keys (one table): nkeys=%d lo=%lld range=%llu slots=%d image=%zu B workgroups=%d overflow=%d\n", dm.nkeys,
+                  (long long)dm.lo, (unsigned long long)dm.range, slots, image, nwg, h_ov);
+        if (h_ov == 0) break;
+        // a key outside the sampled range: the hash tables
+        allow_dense = false;
+        final_cap   = 0;
+        sc.bufs.clear();
+        d_overflow = sc.alloc<int32_t>(1);
+        --attempt;
+        continue;
+      }
+    }
     if (fits_one_table && forced_p == 0) {
       // ---------------- path S: every workgroup aggregates a row chunk in LDS, then partials are merged
       _last_path          = hash_path::LDS_SINGLE_PASS;
@@ -1047,56 +1168,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
       bool const ring_env = env_i64("CUDF_AMD_GB_DENSE_RING", 1) != 0 && env_i64("CUDF_AMD_GB_CHUNKED", 0) == 0;
       if (allow_dense && forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !forced_exact) {
         dense_map dm{};
-        bool dense_ok = false;
-        if (dense_candidate) {
-          // one plain 8-byte key: range from the sample, widened by a margin (the sample's extremes of a dense column miss the
-          // true ones by about range / sample); a key outside [lo, lo + range) voids the attempt (overflow bit 2): redone by hash
-          uint64_t const width  = h_range[1] - h_range[0];  // exact in two's complement for either ordering
-          uint64_t const margin = std::clamp<uint64_t>(width / 64, 4096, uint64_t{1} << 26);
-          uint64_t lo, hi;
-          if (dense_signed) {
-            int64_t const l = static_cast<int64_t>(h_range[0]), h = static_cast<int64_t>(h_range[1]);
-            lo = static_cast<uint64_t>(l < INT64_MIN + static_cast<int64_t>(margin) ? INT64_MIN : l - static_cast<int64_t>(margin));
-            hi = static_cast<uint64_t>(h > INT64_MAX - static_cast<int64_t>(margin) ? INT64_MAX : h + static_cast<int64_t>(margin));
-          } else {
-            lo = h_range[0] < margin ? 0 : h_range[0] - margin;
-            hi = h_range[1] > UINT64_MAX - margin ? UINT64_MAX : h_range[1] + margin;
-          }
-          dm.lo    = lo;
-          dm.range = hi - lo + 1;  // (0 if the keys span the whole type: fails the test below)
-          dense_ok = width <= (uint64_t{1} << 30) && dm.range != 0;
-        } else {
-          // composite: every key column contributes the digit (value - lo_c) of a mixed-radix index, last column fastest
-          double total = 1.0;
-          dense_ok     = true;
-          for (int c = 0; c < p.nkeycols; ++c) {
-            int64_t const l = h_ranges[2 * c], h = h_ranges[2 * c + 1];
-            if (l > h || static_cast<double>(h) - static_cast<double>(l) > 1e9) { dense_ok = false; break; }  // (no valid sampled value / wide)
-            int64_t const width  = h - l;
-            int64_t const margin = width / 64 + (width >= 64 ? 2 : 0);
-            dense_key& dk = dm.key[c];
-            dk.lo        = static_cast<uint64_t>(l - margin);
-            dk.range     = static_cast<uint32_t>(width + 2 * margin + 1);
-            dk.col       = static_cast<int8_t>(c);
-            dk.unit      = static_cast<int8_t>(hp.key_unit[c]);
-            dk.half      = static_cast<int8_t>(hp.key_half[c]);
-            dk.is_signed = p.cols[c].cls == cudf::detail::CLS_SINT;
-            dk.width     = p.cols[c].width;
-            total *= static_cast<double>(dk.range);
-          }
-          dense_ok = dense_ok && total <= static_cast<double>(uint64_t{1} << 30);
-          if (dense_ok) {
-            uint64_t stride = 1;
-            for (int c = p.nkeycols - 1; c >= 0; --c) {
-              dm.key[c].stride = static_cast<uint32_t>(stride);
-              stride *= dm.key[c].range;
-            }
-            dm.range          = stride;
-            dm.nkeys          = p.nkeycols;
-            dm.value_col      = p.nkeycols;
-            dm.value_nullable = p.cols[p.nkeycols].mask != nullptr;
-          }
-        }
+        bool dense_ok = dense_map_from_sample(dm);
         int bits = 14;
         while (bits < 31 && (uint64_t{1} << bits) < dm.range) ++bits;
         // ---- ring scatter (dense_ring_kernels.hip): 12-byte records in two streams, one or two levels of fan-out 16 ... 256, the

@@ -619,6 +619,41 @@ def test_heavy_hitters(G, oracle, vt, hot_fraction):
     _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), ["sum", "count_valid", "mean"])], expect_path="PARTITIONED_LDS")
 
 
+@pytest.mark.parametrize("shape", ["plain", "int32_key_nullable_value", "two_keys", "sorted", "one_hot_key", "outlier"])
+def test_dense_keys_one_table(G, oracle, monkeypatch, shape):
+    """Few groups over a small key range, n >= 4M: every workgroup aggregates its rows straight from the columns into a direct-address
+    table of its own (path T of groupby.cpp), the images are merged. A wave that meets in one slot (sorted rows, one hot key) is
+    reduced across the wave; a key outside the sampled range sends the call to the hash tables."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(111)
+    n = 4_400_000
+    kinds = ["sum", "count_valid", "count_all", "min", "max", "mean"]
+    expect = "DENSE_DIRECT"
+    if shape == "plain":
+        keys, vals, kinds = [rng.integers(-300, 300, n, dtype=np.int64)], HostColumn(rng.random(n), None, "float64"), ["sum", "count_valid"]
+    elif shape == "int32_key_nullable_value":
+        keys = [HostColumn(rng.integers(0, 900, n).astype(np.int32), None, "int32")]
+        vals = HostColumn(rng.integers(-50, 50, n).astype(np.int16), rng.random(n) > 0.3, "int16")
+    elif shape == "two_keys":
+        keys = [HostColumn(rng.integers(0, 40, n).astype(np.uint8), None, "uint8"), HostColumn(rng.integers(-20, 20, n).astype(np.int64), rng.random(n) > 0.1, "int64")]
+        vals = HostColumn(rng.random(n), rng.random(n) > 0.1, "float64")
+    elif shape == "sorted":
+        keys, vals = [np.arange(n, dtype=np.int64) // 9000], HostColumn(rng.random(n), None, "float64")
+    elif shape == "one_hot_key":
+        k = rng.integers(0, 2000, n, dtype=np.int64)
+        k[rng.random(n) < 0.7] = 1234
+        keys, vals, kinds = [k], HostColumn(rng.integers(-9, 9, n, dtype=np.int64), None, "int64"), ["sum", "count_all"]
+    else:
+        k = rng.integers(0, 700, n, dtype=np.int64)
+        k[n // 2 + 5] = 10**9  # one key the sample will not see
+        keys, vals, kinds, expect = [k], HostColumn(rng.random(n), None, "float64"), ["sum", "count_valid"], None
+    _check_against_oracle(G, oracle, keys, [(vals, kinds)], expect_path=expect)
+    if shape == "outlier":
+        assert G.last_path.name != "DENSE_DIRECT"
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE_ONE_TABLE", "0")
+    _check_against_oracle(G, oracle, keys, [(vals, kinds)])
+
+
 @pytest.mark.parametrize("shape", ["sorted", "clustered", "sorted_nulls_two_keys", "float_keys"])
 def test_sorted_and_clustered_keys_are_preaggregated(G, oracle, monkeypatch, shape):
     """Most rows are followed by a row of the same key (the estimate pass measures it): row chunks are aggregated locally first and
