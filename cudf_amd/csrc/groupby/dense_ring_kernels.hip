@@ -16,8 +16,6 @@
 #include "device_common.hpp"
 #include "dense_loader.hpp"
 
-#include <cstdlib>
-
 namespace cudf::groupby::detail {
 namespace {
 
@@ -429,14 +427,9 @@ void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* 
                "ring scatter: fan-out 16 ... 256, rings of at least two granules");
   CUDF_EXPECTS(a.region_cap % 64 == 0 && a.shift >= 0 && a.shift < 31 && a.slices >= 1 && (!a.tag16 || a.shift <= 15), "ring scatter: region geometry");
   if (a.from_columns) {
-    if (a.map.nkeys > 0) {
-      static int const variant = [] { char const* e = std::getenv("CUDF_AMD_GB_RING_COLS_VARIANT"); return e ? std::atoi(e) : 0; }();
-      if (variant == 1) return launch_ring_t<RING_SRC_COLS, 4, 2>(a, d_args, stream);
-      if (variant == 2) return launch_ring_t<RING_SRC_COLS, 2, 2>(a, d_args, stream);
-      if (variant == 3) return launch_ring_t<RING_SRC_COLS, 3, 2>(a, d_args, stream);
-      if (variant == 4) return launch_ring_t<RING_SRC_COLS, 2, 3>(a, d_args, stream);
-      return launch_ring_t<RING_SRC_COLS, 4, 1>(a, d_args, stream);
-    }
+    // (composite loader: 4 rows per thread, one tile ahead. Measured on C4's first level: two tiles ahead spill - 14.3 ms against
+    // 9.4 - and 2 or 3 rows per thread with two or three tiles ahead take 11.3-13.1 ms: the per-tile barriers and flush do not amortise)
+    if (a.map.nkeys > 0) return launch_ring_t<RING_SRC_COLS, 4, 1>(a, d_args, stream);
     CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1, "ring scatter: one plain key column and one plain value column");
     if (a.hot_n > 0) {
       CUDF_EXPECTS(a.tag16 && a.hot_n <= HOT_MAX_KEYS, "ring scatter: heavy hitters on a single level");

@@ -1000,7 +1000,7 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
         dm.bits      = bits;
         dm.log2P     = 0;
         int const DPU    = (dm.nkeys > 0 ? p.KU : 1) + p.NACC;
-        int const nwg    = static_cast<int>(std::clamp<int64_t>(n / 65536, 1, image <= 48 * 1024 ? 512 : 256));
+        int const nwg    = static_cast<int>(std::clamp<int64_t>(n / 16384, 1, image <= 48 * 1024 ? 512 : 256));
         int const dsplit = slots / 64;  // (items of the image fold: 64 slots each)
         dense_agg_args da{};
         da.plan        = p;
