@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: the headline shape (1B rows, 1M groups) over several seeds and two skews, every result checked exactly against
-torch.bincount (counts) and a float64 scatter-add (sums, relative 1e-9)."""
+torch.bincount (counts) and a float64 scatter-add (sums, relative 1e-9).   soak.py [rows] [groups] [seed,seed,...]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,9 +8,11 @@ import cudf_amd
 from cudf_amd import aggregation as agg, groupby as gb
 from cudf_amd.types import NullPolicy
 dev = torch.device("cuda", 0)
-n, groups = 1_000_000_000, 1_000_000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
+groups = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+seeds = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else list(range(8))
 C = cudf_amd.Column.from_torch
-for seed in range(8):
+for seed in seeds:
     g = torch.Generator(device=dev).manual_seed(1000 + seed)
     if seed < 6:
         k = torch.randint(0, groups, (n,), generator=g, device=dev, dtype=torch.int64)
