@@ -794,10 +794,11 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
   // Heavy hitters stay in the (first-level) scatter workgroups: `pa` gets the key list and the per-workgroup partial
   // buffers; merge_hot() folds those partials into one more work item behind the tables' items.
   auto setup_hot = [&](part_args& pa, int64_t P) -> bool {
+    // (first the cheap tests: a scatter without write-combining has granule 0, and wc_scatter_lds_bytes divides by it - 1B rows with
+    // two value columns on 1M groups, 24-byte records at 1024 partitions, died of SIGFPE here)
+    if (hot_keys.empty() || pa.wc_granule == 0 || !p.simple || RU != 2) return false;
     auto const wc_lds = cudf::detail::wc_scatter_lds_bytes(5 * 1024, static_cast<std::size_t>(P), pa.wc_granule, 2);
-    bool const hot = !hot_keys.empty() && pa.wc_granule != 0 && p.simple && RU == 2 &&
-                     wc_lds + partition_hot_lds_bytes() + 1200 <= 160 * 1024;  // (the LDS table needs room next to the tile)
-    if (!hot) return false;
+    if (wc_lds + partition_hot_lds_bytes() + 1200 > 160 * 1024) return false;  // (the LDS table needs room next to the tile)
     size_t const wgs = static_cast<size_t>(pa.geom.slices);
     uint64_t* d_hot  = sc.alloc<uint64_t>(HOT_MAX_KEYS);
     CUDF_HIP_TRY(hipMemcpyAsync(d_hot, hot_keys.data(), hot_keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));

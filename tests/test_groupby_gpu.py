@@ -619,6 +619,17 @@ def test_heavy_hitters(G, oracle, vt, hot_fraction):
     _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), ["sum", "count_valid", "mean"])], expect_path="PARTITIONED_LDS")
 
 
+def test_two_value_columns_at_1024_partitions(G, oracle):
+    """Two value columns (24-byte records) over enough groups for 1024 partitions: the write-combining scatter does not fit there
+    (granule 0), and the heavy-hitter set-up divided by that granule - SIGFPE on 1B rows x 1M groups. Also with three columns."""
+    rng = np.random.default_rng(131)
+    n = 4_500_000
+    k = rng.integers(0, 1_200_000, n, dtype=np.int64) * 977 + 13  # sparse keys: the hash tables
+    vals = [rng.random(n), rng.integers(-100, 100, n, dtype=np.int64), rng.random(n)]
+    _check_against_oracle(G, oracle, [k], [(vals[0], ["sum", "mean"]), (vals[1], ["sum", "mean"])], expect_path="PARTITIONED_LDS")
+    _check_against_oracle(G, oracle, [k], [(vals[0], ["sum"]), (vals[1], ["max", "count_valid"]), (vals[2], ["min"])], expect_path="PARTITIONED_LDS")
+
+
 @pytest.mark.parametrize("shape", ["plain", "int32_key_nullable_value", "two_keys", "sorted", "one_hot_key", "outlier"])
 def test_dense_keys_one_table(G, oracle, monkeypatch, shape):
     """Few groups over a small key range, n >= 4M: every workgroup aggregates its rows straight from the columns into a direct-address
