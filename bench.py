@@ -237,6 +237,21 @@ def main():
         def step():
             return D.distributed_groupby_sum_count(keys, vals, stream=stream, mode=dist_mode)
 
+        # The in-library exchange has only ever run at world size 1 (this pool hands out one GPU). If its first step RAISES on any
+        # rank (RCCL not loadable, communicator creation refused), every rank falls back to the same exchange through
+        # torch.distributed - still the literal config-5 form - and the line says so. (A collective that hangs cannot be recovered.)
+        if dist_mode == "shuffle_native":
+            first_error = None
+            try:
+                step()
+            except Exception as e:  # noqa: BLE001
+                first_error = repr(e)
+            ok = torch.tensor([0 if first_error else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                sys.stderr.write(f"[bench] shuffle_native failed on some rank ({first_error}); falling back to the torch.distributed exchange\n")
+                dist_mode = "shuffle"
+
     def barrier():
         if world > 1:
             dist.barrier()
