@@ -57,6 +57,10 @@ def parse():
                          "range (hash table instead of the direct-address table); c4 = configs[3] multi-key groupby. One GPU only.")
     ap.add_argument("--scale", type=float, default=1.0, help="c3 / c4: fraction of the BASELINE size (parity / smoke runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="c2 at one GPU: skip the variants (hash-table keys, two value columns) and the C3 / C3-sparse / C4 runs that the "
+                         "headline line otherwise carries in `hash_table_variant`, `two_value_columns_variant` and `secondary`")
+    ap.add_argument("--variant-steps", type=int, default=5)
     ap.add_argument("--cpu-sample-rows", type=int, default=60_000_000)
     return ap.parse_args()
 
@@ -174,6 +178,35 @@ def run_config(args, json_fd):
     os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 
+def run_secondary_children():
+    """configs[2] (dense and sparse keys) and configs[3] at full size, one child process each (python bench.py --config ...)."""
+    import subprocess
+    out = {}
+    budget_s = float(os.environ.get("BENCH_SECONDARY_TIMEOUT_S", "100"))
+    for cfg in ("c3", "c3sparse", "c4"):
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s, cwd=ROOT)
+            lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                out[cfg] = {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr.decode(errors="replace")[-400:]}
+                continue
+            doc = json.loads(lines[-1])
+            checks = doc["config"]["checks"]
+            out[cfg] = {"ms_per_step": doc["ms_per_step"], "value": doc["value"], "unit": doc["unit"], "steps": doc["steps"],
+                        "frac": doc["roofline"]["frac"], "whole_call_frac": doc["roofline"]["whole_call_frac"],
+                        "dominant_kernel": doc["roofline"]["kernel"], "kernels_ms_per_step": doc["roofline"]["kernels_ms_per_step"],
+                        "checks": checks, "checks_ok": all(v for k, v in checks.items()
+                                         if isinstance(v, bool) and (k.endswith("_ok") or k in ("keys_equal", "no_null_rows", "pairs_distinct"))),
+                        "wall_s": time.perf_counter() - t0}
+        except subprocess.TimeoutExpired:
+            out[cfg] = {"error": f"not finished after {budget_s:.0f} s"}
+        except Exception as e:  # noqa: BLE001
+            out[cfg] = {"error": repr(e)}
+    return out
+
+
 def _timeit(fn):
     t0 = time.perf_counter()
     fn()
@@ -276,6 +309,69 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # ---- N == 1, after the primary timed region: the other side of the cliffs next to the headline, in the driver's own record.
+    # hash_table_variant: the same rows with every key multiplied by an odd constant (a bijection: same groups, same counts, but
+    # the keys no longer span a small range, so the open-addressing hash tables serve the call instead of the direct-address ones);
+    # two_value_columns_variant: the same keys with a second float64 column, {a: SUM, COUNT; b: SUM};
+    # secondary: BASELINE configs[2] / configs[3] (and the sparse-key form of the join) at full size, each in a CHILD process (its
+    # own HIP context: a failure there cannot cost the headline its line), with the property checks of bench_configs.py.
+    extras = {}
+    if world == 1 and not force_dist and not args.no_secondary and os.environ.get("BENCH_SECONDARY", "1") != "0":
+        primary_groups = last[1][0].num_rows()
+        last = (last[0], None)
+
+        def timed_variant(make_step, what):
+            try:
+                vstep = make_step()
+                vstep()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                out = None
+                for _ in range(args.variant_steps):
+                    out = None
+                    out = vstep()
+                torch.cuda.synchronize()
+                vdt = (time.perf_counter() - t1) / args.variant_steps
+                g, (uk, _res) = out
+                return {"ms_per_step": vdt * 1e3, "value": n / vdt, "unit": "rows/s", "steps": args.variant_steps, "path": g.last_path.name,
+                        "groups": uk.num_rows(), "groups_match_primary": uk.num_rows() == primary_groups,
+                        "whole_call_frac": BYTES_PER_ROW * n / vdt / 1e9 / HBM_PEAK_GBS, "what": what}
+            except Exception as e:  # noqa: BLE001 - reported in the line
+                return {"error": repr(e), "what": what}
+
+        def make_hash_step():
+            skeys = keys * 1_000_003
+            scol = cudf_amd.Column.from_torch(skeys)
+
+            def vstep():
+                g = gb.GroupBy(cudf_amd.Table([scol]))
+                return g, g.aggregate([gb.GroupByRequest(vcol, [agg.sum(), agg.count(NullPolicy.EXCLUDE)])], stream=stream)
+            vstep.keep = skeys
+            return vstep
+
+        def make_two_value_step():
+            gen.manual_seed(44 + rank)
+            vals2 = torch.rand(n, generator=gen, device=dev, dtype=torch.float64)
+            v2col = cudf_amd.Column.from_torch(vals2)
+
+            def vstep():
+                g = gb.GroupBy(cudf_amd.Table([kcol]))
+                return g, g.aggregate([gb.GroupByRequest(vcol, [agg.sum(), agg.count(NullPolicy.EXCLUDE)]),
+                                       gb.GroupByRequest(v2col, [agg.sum()])], stream=stream)
+            vstep.keep = vals2
+            return vstep
+
+        extras["hash_table_variant"] = timed_variant(
+            make_hash_step, "C2 with keys x 1,000,003 (same rows, same groups; sparse keys: open-addressing LDS hash tables)")
+        torch.cuda.empty_cache()
+        extras["two_value_columns_variant"] = timed_variant(
+            make_two_value_step, "C2 with a second float64 value column: {a: SUM + COUNT_VALID, b: SUM} in one call (24 algorithmic bytes per row)")
+        if "ms_per_step" in extras["two_value_columns_variant"]:
+            tv = extras["two_value_columns_variant"]
+            tv["whole_call_frac"] = 24 * n / (tv["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        torch.cuda.empty_cache()
+        extras["secondary"] = run_secondary_children()
+
     def build_line(pre, pre_error):
         ms_per_step = dt / args.steps * 1e3
         total_rows = n * world
@@ -330,6 +426,8 @@ def main():
                           "what": what}
         if pre_error is not None:
             line["raw_row_shuffle_variant" if other_mode != "preaggregate" else "preaggregated_variant"] = {"error": pre_error}
+        if world == 1 and not force_dist:
+            line.update(extras)
         if world == 1 and not force_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(groups, args.cpu_sample_rows)
         return line

@@ -66,17 +66,49 @@ def make_c4(scale, dev=None):
         return grp, grp.aggregate([gb.GroupByRequest(vals, [agg.mean(), agg.min(), agg.max()])], stream=torch.cuda.current_stream())
 
     def check(result):
+        """Per-group torch reference (as the full-size C2 test does): the groups are exactly the distinct valid key pairs, every
+        group's COUNT-derived validity, MIN and MAX are bit-exact, every MEAN is sum / count within the order-of-summation bound
+        (kat.sum_atol: m^2 * eps * max|v| for groups of at most m rows)."""
+        import numpy as np
         grp, (uk, res) = result
         G = uk.num_rows()
-        mean, mn, mx = [c.to_torch() for c in res[0].columns()]
-        # properties: group count == distinct valid (k0,k1) pairs; global min / max exact; every mean within [min, max]
-        combo = (k0 * 1000 + k1.to(torch.int64))[k1valid]
-        distinct = int(torch.unique(combo).numel())
+        NG = 10_000 * 1_000
+        combo = k0 * 1000 + k1.to(torch.int64)
+        cnt_rows = torch.bincount(combo[k1valid], minlength=NG)          # rows per key pair (NULL k1 dropped: EXCLUDE)
         sel = k1valid & vvalid
-        ok = ~torch.isnan(mean)
-        return {"groups": G, "distinct_pairs": distinct, "groups_ok": G == distinct,
-                "global_max_ok": bool(float(mx[ok].max()) == float(v[sel].max())), "global_min_ok": bool(float(mn[ok].min()) == float(v[sel].min())),
-                "mean_within_min_max": bool(((mean[ok] >= mn[ok]) & (mean[ok] <= mx[ok])).all()), "path": grp.last_path.name}
+        idx, vs = combo[sel], v[sel]
+        exp_cnt = torch.bincount(idx, minlength=NG)                      # valid values per key pair
+        exp_sum = torch.zeros(NG, dtype=torch.float64, device=dev).scatter_add_(0, idx, vs)
+        exp_min = torch.full((NG,), float("inf"), dtype=torch.float64, device=dev).scatter_reduce_(0, idx, vs, "amin", include_self=True)
+        exp_max = torch.full((NG,), float("-inf"), dtype=torch.float64, device=dev).scatter_reduce_(0, idx, vs, "amax", include_self=True)
+        del idx, vs, sel, combo
+        distinct = int((cnt_rows > 0).sum())
+        gk0, gk1 = [c.to_torch() for c in uk.columns()]
+        gid = gk0 * 1000 + gk1.to(torch.int64)
+        keys_in_range = bool(((gid >= 0) & (gid < NG)).all())
+        gid = gid.clamp(0, NG - 1)
+        keys_once = bool(torch.unique(gid).numel() == G) and bool((cnt_rows[gid] > 0).all())
+        cols = res[0].columns()
+        mean, mn, mx = [c.to_torch() for c in cols]
+        valid = [torch.from_numpy(c.to_numpy()[1]).to(dev) if c.nullable() else torch.ones(G, dtype=torch.bool, device=dev) for c in cols]
+        has = exp_cnt[gid] > 0  # a group whose values are all NULL yields NULL results
+        masks_ok = all(bool((vd == has).all()) for vd in valid)
+        m = float(exp_cnt.max())
+        tol = m * m * float(np.finfo(np.float64).eps)
+        c_g = exp_cnt[gid].clamp(min=1).to(torch.float64)
+        mean_err = float(((mean - exp_sum[gid] / c_g).abs() * c_g)[has].max()) if bool(has.any()) else 0.0
+        min_ok = bool((mn[has] == exp_min[gid][has]).all())
+        max_ok = bool((mx[has] == exp_max[gid][has]).all())
+        ok = has
+        out = {"groups": G, "distinct_pairs": distinct, "groups_ok": G == distinct and keys_in_range and keys_once,
+               "masks_ok": masks_ok, "per_group_min_ok": min_ok, "per_group_max_ok": max_ok,
+               "per_group_mean_ok": mean_err <= tol, "mean_sum_err": mean_err, "mean_sum_tol": tol,
+               # the properties of the earlier check, kept so that old and new records can be compared
+               "global_max_ok": bool(float(mx[ok].max()) == float(exp_max.max())) if bool(ok.any()) else True,
+               "global_min_ok": bool(float(mn[ok].min()) == float(exp_min.min())) if bool(ok.any()) else True,
+               "mean_within_min_max": bool(((mean[ok] >= mn[ok]) & (mean[ok] <= mx[ok])).all()), "path": grp.last_path.name}
+        out["all_ok"] = all(out[k] for k in ("groups_ok", "masks_ok", "per_group_min_ok", "per_group_max_ok", "per_group_mean_ok"))
+        return out
 
     return run, check, n, n * (8 + 4 + 8) + 2 * n / 8
 

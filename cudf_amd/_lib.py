@@ -22,6 +22,7 @@ _P = C.c_void_p
 SYMBOLS = {
     "cudf_amd_last_error": (C.c_char_p, []),
     "cudf_amd_version": (C.c_char_p, []),
+    "cudf_amd_abi_version": (C.c_int32, []),
     "cudf_amd_malloc": (C.c_int, [C.POINTER(_P), C.c_size_t, _P]),
     "cudf_amd_free": (C.c_int, [_P, _P]),
     "cudf_amd_memcpy": (C.c_int, [_P, _P, C.c_size_t, C.c_int32, _P]),
@@ -60,6 +61,12 @@ SYMBOLS = {
     "cudf_amd_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "cudf_amd_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.POINTER(_P)]),
     "cudf_amd_comm_destroy": (None, [_P]),
+    "cudf_amd_comm_create_loopback": (C.c_int, [C.c_int32, C.POINTER(_P)]),
+    "cudf_amd_comm_set_max_message_bytes": (C.c_int, [_P, C.c_int64]),
+    "cudf_amd_plan_exchange": (C.c_int, [C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64)]),
+    "cudf_amd_shuffle_join": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.POINTER(ColumnView), C.c_int32, C.c_int32, _P,
+                                        C.POINTER(_P)]),
     "cudf_amd_range_partition": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P,
                                            C.POINTER(_P), C.POINTER(C.c_int32)]),
     "cudf_amd_shuffle": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.POINTER(C.c_int32), C.c_int32, _P, C.POINTER(_P)]),

@@ -50,7 +50,7 @@ class _TableHandle:
 
 class Column:
     def __init__(self, dtype: DataType, size: int, data_ptr, mask_ptr=None, null_count: int = 0, offset: int = 0,
-                 owner=None, children=None):
+                 owner=None, children=None, stream=None):
         self._dtype = dtype
         self._size = int(size)
         self._data = int(data_ptr or 0)
@@ -59,6 +59,12 @@ class Column:
         self._offset = int(offset)
         self._owner = owner  # keeps the underlying memory alive
         self._children = list(children or [])  # STRUCT columns (SUM_OVERFLOW: [sum, overflow])
+        # The stream that produced this column (results of groupby / join / gather are stream-ordered, like every libcudf
+        # result): host copies and synchronisations below run on it. None = the default stream (caller-provided memory).
+        self._stream = stream
+
+    def stream(self):
+        return self._stream
 
     # ---- pylibcudf.Column accessors
     def type(self) -> DataType:
@@ -142,25 +148,27 @@ class Column:
     def to_numpy(self):
         """Returns (data, valid_or_None) on the host. A STRUCT column returns the tuple of its children's data."""
         lib = _lib.load()
+        sp = _stream_ptr(self._stream)
         if self._children:
             data = tuple(c.to_numpy()[0] for c in self._children)
             valid = None
             if self._mask:
-                valid = Column(DataType(TypeId.INT8), self._size, 0, self._mask, self._null_count, self._offset, self._owner)._valid_bits()
+                valid = Column(DataType(TypeId.INT8), self._size, 0, self._mask, self._null_count, self._offset, self._owner,
+                               stream=self._stream)._valid_bits()
             return data, valid
         npdt = self._dtype.numpy_dtype()
         raw_dt = np.uint8 if npdt == np.bool_ else npdt
         out = np.empty(self._size, dtype=raw_dt)
         if self._size:
             src = self._data + self._offset * out.itemsize
-            _lib.check(lib.cudf_amd_memcpy(out.ctypes.data, C.c_void_p(src), out.nbytes, 1, None))
+            _lib.check(lib.cudf_amd_memcpy(out.ctypes.data, C.c_void_p(src), out.nbytes, 1, sp))
         valid = None
         if self._mask:
             nwords = (self._offset + self._size + 31) // 32
             words = np.empty(max(nwords, 1), dtype=np.uint32)
             if nwords:
-                _lib.check(lib.cudf_amd_memcpy(words.ctypes.data, C.c_void_p(self._mask), nwords * 4, 1, None))
-        _lib.check(lib.cudf_amd_stream_synchronize(None))
+                _lib.check(lib.cudf_amd_memcpy(words.ctypes.data, C.c_void_p(self._mask), nwords * 4, 1, sp))
+        _lib.check(lib.cudf_amd_stream_synchronize(sp))
         if self._mask:
             bits = np.unpackbits(words.view(np.uint8), bitorder="little")
             valid = bits[self._offset:self._offset + self._size].astype(bool)
@@ -170,11 +178,12 @@ class Column:
 
     def _valid_bits(self):
         lib = _lib.load()
+        sp = _stream_ptr(self._stream)
         nwords = (self._offset + self._size + 31) // 32
         words = np.empty(max(nwords, 1), dtype=np.uint32)
         if nwords:
-            _lib.check(lib.cudf_amd_memcpy(words.ctypes.data, C.c_void_p(self._mask), nwords * 4, 1, None))
-        _lib.check(lib.cudf_amd_stream_synchronize(None))
+            _lib.check(lib.cudf_amd_memcpy(words.ctypes.data, C.c_void_p(self._mask), nwords * 4, 1, sp))
+        _lib.check(lib.cudf_amd_stream_synchronize(sp))
         bits = np.unpackbits(words.view(np.uint8), bitorder="little")
         return bits[self._offset:self._offset + self._size].astype(bool)
 
@@ -184,8 +193,12 @@ class Column:
         npdt = self._dtype.numpy_dtype()
         if npdt == np.bool_:
             npdt = np.dtype(np.uint8)
-        return {"shape": (self._size,), "typestr": npdt.str, "version": 2,
-                "data": (self._data + self._offset * npdt.itemsize, False)}
+        cai = {"shape": (self._size,), "typestr": npdt.str, "version": 3,
+               "data": (self._data + self._offset * npdt.itemsize, False)}
+        sp = _stream_ptr(self._stream)
+        if sp is not None and sp.value:
+            cai["stream"] = int(sp.value)  # the consumer orders its reads behind the producing stream
+        return cai
 
     def to_torch(self):
         """Zero-copy torch tensor over the column's data (validity is not carried); keeps the column alive."""
@@ -193,6 +206,11 @@ class Column:
 
         if self._size == 0:
             return torch.empty(0, dtype=torch.from_numpy(np.empty(0, self._dtype.numpy_dtype())).dtype, device="cuda")
+        sp = _stream_ptr(self._stream)
+        # produced on another stream than torch's current one: the tensor is handed out only once it is complete
+        # (work queued on torch's current stream is ordered behind the producer by the stream itself)
+        if sp is not None and sp.value and int(sp.value) != int(torch.cuda.current_stream().cuda_stream):
+            _lib.check(_lib.load().cudf_amd_stream_synchronize(sp))
         t = torch.as_tensor(self, device="cuda")
         t._cudf_amd_owner = self
         return t
@@ -222,7 +240,7 @@ class Table:
         return arr
 
     @staticmethod
-    def _from_handle(handle) -> "Table":
+    def _from_handle(handle, stream=None) -> "Table":
         lib = _lib.load()
         owner = _TableHandle(handle)
         cols = []
@@ -234,7 +252,7 @@ class Table:
                 cv = _lib.ColumnView()
                 _lib.check(lib.cudf_amd_table_column_child(handle, i, j, C.byref(cv)))
                 children.append(Column(DataType(TypeId(cv.type_id), cv.scale), cv.size, cv.data, cv.null_mask, cv.null_count,
-                                       cv.offset, owner))
+                                       cv.offset, owner, stream=stream))
             cols.append(Column(DataType(TypeId(v.type_id), v.scale), v.size, v.data, v.null_mask, v.null_count,
-                               v.offset, owner, children))
+                               v.offset, owner, children, stream=stream))
         return Table(cols)

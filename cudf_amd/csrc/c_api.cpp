@@ -129,7 +129,10 @@ std::unique_ptr<cudf::groupby_aggregation> make_agg(int32_t kind, int32_t const*
 extern "C" {
 
 const char* cudf_amd_last_error(void) { return g_last_error.c_str(); }
-const char* cudf_amd_version(void) { return "cudf_amd 0.1.0 (gfx950; libcudf 26.10 API subset)"; }
+const char* cudf_amd_version(void) { return "cudf_amd 0.3.0 (gfx950; libcudf 26.10 API subset)"; }
+// Bumped whenever a struct layout or the meaning of an argument of this header changes (2: cudf_amd_aggregation_request gained
+// `params`, cudf_amd_hash_partition writes num_partitions + 1 offsets; 3: loopback communicators, shuffle_join).
+int32_t cudf_amd_abi_version(void) { return CUDF_AMD_ABI_VERSION; }
 
 // sizes of the live cudf_amd_malloc allocations: the resource's deallocate takes the size, the C ABI's free does not
 static std::mutex g_alloc_mu;
@@ -476,6 +479,61 @@ cudf_amd_status cudf_amd_comm_create(const uint8_t* id_128_bytes, int32_t world_
   });
 }
 void cudf_amd_comm_destroy(cudf_amd_comm_t comm) { delete comm; }
+cudf_amd_status cudf_amd_comm_create_loopback(int32_t world_size, cudf_amd_comm_t* out_comms)
+{
+  return guarded([&] {
+    for (int32_t r = 0; r < world_size; ++r) out_comms[r] = nullptr;
+    auto ends = cudf::distributed::communicator::make_loopback(world_size);
+    for (int32_t r = 0; r < world_size; ++r) {
+      auto h        = std::make_unique<cudf_amd_comm_s>();
+      h->comm       = std::move(ends[r]);
+      out_comms[r]  = h.release();
+    }
+  });
+}
+cudf_amd_status cudf_amd_comm_set_max_message_bytes(cudf_amd_comm_t comm, int64_t bytes)
+{
+  return guarded([&] {
+    CUDF_EXPECTS(comm != nullptr && comm->comm != nullptr, "null communicator", std::invalid_argument);
+    comm->comm->set_max_message_bytes(bytes);
+  });
+}
+cudf_amd_status cudf_amd_plan_exchange(const int64_t* counts, int32_t world_size, int32_t rank, int64_t* out_recv_count,
+                                       int64_t* out_recv_offset, int64_t* out_biggest)
+{
+  // (host arithmetic only: no device resource is touched, so it runs on a box without a GPU)
+  try {
+    CUDF_EXPECTS(world_size >= 1 && counts != nullptr, "plan_exchange: a world x world count matrix", std::invalid_argument);
+    std::vector<int64_t> m(counts, counts + static_cast<std::size_t>(world_size) * world_size);
+    auto const ep = cudf::distributed::plan_exchange(m, world_size, rank);
+    for (int32_t p = 0; p < world_size; ++p) out_recv_count[p] = ep.recv_count[p];
+    for (int32_t p = 0; p <= world_size; ++p) out_recv_offset[p] = ep.recv_offset[p];
+    *out_biggest = ep.biggest;
+    return CUDF_AMD_OK;
+  } catch (std::invalid_argument const& e) {
+    g_last_error = e.what();
+    return CUDF_AMD_INVALID_ARGUMENT;
+  } catch (std::exception const& e) {
+    g_last_error = e.what();
+    return CUDF_AMD_OTHER_ERROR;
+  }
+}
+cudf_amd_status cudf_amd_shuffle_join(cudf_amd_comm_t comm, const cudf_amd_column_view* left_keys, int32_t num_left,
+                                      const cudf_amd_column_view* right_keys, int32_t num_right, int32_t nulls_equal, void* stream,
+                                      cudf_amd_table_t* out_global_row_ids)
+{
+  return guarded([&] {
+    *out_global_row_ids = nullptr;
+    CUDF_EXPECTS(comm != nullptr && comm->comm != nullptr, "null communicator", std::invalid_argument);
+    auto [l, r] = cudf::distributed::shuffle_join(to_table(left_keys, num_left), to_table(right_keys, num_right), *comm->comm,
+                                                  nulls_equal ? cudf::null_equality::EQUAL : cudf::null_equality::UNEQUAL,
+                                                  cudf::stream_ref{as_stream(stream)});
+    auto h = std::make_unique<cudf_amd_table_s>();
+    h->cols.push_back(std::move(l));
+    h->cols.push_back(std::move(r));
+    *out_global_row_ids = h.release();
+  });
+}
 cudf_amd_status cudf_amd_range_partition(const cudf_amd_column_view* input, int32_t num_columns, const int32_t* key_columns,
                                          int32_t num_key_columns, int32_t num_destinations, void* stream,
                                          cudf_amd_table_t* out_table, int32_t* out_offsets)

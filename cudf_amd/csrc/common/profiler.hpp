@@ -33,4 +33,21 @@ class scope {
   int _slot{-1};
   hipStream_t _stream{};
 };
+
+// roctx range over a public entry point - the counterpart of the reference's CUDF_FUNC_RANGE() NVTX ranges
+// (cpp/include/cudf/detail/nvtx/ranges.hpp:50; first line of groupby.cu:224, join.cu:116). The roctx library
+// (librocprofiler-sdk-roctx / libroctx64) is resolved at run time on first use; without it a range costs one relaxed load.
+// `rocprofv3 --marker-trace` shows the ranges.
+class func_range {
+ public:
+  explicit func_range(char const* name);
+  ~func_range();
+  func_range(func_range const&)            = delete;
+  func_range& operator=(func_range const&) = delete;
+
+ private:
+  bool _pushed{false};
+};
 }  // namespace cudf::detail::prof
+
+#define CUDF_FUNC_RANGE() ::cudf::detail::prof::func_range const cudf_func_range_{__func__}

@@ -14,8 +14,12 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cudf/join/join.hpp>
+
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -76,6 +80,189 @@ rccl_api const& rccl()
     if (r_ != ncclSuccess) CUDF_FAIL(std::string{"RCCL error: "} + rccl().GetErrorString(r_) + " in " #call); \
   } while (0)
 
+// ------------------------------------------------------------------ transports
+class rccl_transport final : public transport {
+ public:
+  rccl_transport(unique_id const& id, int world_size, int rank)
+  {
+    ncclUniqueId nid;
+    std::memcpy(&nid, id.data(), sizeof(nid));
+    CUDF_RCCL_TRY(rccl().CommInitRank(&_comm, world_size, nid, rank));
+  }
+  ~rccl_transport() override
+  {
+    if (_comm != nullptr) (void)rccl().CommDestroy(_comm);
+  }
+  void all_gather(void const* send, void* recv, std::size_t count_int64, hipStream_t stream) override
+  {
+    CUDF_RCCL_TRY(rccl().AllGather(send, recv, count_int64, ncclInt64, _comm, stream));
+  }
+  void group_start() override { CUDF_RCCL_TRY(rccl().GroupStart()); }
+  void send(void const* buf, std::size_t bytes, int peer, hipStream_t stream) override
+  {
+    CUDF_RCCL_TRY(rccl().Send(buf, bytes, ncclInt8, peer, _comm, stream));
+  }
+  void recv(void* buf, std::size_t bytes, int peer, hipStream_t stream) override
+  {
+    CUDF_RCCL_TRY(rccl().Recv(buf, bytes, ncclInt8, peer, _comm, stream));
+  }
+  void group_end() override { CUDF_RCCL_TRY(rccl().GroupEnd()); }
+  [[nodiscard]] void* native_handle() const noexcept override { return _comm; }
+
+ private:
+  ncclComm_t _comm{};
+};
+
+// Loopback: V virtual ranks in one process on one device, one host thread per rank. A collective is a rendezvous of the V
+// threads: every rank drains its stream (its buffers are complete), publishes its pointers, and after the barrier copies what it
+// RECEIVES with device copies on its own stream; a second barrier releases the senders' buffers. Sends and receives between two
+// ranks match in the order they were posted, as RCCL's do.
+struct loopback_hub {
+  explicit loopback_hub(int v) : world{v}, ag_send(v, nullptr), sends(v) {}
+  struct posted {
+    int peer;
+    void const* buf;
+    std::size_t bytes;
+  };
+  int const world;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived{0};
+  std::uint64_t generation{0};
+  bool failed{false};
+  std::vector<void const*> ag_send;         // all_gather: every rank's send buffer
+  std::vector<std::vector<posted>> sends;   // group: what every rank sends, in posting order
+  void barrier()
+  {
+    std::unique_lock<std::mutex> lk{mu};
+    CUDF_EXPECTS(!failed, "loopback transport: another rank failed");
+    std::uint64_t const gen = generation;
+    if (++arrived == world) {
+      arrived = 0;
+      ++generation;
+      cv.notify_all();
+      return;
+    }
+    cv.wait(lk, [&] { return generation != gen || failed; });
+    CUDF_EXPECTS(!failed || generation != gen, "loopback transport: another rank failed");
+  }
+  void fail()
+  {
+    std::lock_guard<std::mutex> lk{mu};
+    failed = true;
+    cv.notify_all();
+  }
+};
+class loopback_transport final : public transport {
+ public:
+  loopback_transport(std::shared_ptr<loopback_hub> hub, int rank) : _hub{std::move(hub)}, _rank{rank} {}
+  void all_gather(void const* send, void* recv, std::size_t count_int64, hipStream_t stream) override
+  {
+    guarded([&] {
+      CUDF_HIP_TRY(hipStreamSynchronize(stream));
+      _hub->ag_send[_rank] = send;
+      _hub->barrier();
+      std::size_t const bytes = count_int64 * sizeof(int64_t);
+      for (int p = 0; p < _hub->world; ++p)
+        CUDF_HIP_TRY(hipMemcpyAsync(static_cast<char*>(recv) + p * bytes, _hub->ag_send[p], bytes, hipMemcpyDeviceToDevice, stream));
+      CUDF_HIP_TRY(hipStreamSynchronize(stream));
+      _hub->barrier();
+    });
+  }
+  void group_start() override
+  {
+    CUDF_EXPECTS(!_open, "loopback transport: group already open");
+    _open = true;
+    _sends.clear();
+    _recvs.clear();
+    _stream = nullptr;
+  }
+  void send(void const* buf, std::size_t bytes, int peer, hipStream_t stream) override
+  {
+    CUDF_EXPECTS(_open && peer >= 0 && peer < _hub->world, "loopback transport: send outside a group or to a rank outside the world");
+    _sends.push_back({peer, buf, bytes});
+    _stream = stream;
+  }
+  void recv(void* buf, std::size_t bytes, int peer, hipStream_t stream) override
+  {
+    CUDF_EXPECTS(_open && peer >= 0 && peer < _hub->world, "loopback transport: recv outside a group or from a rank outside the world");
+    _recvs.push_back({peer, buf, bytes});
+    _stream = stream;
+  }
+  void group_end() override
+  {
+    CUDF_EXPECTS(_open, "loopback transport: no open group");
+    _open = false;
+    guarded([&] {
+      CUDF_HIP_TRY(hipStreamSynchronize(_stream));  // what this rank sends is complete
+      _hub->sends[_rank] = _sends;
+      _hub->barrier();
+      std::vector<std::size_t> next(static_cast<std::size_t>(_hub->world), 0);  // per source: its next unmatched send to this rank
+      for (auto const& r : _recvs) {
+        auto const& from = _hub->sends[r.peer];
+        std::size_t& i   = next[r.peer];
+        while (i < from.size() && from[i].peer != _rank) ++i;
+        CUDF_EXPECTS(i < from.size(), "loopback transport: a receive without a matching send");
+        CUDF_EXPECTS(from[i].bytes == r.bytes, "loopback transport: send and receive sizes differ");
+        CUDF_HIP_TRY(hipMemcpyAsync(const_cast<void*>(r.buf), from[i].buf, r.bytes, hipMemcpyDeviceToDevice, _stream));
+        ++i;
+      }
+      for (int p = 0; p < _hub->world; ++p) {  // every send to this rank must have been received
+        auto const& from = _hub->sends[p];
+        std::size_t i    = next[p];
+        while (i < from.size() && from[i].peer != _rank) ++i;
+        CUDF_EXPECTS(i == from.size(), "loopback transport: a send without a matching receive");
+      }
+      CUDF_HIP_TRY(hipStreamSynchronize(_stream));
+      _hub->barrier();  // the senders' buffers are free again
+    });
+  }
+
+ private:
+  template <typename F>
+  void guarded(F&& f)
+  {
+    try {
+      f();
+    } catch (...) {
+      _hub->fail();  // the other ranks leave their barriers with an error instead of waiting for ever
+      throw;
+    }
+  }
+  std::shared_ptr<loopback_hub> _hub;
+  int _rank;
+  bool _open{false};
+  std::vector<loopback_hub::posted> _sends, _recvs;
+  hipStream_t _stream{nullptr};
+};
+
+// Closes an open group when the scope is left by an exception (a failed Send between GroupStart and GroupEnd used to leave the
+// group open for ever).
+class group_scope {
+ public:
+  explicit group_scope(transport& t) : _t{t} { _t.group_start(); }
+  void end()
+  {
+    _open = false;
+    _t.group_end();
+  }
+  ~group_scope()
+  {
+    if (_open) {
+      try {
+        _t.group_end();
+      } catch (...) {
+      }
+    }
+  }
+  group_scope(group_scope const&)            = delete;
+  group_scope& operator=(group_scope const&) = delete;
+
+ private:
+  transport& _t;
+  bool _open{true};
+};
+
 // ------------------------------------------------------------------ hash-range partition kernels
 constexpr int RP_BLOCK = 1024, RP_R = 4, RP_TILE = RP_BLOCK * RP_R, RP_MAX_PARTS = 64;
 struct rp_args {
@@ -118,18 +305,27 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_hist(rp_args const* __restrict_
 }
 __global__ void __launch_bounds__(64) k_rp_scan(rp_args const* __restrict__ ap)
 {
+  // one lane per destination (nparts <= 64): its rows over all workgroups, a wave-wide exclusive scan over the destinations,
+  // then the cell bases (one lane walking all wgs * nparts cells was a millisecond of dependent loads on every shuffle)
   rp_args const& a = *ap;
-  int const N = a.nparts;
-  if (threadIdx.x == 0) {  // (wgs * nparts <= 64K entries: one lane is enough)
-    int64_t run = 0;
-    for (int d = 0; d < N; ++d) {
-      a.offsets[d] = run;
-      for (int w = 0; w < a.wgs; ++w) {
-        a.cell_base[static_cast<int64_t>(w) * N + d] = run;
-        run += a.counts[static_cast<int64_t>(w) * N + d];
-      }
+  int const N = a.nparts, d = threadIdx.x;
+  int64_t tot = 0;
+  if (d < N)
+    for (int w = 0; w < a.wgs; ++w) tot += a.counts[static_cast<int64_t>(w) * N + d];
+  int64_t inc = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int64_t const t = __shfl_up(inc, o);
+    if (d >= o) inc += t;
+  }
+  if (d < N) {
+    int64_t run  = inc - tot;
+    a.offsets[d] = run;
+    for (int w = 0; w < a.wgs; ++w) {
+      a.cell_base[static_cast<int64_t>(w) * N + d] = run;
+      run += a.counts[static_cast<int64_t>(w) * N + d];
     }
-    a.offsets[N] = run;
+    if (d == N - 1) a.offsets[N] = run;
   }
 }
 template <typename T>
@@ -375,18 +571,42 @@ unique_id communicator::make_unique_id()
   std::memcpy(out.data(), &id, sizeof(id));
   return out;
 }
+communicator::communicator(std::unique_ptr<transport> t, int world_size, int rank) : _transport{std::move(t)}, _world{world_size}, _rank{rank} {}
 communicator::communicator(unique_id const& id, int world_size, int rank) : _world{world_size}, _rank{rank}
 {
   CUDF_EXPECTS(world_size >= 1 && rank >= 0 && rank < world_size, "communicator: rank outside the world", std::invalid_argument);
-  ncclUniqueId nid;
-  std::memcpy(&nid, id.data(), sizeof(nid));
-  ncclComm_t c{};
-  CUDF_RCCL_TRY(rccl().CommInitRank(&c, world_size, nid, rank));
-  _comm = c;
+  _transport = std::make_unique<rccl_transport>(id, world_size, rank);
 }
-communicator::~communicator()
+std::vector<std::unique_ptr<communicator>> communicator::make_loopback(int world_size)
 {
-  if (_comm != nullptr) (void)rccl().CommDestroy(static_cast<ncclComm_t>(_comm));
+  CUDF_EXPECTS(world_size >= 1 && world_size <= RP_MAX_PARTS, "communicator: a loopback world of 1 to 64 ranks", std::invalid_argument);
+  auto hub = std::make_shared<loopback_hub>(world_size);
+  std::vector<std::unique_ptr<communicator>> out;
+  for (int r = 0; r < world_size; ++r)
+    out.push_back(std::unique_ptr<communicator>{new communicator{std::make_unique<loopback_transport>(hub, r), world_size, r}});
+  return out;
+}
+communicator::~communicator() = default;
+void communicator::set_max_message_bytes(std::int64_t bytes)
+{
+  CUDF_EXPECTS(bytes >= 8, "communicator: a message holds at least one 8-byte element", std::invalid_argument);
+  _max_message_bytes = bytes;
+}
+
+exchange_plan plan_exchange(std::vector<std::int64_t> const& counts, int world, int me)
+{
+  CUDF_EXPECTS(world >= 1 && me >= 0 && me < world && counts.size() == static_cast<std::size_t>(world) * world,
+               "plan_exchange: a world x world count matrix and a rank inside the world", std::invalid_argument);
+  exchange_plan ep;
+  ep.recv_count.resize(world);
+  ep.recv_offset.assign(static_cast<std::size_t>(world) + 1, 0);
+  for (int p = 0; p < world; ++p) {
+    ep.recv_count[p]      = counts[static_cast<std::size_t>(p) * world + me];
+    ep.recv_offset[p + 1] = ep.recv_offset[p] + ep.recv_count[p];
+    for (int q = 0; q < world; ++q)
+      if (p != q) ep.biggest = std::max(ep.biggest, counts[static_cast<std::size_t>(p) * world + q]);  // (the own slice is a device copy)
+  }
+  return ep;
 }
 
 // ------------------------------------------------------------------ range_partition
@@ -406,10 +626,11 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> range_partition(table_
 std::unique_ptr<table> shuffle(table_view const& input, std::vector<size_type> const& key_columns, communicator& comm, stream_ref stream,
                                rmm::device_async_resource_ref mr)
 {
+  CUDF_FUNC_RANGE();
   hipStream_t const s = stream.value();
   int const N = comm.size(), me = comm.rank();
-  auto const nc = static_cast<ncclComm_t>(comm.handle());
-  auto tmp      = cudf::get_current_device_resource_ref();
+  transport& link = comm.link();
+  auto tmp        = cudf::get_current_device_resource_ref();
   CUDF_EXPECTS(input.num_columns() >= 1 && input.num_columns() < 60, "shuffle: 1 to 59 columns", std::invalid_argument);
   auto const hashed = input.select(key_columns);
   CUDF_EXPECTS(hashed.num_columns() >= 1, "shuffle: at least one key column", std::invalid_argument);
@@ -419,7 +640,7 @@ std::unique_ptr<table> shuffle(table_view const& input, std::vector<size_type> c
   std::vector<int64_t> h_send(static_cast<std::size_t>(N) + 1, 0), h_all(static_cast<std::size_t>(N + 1) * N, 0);
   h_send[N] = static_cast<int64_t>(nullable_bits(input));
   CUDF_HIP_TRY(hipMemcpyAsync(ctl_send.data(), h_send.data(), ctl_send.size(), hipMemcpyHostToDevice, s));
-  CUDF_RCCL_TRY(rccl().AllGather(ctl_send.data(), ctl_recv.data(), static_cast<std::size_t>(N) + 1, ncclInt64, nc, s));
+  link.all_gather(ctl_send.data(), ctl_recv.data(), static_cast<std::size_t>(N) + 1, s);
   CUDF_HIP_TRY(hipMemcpyAsync(h_all.data(), ctl_recv.data(), ctl_recv.size(), hipMemcpyDeviceToHost, s));
   CUDF_HIP_TRY(hipStreamSynchronize(s));
   uint64_t with_validity = 0;
@@ -432,23 +653,22 @@ std::unique_ptr<table> shuffle(table_view const& input, std::vector<size_type> c
   // ---- counts: every rank learns what every rank sends to every rank
   for (int p = 0; p < N; ++p) h_send[p] = off[p + 1] - off[p];
   CUDF_HIP_TRY(hipMemcpyAsync(ctl_send.data(), h_send.data(), ctl_send.size(), hipMemcpyHostToDevice, s));
-  CUDF_RCCL_TRY(rccl().AllGather(ctl_send.data(), ctl_recv.data(), static_cast<std::size_t>(N) + 1, ncclInt64, nc, s));
+  link.all_gather(ctl_send.data(), ctl_recv.data(), static_cast<std::size_t>(N) + 1, s);
   CUDF_HIP_TRY(hipMemcpyAsync(h_all.data(), ctl_recv.data(), ctl_recv.size(), hipMemcpyDeviceToHost, s));
   CUDF_HIP_TRY(hipStreamSynchronize(s));
-  std::vector<int64_t> rcnt(N), roff(static_cast<std::size_t>(N) + 1, 0);
-  int64_t biggest = 0;  // the largest (sender, receiver) message in rows: every rank runs the same number of rounds
-  for (int p = 0; p < N; ++p) {
-    rcnt[p]     = h_all[static_cast<std::size_t>(p) * (N + 1) + me];
-    roff[p + 1] = roff[p] + rcnt[p];
-    for (int q = 0; q < N; ++q)
-      if (p != q) biggest = std::max(biggest, h_all[static_cast<std::size_t>(p) * (N + 1) + q]);
-  }
-  int64_t const total = roff[N];
+  std::vector<int64_t> matrix(static_cast<std::size_t>(N) * N);
+  for (int p = 0; p < N; ++p)
+    for (int q = 0; q < N; ++q) matrix[static_cast<std::size_t>(p) * N + q] = h_all[static_cast<std::size_t>(p) * (N + 1) + q];
+  exchange_plan const ep    = plan_exchange(matrix, N, me);
+  auto const& rcnt          = ep.recv_count;
+  auto const& roff          = ep.recv_offset;
+  int64_t const biggest     = ep.biggest;  // the largest (sender, receiver) message in rows: every rank runs the same number of rounds
+  int64_t const total       = roff[N];
   CUDF_EXPECTS(total <= std::numeric_limits<size_type>::max(), "shuffle: a rank would receive more rows than a column holds", std::overflow_error);
 
-  // ---- payload: per column, ncclGroupStart { Send / Recv per peer } ncclGroupEnd in rounds of <= 1 GiB messages; the own
-  // slice is a device copy
-  constexpr int64_t MAX_MESSAGE_BYTES = int64_t{1} << 30;
+  // ---- payload: per column, group_start { send / recv per peer } group_end in rounds of bounded messages (RCCL: ncclGroupStart /
+  // ncclSend / ncclRecv / ncclGroupEnd); the own slice is a device copy
+  int64_t const max_message_bytes = comm.max_message_bytes();
   std::vector<rmm::device_buffer> recv;
   cudf::detail::prof::scope p_{"shuffle_exchange", s};
   for (std::size_t c = 0; c < f.cols.size(); ++c) {
@@ -458,17 +678,17 @@ std::unique_ptr<table> shuffle(table_view const& input, std::vector<size_type> c
     char* dst       = static_cast<char*>(recv.back().data());
     if (h_send[me] > 0)
       CUDF_HIP_TRY(hipMemcpyAsync(dst + roff[me] * w, src + off[me] * w, static_cast<std::size_t>(h_send[me] * w), hipMemcpyDeviceToDevice, s));
-    int64_t const chunk = std::max<int64_t>(1, MAX_MESSAGE_BYTES / w);
+    int64_t const chunk = std::max<int64_t>(1, max_message_bytes / w);
     for (int64_t done = 0; done < biggest; done += chunk) {
-      CUDF_RCCL_TRY(rccl().GroupStart());
+      group_scope group{link};  // (closed on every path out of this scope: a failed send does not leave the group open)
       for (int p = 0; p < N; ++p) {
         if (p == me) continue;
         int64_t const sb = std::min(done, h_send[p]), se = std::min(done + chunk, h_send[p]);
-        if (se > sb) CUDF_RCCL_TRY(rccl().Send(src + (off[p] + sb) * w, static_cast<std::size_t>((se - sb) * w), ncclInt8, p, nc, s));
+        if (se > sb) link.send(src + (off[p] + sb) * w, static_cast<std::size_t>((se - sb) * w), p, s);
         int64_t const rb = std::min(done, rcnt[p]), re = std::min(done + chunk, rcnt[p]);
-        if (re > rb) CUDF_RCCL_TRY(rccl().Recv(dst + (roff[p] + rb) * w, static_cast<std::size_t>((re - rb) * w), ncclInt8, p, nc, s));
+        if (re > rb) link.recv(dst + (roff[p] + rb) * w, static_cast<std::size_t>((re - rb) * w), p, s);
       }
-      CUDF_RCCL_TRY(rccl().GroupEnd());
+      group.end();
     }
   }
   return assemble(input, f, std::move(recv), total, stream, mr);
@@ -479,6 +699,7 @@ std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> shuf
   table_view const& keys, std::span<groupby::aggregation_request const> requests, communicator& comm, null_policy null_handling,
   stream_ref stream, rmm::device_async_resource_ref mr)
 {
+  CUDF_FUNC_RANGE();
   // the rows that travel: the key columns, then each DISTINCT value column once
   std::vector<column_view> cols(keys.begin(), keys.end());
   std::vector<size_type> key_idx(static_cast<std::size_t>(keys.num_columns()));
@@ -510,6 +731,78 @@ std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> shuf
   }
   groupby::groupby gb{table_view{kcols}, null_handling};
   return gb.aggregate(local, stream, mr);
+}
+
+// ------------------------------------------------------------------ shuffle_join
+namespace {
+__global__ void __launch_bounds__(256) k_global_ids(int64_t first, int64_t n, int64_t* out)
+{
+  int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) out[i] = first + i;
+}
+__global__ void __launch_bounds__(256) k_gather_ids(size_type const* idx, int64_t const* ids, int64_t n, int64_t* out)
+{
+  int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) out[i] = ids[idx[i]];
+}
+// One side of a distributed join: (keys, global row id) shuffled by key; returns the table this rank owns (keys first, id last).
+std::unique_ptr<table> shuffle_side(table_view const& keys, communicator& comm, stream_ref stream)
+{
+  hipStream_t const s = stream.value();
+  int const N = comm.size(), me = comm.rank();
+  auto tmp = cudf::get_current_device_resource_ref();
+  // this rank's first global row id = rows of the lower ranks
+  rmm::device_buffer d_mine{sizeof(int64_t), s, tmp}, d_all{sizeof(int64_t) * N, s, tmp};
+  int64_t const mine = keys.num_rows();
+  std::vector<int64_t> h_all(N, 0);
+  CUDF_HIP_TRY(hipMemcpyAsync(d_mine.data(), &mine, sizeof(int64_t), hipMemcpyHostToDevice, s));
+  comm.link().all_gather(d_mine.data(), d_all.data(), 1, s);
+  CUDF_HIP_TRY(hipMemcpyAsync(h_all.data(), d_all.data(), sizeof(int64_t) * N, hipMemcpyDeviceToHost, s));
+  CUDF_HIP_TRY(hipStreamSynchronize(s));
+  int64_t first = 0;
+  for (int p = 0; p < me; ++p) first += h_all[p];
+  rmm::device_buffer ids{sizeof(int64_t) * static_cast<std::size_t>(std::max<int64_t>(mine, 1)), s, tmp};
+  if (mine > 0)
+    hipLaunchKernelGGL(k_global_ids, dim3(static_cast<unsigned>((mine + 255) / 256)), dim3(256), 0, s, first, mine, static_cast<int64_t*>(ids.data()));
+  CUDF_HIP_TRY(hipGetLastError());
+  std::vector<column_view> cols(keys.begin(), keys.end());
+  cols.push_back(column_view{data_type{type_id::INT64}, static_cast<size_type>(mine), ids.data(), nullptr, 0, 0});
+  std::vector<size_type> key_idx(static_cast<std::size_t>(keys.num_columns()));
+  std::iota(key_idx.begin(), key_idx.end(), 0);
+  return shuffle(table_view{cols}, key_idx, comm, stream, tmp);
+}
+}  // namespace
+
+std::pair<std::unique_ptr<column>, std::unique_ptr<column>> shuffle_join(table_view const& left_keys, table_view const& right_keys,
+                                                                         communicator& comm, null_equality compare_nulls, stream_ref stream,
+                                                                         rmm::device_async_resource_ref mr)
+{
+  CUDF_FUNC_RANGE();
+  CUDF_EXPECTS(left_keys.num_columns() >= 1 && left_keys.num_columns() == right_keys.num_columns(),
+               "shuffle_join: the two sides need the same number (at least one) of key columns", std::invalid_argument);
+  hipStream_t const s = stream.value();
+  auto const L = shuffle_side(left_keys, comm, stream);
+  auto const R = shuffle_side(right_keys, comm, stream);
+  int const nk = left_keys.num_columns();
+  std::vector<column_view> lk, rk;
+  for (int c = 0; c < nk; ++c) {
+    lk.push_back(L->view().column(c));
+    rk.push_back(R->view().column(c));
+  }
+  auto [li, ri] = cudf::inner_join(table_view{lk}, table_view{rk}, compare_nulls, stream, cudf::get_current_device_resource_ref());
+  auto const m  = static_cast<int64_t>(li->size());
+  auto out_col  = [&](rmm::device_uvector<size_type> const& idx, column_view const& ids) {
+    rmm::device_buffer buf{sizeof(int64_t) * static_cast<std::size_t>(std::max<int64_t>(m, 1)), s, mr};
+    if (m > 0)
+      hipLaunchKernelGGL(k_gather_ids, dim3(static_cast<unsigned>((m + 255) / 256)), dim3(256), 0, s, idx.data(), ids.data<int64_t>(), m,
+                         static_cast<int64_t*>(buf.data()));
+    CUDF_HIP_TRY(hipGetLastError());
+    return std::make_unique<column>(data_type{type_id::INT64}, static_cast<size_type>(m), std::move(buf), rmm::device_buffer{}, 0);
+  };
+  auto lo = out_col(*li, L->view().column(nk));
+  auto ro = out_col(*ri, R->view().column(nk));
+  CUDF_HIP_TRY(hipStreamSynchronize(s));  // (the shuffled sides and the index vectors go back to the pool when this returns)
+  return {std::move(lo), std::move(ro)};
 }
 
 }  // namespace distributed

@@ -604,11 +604,8 @@ template <int INPUT, int KUT, int PAYT, int NACCT, bool SIMPLE, bool EXACT, uint
 static void launch_aggregate_n(agg_args const& a, agg_args* d_args, hipStream_t stream)
 {
   auto const lds = aggregate_lds_bytes(a.plan, a.geom);
-  static bool attr_set = false;
-  if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT, SIG>));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;  // (the API is re-entrant across objects: two threads may launch this kernel first)
+  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT, SIG>)); });
   hipLaunchKernelGGL(k_store_args<agg_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"aggregate", stream};
   hipLaunchKernelGGL((k_aggregate<INPUT, KUT, PAYT, NACCT, SIMPLE, EXACT, SIG>), dim3(a.nitems), dim3(a.geom.block), lds,

@@ -187,11 +187,8 @@ __global__ void __launch_bounds__(1024) k_aggregate_dense_columns(dense_agg_args
 template <uint64_t SIG, int NACCT, int SRC>
 void launch_dcol_t(dense_agg_args const& a, dense_agg_args const* d_args, hipStream_t stream)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate_dense_columns<SIG, NACCT, SRC>));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;  // (the API is re-entrant across objects: two threads may launch this kernel first)
+  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_aggregate_dense_columns<SIG, NACCT, SRC>)); });
   cudf::detail::prof::scope prof_{"aggregate", stream};
   hipLaunchKernelGGL((k_aggregate_dense_columns<SIG, NACCT, SRC>), dim3(a.nsplit), dim3(1024), a.image_bytes, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());

@@ -509,11 +509,8 @@ void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t str
 template <uint64_t SIG, int NACCT, bool SOA>
 static void launch_dense_t(dense_agg_args const& a, dense_agg_args const* d_args, bool first_chunk, bool last_chunk, hipStream_t stream)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_aggregate_dense<SIG, NACCT, SOA>));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;  // (the API is re-entrant across objects: two threads may launch this kernel first)
+  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_aggregate_dense<SIG, NACCT, SOA>)); });
   cudf::detail::prof::scope prof_{"aggregate", stream};
   hipLaunchKernelGGL((k_aggregate_dense<SIG, NACCT, SOA>), dim3(a.nitems * std::max(a.nsplit, 1)), dim3(a.block), a.image_bytes, stream, d_args,
                      first_chunk ? 1 : 0, last_chunk ? 1 : 0);

@@ -392,11 +392,8 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
 template <int SRC, int RPT, int D, typename TAG, bool HOT = false>
 void launch_ring_tag(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D, TAG, HOT>));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;  // (the API is re-entrant across objects: two threads may launch this kernel first)
+  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D, TAG, HOT>)); });
   // rings (values + tags), 2 KiB for the ring counters of up to 256 partitions, then the heavy-hitter table
   std::size_t const lds = static_cast<std::size_t>(DENSE_RING_SLOTS) * 16 + 2048 + (HOT ? static_cast<std::size_t>(HOT_SLOTS) * (8 + 8 + 4) : 0);
   int const items       = a.from_columns ? a.slices : a.nseg * a.slices;

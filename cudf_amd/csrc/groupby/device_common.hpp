@@ -7,6 +7,8 @@
 
 #include <cudf/utilities/error.hpp>
 
+#include <mutex>
+
 namespace cudf::groupby::detail {
 
 using cudf::detail::col_is_valid;

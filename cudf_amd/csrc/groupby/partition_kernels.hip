@@ -616,11 +616,8 @@ static void launch_scatter_t(part_args const& a, part_args const* d_args, hipStr
   g.tile_rows  = g.block * RPT;
   auto const lds = partition_lds_bytes(a.plan, g);
   CUDF_EXPECTS(lds <= 160 * 1024, "partition kernel: LDS budget exceeded (fan-out too large for this record width)");
-  static bool attr_set = false;
-  if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter<UT, RPT, SIMPLE, EXACT>));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;  // (the API is re-entrant across objects: two threads may launch this kernel first)
+  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter<UT, RPT, SIMPLE, EXACT>)); });
   int const items = g.nseg * g.slices;
   cudf::detail::prof::scope prof_{"partition_scatter", stream};
   hipLaunchKernelGGL((k_partition_scatter<UT, RPT, SIMPLE, EXACT>), dim3(items), dim3(g.block), lds, stream, d_args);
@@ -650,11 +647,8 @@ static void launch_scatter_wc_src(part_args const& a, part_args const* d_args, h
   auto const lds = cudf::detail::wc_scatter_lds_bytes(g.tile_rows, g.P, G, UT) + (HOT ? partition_hot_lds_bytes() : 0);
   CUDF_EXPECTS(lds + 1200 <= 160 * 1024, "write-combining partition kernel: LDS budget exceeded");
   CUDF_EXPECTS(!HOT || g.block == 1024, "heavy hitters: 1024-thread scatter workgroups");
-  static bool attr_set = false;
-  if (!attr_set) {
-    allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SRC, HOT, DENSE>));
-    attr_set = true;
-  }
+  static std::once_flag attr_once;  // (the API is re-entrant across objects: two threads may launch this kernel first)
+  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_partition_scatter_wc<UT, RPT, G, SRC, HOT, DENSE>)); });
   cudf::detail::prof::scope prof_{a.from_columns ? "partition_scatter" : "partition_scatter_level2", stream};
   hipLaunchKernelGGL((k_partition_scatter_wc<UT, RPT, G, SRC, HOT, DENSE>), dim3(g.nseg * g.slices), dim3(g.block), lds, stream, d_args, chunk);
   CUDF_HIP_TRY(hipGetLastError());

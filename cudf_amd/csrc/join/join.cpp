@@ -5,6 +5,7 @@
 // retrieve_impl.cuh:169-222 (probe entry), size_impl.cuh:26-61 (size), join_utils.cu:45-221 (trivial left join,
 // full-join complement), join_common_utils.hpp:25-32 (load-factor check).
 #include "engine.hpp"
+#include "../common/profiler.hpp"
 
 #include <cudf/join/hash_join.hpp>
 #include <cudf/join/join.hpp>
@@ -460,67 +461,81 @@ hash_join::hash_join(table_view const& right, null_equality compare_nulls, strea
 
 hash_join::hash_join(table_view const& right, nullable_join has_nulls, null_equality compare_nulls, double load_factor,
                      stream_ref stream, rmm::device_async_resource_ref mr)
-  : _impl{std::make_unique<detail::hash_join_impl const>(right, has_nulls == nullable_join::YES, compare_nulls, load_factor,
-                                                         stream, mr)}
+  : _impl{[&] {
+      CUDF_FUNC_RANGE();  // (reference hash_join.cu:62: the build is the constructor's work)
+      return std::make_unique<detail::hash_join_impl const>(right, has_nulls == nullable_join::YES, compare_nulls, load_factor, stream, mr);
+    }()}
 {
 }
 
 join_index_pair hash_join::inner_join(table_view const& left, std::optional<std::size_t> output_size, stream_ref stream,
                                       rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->probe(left, join_kind::INNER_JOIN, output_size, stream, mr);
 }
 join_index_pair hash_join::left_join(table_view const& left, std::optional<std::size_t> output_size, stream_ref stream,
                                      rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->probe(left, join_kind::LEFT_JOIN, output_size, stream, mr);
 }
 join_index_pair hash_join::full_join(table_view const& left, std::optional<std::size_t> output_size, stream_ref stream,
                                      rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->probe(left, join_kind::FULL_JOIN, output_size, stream, mr);
 }
 std::size_t hash_join::inner_join_size(table_view const& left, stream_ref stream) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->join_size(left, join_kind::INNER_JOIN, stream);
 }
 std::size_t hash_join::left_join_size(table_view const& left, stream_ref stream) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->join_size(left, join_kind::LEFT_JOIN, stream);
 }
 std::size_t hash_join::full_join_size(table_view const& left, stream_ref stream, rmm::device_async_resource_ref) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->join_size(left, join_kind::FULL_JOIN, stream);
 }
 
 join_match_context hash_join::inner_join_match_context(table_view const& left, stream_ref stream,
                                                        rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return join_match_context{left, _impl->match_counts(left, join_kind::INNER_JOIN, stream, mr)};
 }
 join_match_context hash_join::left_join_match_context(table_view const& left, stream_ref stream,
                                                       rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return join_match_context{left, _impl->match_counts(left, join_kind::LEFT_JOIN, stream, mr)};
 }
 join_match_context hash_join::full_join_match_context(table_view const& left, stream_ref stream,
                                                       rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return join_match_context{left, _impl->match_counts(left, join_kind::FULL_JOIN, stream, mr)};
 }
 join_index_pair hash_join::partitioned_inner_join(join_partition_context const& context, stream_ref stream,
                                                   rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->partitioned(context, join_kind::INNER_JOIN, stream, mr);
 }
 join_index_pair hash_join::partitioned_left_join(join_partition_context const& context, stream_ref stream,
                                                  rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->partitioned(context, join_kind::LEFT_JOIN, stream, mr);
 }
 join_index_pair hash_join::partitioned_full_join(join_partition_context const& context, stream_ref stream,
                                                  rmm::device_async_resource_ref mr) const
 {
+  CUDF_FUNC_RANGE();
   return _impl->partitioned(context, join_kind::FULL_JOIN, stream, mr);
 }
 // Concatenates the partial probe-side results and appends (JoinNoMatch, r) for every right row r that no partial
@@ -530,6 +545,7 @@ join_index_pair hash_join::finalize_partitioned_full_join(
   cudf::host_span<cudf::device_span<size_type const> const> right_partials, size_type left_table_num_rows,
   size_type right_table_num_rows, stream_ref stream, rmm::device_async_resource_ref mr)
 {
+  CUDF_FUNC_RANGE();
   CUDF_EXPECTS(left_partials.size() == right_partials.size(), "left and right partial results differ in number",
                std::invalid_argument);
   CUDF_EXPECTS(left_table_num_rows >= 0 && right_table_num_rows >= 0, "negative table size", std::invalid_argument);
@@ -584,6 +600,7 @@ join_index_pair hash_join::finalize_partitioned_full_join(
 join_index_pair inner_join(table_view const& left, table_view const& right, null_equality compare_nulls, stream_ref stream,
                            rmm::device_async_resource_ref mr)
 {
+  CUDF_FUNC_RANGE();
   auto const has_nulls = (cudf::has_nulls(left) || cudf::has_nulls(right)) ? nullable_join::YES : nullable_join::NO;
   // build on the smaller table; ties build on right (reference join.cu:50-57)
   if (right.num_rows() > left.num_rows()) {
@@ -598,6 +615,7 @@ join_index_pair inner_join(table_view const& left, table_view const& right, null
 join_index_pair left_join(table_view const& left, table_view const& right, null_equality compare_nulls, stream_ref stream,
                           rmm::device_async_resource_ref mr)
 {
+  CUDF_FUNC_RANGE();
   auto const has_nulls = (cudf::has_nulls(left) || cudf::has_nulls(right)) ? nullable_join::YES : nullable_join::NO;
   hash_join hj{right, has_nulls, compare_nulls, 0.5, stream};
   return hj.left_join(left, std::nullopt, stream, mr);
@@ -606,6 +624,7 @@ join_index_pair left_join(table_view const& left, table_view const& right, null_
 join_index_pair full_join(table_view const& left, table_view const& right, null_equality compare_nulls, stream_ref stream,
                           rmm::device_async_resource_ref mr)
 {
+  CUDF_FUNC_RANGE();
   auto const has_nulls = (cudf::has_nulls(left) || cudf::has_nulls(right)) ? nullable_join::YES : nullable_join::NO;
   hash_join hj{right, has_nulls, compare_nulls, 0.5, stream};
   return hj.full_join(left, std::nullopt, stream, mr);

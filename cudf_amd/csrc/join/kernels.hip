@@ -1,5 +1,6 @@
 // SPDX-License-Identifier: Apache-2.0
 // gfx950 kernels of the hash-join engine (see engine.hpp).
+#include <mutex>
 #include "engine.hpp"
 #include "../common/wc_scatter.hpp"
 #include "../common/profiler.hpp"
@@ -763,12 +764,11 @@ void launch_probe_partition(join_args const& a, join_args* d_args, hipStream_t s
   int const G         = P > 512 ? 4 : 8;
   auto const lds      = wc_scatter_lds_bytes(1024 * RPT, P, G);
   CUDF_EXPECTS(lds <= 160 * 1024 - 64, "join probe partition: LDS budget exceeded");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
     CUDF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(&k_probe_partition<RPT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     CUDF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(&k_probe_partition<RPT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    attr_set = true;
-  }
+  });
   if (G == 4) hipLaunchKernelGGL((k_probe_partition<RPT, 4>), dim3(a.pslices), dim3(1024), lds, stream, d_args);
   else hipLaunchKernelGGL((k_probe_partition<RPT, 8>), dim3(a.pslices), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());

@@ -16,6 +16,7 @@
 #include <cudf/utilities/error.hpp>
 
 #include <algorithm>
+#include <mutex>
 #include <numeric>
 
 namespace cudf {
@@ -383,14 +384,13 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> hash_partition(table_v
   {
     size_t const lds = PART_TILE * 8 + P * (8 + 8 + 4 + 4) + PART_TILE * 2;
     // beyond 1024 partitions the tile needs more than the default 64 KiB of dynamic LDS (139 KiB at 4096): opt in once
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
       hipFuncAttributes attr{};
       CUDF_HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<void const*>(&k_hp_scatter)));
       CUDF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(&k_hp_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
-      attr_set = true;
-    }
+    });
     prof::scope p_{"hash_partition_scatter", s};
     hipLaunchKernelGGL(k_hp_scatter, dim3(a.slices), dim3(PART_BLOCK), lds, s, da);
     CUDF_HIP_TRY(hipGetLastError());

@@ -1,6 +1,9 @@
 // SPDX-License-Identifier: Apache-2.0
 #include "../common/profiler.hpp"
 
+#include <dlfcn.h>
+
+#include <atomic>
 #include <map>
 #include <mutex>
 
@@ -67,5 +70,50 @@ scope::~scope()
   if (_slot < 0) return;
   std::lock_guard<std::mutex> g{g_mu};
   if (_slot < static_cast<int>(g_pending.size())) (void)hipEventRecord(g_pending[_slot].stop, _stream);
+}
+
+namespace {
+using roctx_push_t = int (*)(char const*);
+using roctx_pop_t  = int (*)();
+std::atomic<int> g_roctx_state{0};  // 0: not resolved yet, 1: available, 2: absent
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop   = nullptr;
+std::once_flag g_roctx_once;
+
+void resolve_roctx()
+{
+  std::call_once(g_roctx_once, [] {
+    for (char const* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void* h = dlopen(name, RTLD_LAZY | RTLD_LOCAL);
+      if (h == nullptr) continue;
+      auto push = reinterpret_cast<roctx_push_t>(dlsym(h, "roctxRangePushA"));
+      auto pop  = reinterpret_cast<roctx_pop_t>(dlsym(h, "roctxRangePop"));
+      if (push != nullptr && pop != nullptr) {
+        g_roctx_push = push;
+        g_roctx_pop  = pop;
+        g_roctx_state.store(1, std::memory_order_release);
+        return;
+      }
+    }
+    g_roctx_state.store(2, std::memory_order_release);
+  });
+}
+}  // namespace
+
+func_range::func_range(char const* name)
+{
+  int st = g_roctx_state.load(std::memory_order_acquire);
+  if (st == 0) {
+    resolve_roctx();
+    st = g_roctx_state.load(std::memory_order_acquire);
+  }
+  if (st == 1) {
+    (void)g_roctx_push(name);
+    _pushed = true;
+  }
+}
+func_range::~func_range()
+{
+  if (_pushed) (void)g_roctx_pop();
 }
 }  // namespace cudf::detail::prof

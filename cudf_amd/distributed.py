@@ -34,22 +34,60 @@ class Communicator:
         if world_size is None:
             world_size = dist.get_world_size(group) if dist.is_initialized() else 1
             rank = dist.get_rank(group) if dist.is_initialized() else 0
-        ident = (C.c_uint8 * 128)()
-        if rank == 0:
-            _lib.check(lib.cudf_amd_comm_unique_id(ident))
-        if world_size > 1:
-            box = [bytes(ident)]
-            dist.broadcast_object_list(box, src=0, group=group)
-            ident = (C.c_uint8 * 128)(*box[0])
         self._handle = C.c_void_p()
+        ident = (C.c_uint8 * 128)()
+        # EVERY rank takes part in the id broadcast, whatever happened on rank 0: rank 0 broadcasts the id or an error marker,
+        # and all ranks raise together after the broadcast (a rank 0 that raised before it left the others waiting in a
+        # collective the rest of the job had already moved past).
+        error = None
+        if rank == 0:
+            try:
+                _lib.check(lib.cudf_amd_comm_unique_id(ident))
+            except Exception as e:  # noqa: BLE001 - travels to every rank below
+                error = repr(e)
+        if world_size > 1:
+            box = [("error", error) if error is not None else ("id", bytes(ident))]
+            dist.broadcast_object_list(box, src=0, group=group)
+            kind, payload = box[0]
+            if kind == "error":
+                error = payload
+            else:
+                ident = (C.c_uint8 * 128)(*payload)
+        if error is not None:
+            raise _lib.CudfAmdError(f"communicator: rank 0 could not create the RCCL unique id: {error}")
         _lib.check(lib.cudf_amd_comm_create(ident, world_size, rank, C.byref(self._handle)))
         self.world_size, self.rank = world_size, rank
 
+    @classmethod
+    def loopback(cls, world_size: int):
+        """The world_size ends of an in-process LOOPBACK world (include/cudf/distributed.hpp `transport`): virtual ranks on the
+        current device, sends and receives matched into device copies. Every end must be driven by its own host thread - the
+        collectives rendezvous (ctypes releases the GIL for the duration of a call)."""
+        lib = _lib.load()
+        handles = (C.c_void_p * world_size)()
+        _lib.check(lib.cudf_amd_comm_create_loopback(world_size, handles))
+        ends = []
+        for r in range(world_size):
+            c = cls.__new__(cls)
+            c._handle = C.c_void_p(handles[r])
+            c.world_size, c.rank = world_size, r
+            ends.append(c)
+        return ends
+
+    def set_max_message_bytes(self, nbytes: int):
+        """Largest single message of the payload exchange (default 1 GiB); every rank must set the same value."""
+        _lib.check(_lib.load().cudf_amd_comm_set_max_message_bytes(self._handle, int(nbytes)))
+
+    def close(self):
+        """Destroys the RCCL communicator (call before torch.distributed.destroy_process_group / interpreter teardown:
+        ncclCommDestroy after the HIP runtime has shut down can hang)."""
+        if self._handle:
+            _lib.load().cudf_amd_comm_destroy(self._handle)
+            self._handle = C.c_void_p()
+
     def __del__(self):
         try:
-            if self._handle:
-                _lib.load().cudf_amd_comm_destroy(self._handle)
-                self._handle = None
+            self.close()
         except Exception:
             pass
 
@@ -62,7 +100,7 @@ def range_partition(table: Table, key_columns, num_destinations: int, stream=Non
     out = C.c_void_p()
     _lib.check(_lib.load().cudf_amd_range_partition(table._views(), table.num_columns(), cols, len(key_columns), num_destinations,
                                                     _stream_ptr(stream), C.byref(out), offs))
-    return Table._from_handle(out), list(offs)
+    return Table._from_handle(out, stream), list(offs)
 
 
 def shuffle(comm: Communicator, table: Table, key_columns, stream=None) -> Table:
@@ -71,7 +109,7 @@ def shuffle(comm: Communicator, table: Table, key_columns, stream=None) -> Table
     out = C.c_void_p()
     _lib.check(_lib.load().cudf_amd_shuffle(comm._handle, table._views(), table.num_columns(), cols, len(key_columns),
                                             _stream_ptr(stream), C.byref(out)))
-    return Table._from_handle(out)
+    return Table._from_handle(out, stream)
 
 
 def shuffle_groupby(comm: Communicator, keys: Table, requests, null_handling=0, stream=None):
@@ -88,12 +126,31 @@ def shuffle_groupby(comm: Communicator, keys: Table, requests, null_handling=0, 
     out_keys, out_res = C.c_void_p(), C.c_void_p()
     _lib.check(_lib.load().cudf_amd_shuffle_groupby(comm._handle, keys._views(), keys.num_columns(), int(null_handling), rarr,
                                                     len(reqs), _stream_ptr(stream), C.byref(out_keys), C.byref(out_res)))
-    flat = Table._from_handle(out_res).columns()
+    flat = Table._from_handle(out_res, stream).columns()
     results, p = [], 0
     for r in requests:
         results.append(Table(flat[p:p + len(r._aggregations)]))
         p += len(r._aggregations)
-    return Table._from_handle(out_keys), results
+    return Table._from_handle(out_keys, stream), results
+
+
+def shuffle_join(comm: Communicator, left_keys: Table, right_keys: Table, nulls_equal=True, stream=None):
+    """cudf::distributed::shuffle_join: inner join of two row-sharded key tables. Collective. -> (global left row ids, global right
+    row ids) as INT64 Columns: the pairs whose key this rank owns."""
+    out = C.c_void_p()
+    _lib.check(_lib.load().cudf_amd_shuffle_join(comm._handle, left_keys._views(), left_keys.num_columns(), right_keys._views(),
+                                                 right_keys.num_columns(), 1 if nulls_equal else 0, _stream_ptr(stream), C.byref(out)))
+    cols = Table._from_handle(out, stream).columns()
+    return cols[0], cols[1]
+
+
+def plan_exchange(counts, world_size: int, rank: int):
+    """cudf::distributed::plan_exchange (host arithmetic only): counts[p][q] = rows rank p sends to rank q ->
+    (rows received from each peer, world_size + 1 receive offsets, largest message between two different ranks in rows)."""
+    flat = (C.c_int64 * (world_size * world_size))(*[int(counts[p][q]) for p in range(world_size) for q in range(world_size)])
+    rc, ro, big = (C.c_int64 * world_size)(), (C.c_int64 * (world_size + 1))(), C.c_int64()
+    _lib.check(_lib.load().cudf_amd_plan_exchange(flat, world_size, rank, rc, ro, C.byref(big)))
+    return list(rc), list(ro), big.value
 
 
 class GpuBackend:
@@ -189,15 +246,29 @@ def exchange(columns, offsets, group=None, max_message_bytes=None):
     return out
 
 
-_COMMS = {}
+import weakref
+
+_COMMS = weakref.WeakKeyDictionary()  # process group OBJECT -> Communicator (an id() can be reused once a group is collected)
+_DEFAULT_COMM = []                    # the default group (group=None)
 
 
 def _native_comm(group=None):
     """One library communicator per torch process group (created on first use: a collective)."""
-    key = id(group)
-    if key not in _COMMS:
-        _COMMS[key] = Communicator(group)
-    return _COMMS[key]
+    if group is None:
+        if not _DEFAULT_COMM:
+            _DEFAULT_COMM.append(Communicator(None))
+        return _DEFAULT_COMM[0]
+    if group not in _COMMS:
+        _COMMS[group] = Communicator(group)
+    return _COMMS[group]
+
+
+def close_communicators():
+    """Destroys every cached library communicator (before destroy_process_group())."""
+    for c in list(_COMMS.values()) + list(_DEFAULT_COMM):
+        c.close()
+    _COMMS.clear()
+    _DEFAULT_COMM.clear()
 
 
 def distributed_groupby_sum_count(keys, vals, stream=None, mode="shuffle", backend=None, group=None,
@@ -233,7 +304,16 @@ def distributed_inner_join(left_keys, right_keys, stream=None, backend=None, gro
     by key with the same hash, every partition meets on its owner rank (one all-to-all per side, the GLOBAL row id
     = rank offset + local index travels as a payload column), and the owner joins locally. Every matching
     (left row, right row) pair of the whole tables is returned exactly once, by the rank that owns the key:
-    -> (global left row ids, global right row ids) as int64 tensors."""
+    -> (global left row ids, global right row ids) as int64 tensors.
+    Default: cudf::distributed::shuffle_join inside the library (hash-range ownership, RCCL). With a `backend` (the CPU tests'
+    host backend) or a message limit, the same data flow through torch.distributed."""
+    if backend is None and max_message_bytes is None:
+        # inside the library: cudf::distributed::shuffle_join over the library's own communicator (RCCL Send / Recv)
+        import cudf_amd
+        comm = _native_comm(group)
+        li, ri = shuffle_join(comm, cudf_amd.Table([cudf_amd.Column.from_torch(left_keys)]),
+                              cudf_amd.Table([cudf_amd.Column.from_torch(right_keys)]), stream=stream)
+        return li.to_torch(), ri.to_torch()
     backend = backend or GpuBackend(stream)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)

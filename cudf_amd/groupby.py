@@ -46,8 +46,8 @@ class GroupBy:
                                                   len(reqs), _stream_ptr(stream), C.byref(out_keys),
                                                   C.byref(out_res), C.byref(path)))
         self.last_path = HashPath(path.value)
-        keys = Table._from_handle(out_keys)
-        flat = Table._from_handle(out_res).columns()
+        keys = Table._from_handle(out_keys, stream)
+        flat = Table._from_handle(out_res, stream).columns()
         results, p = [], 0
         for r in requests:
             results.append(Table(flat[p:p + len(r._aggregations)]))

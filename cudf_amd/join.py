@@ -15,7 +15,7 @@ def _join(left_keys: Table, right_keys: Table, nulls_equal, kind, stream):
     _lib.check(_lib.load().cudf_amd_join(left_keys._views(), left_keys.num_columns(), right_keys._views(),
                                          right_keys.num_columns(), 1 if nulls_equal == NullEquality.EQUAL else 0,
                                          _KIND[kind], _stream_ptr(stream), C.byref(out)))
-    cols = Table._from_handle(out).columns()
+    cols = Table._from_handle(out, stream).columns()
     return cols[0], cols[1]
 
 
@@ -73,7 +73,7 @@ class HashJoin:
         _lib.check(_lib.load().cudf_amd_hash_join_probe(self._h, left_keys._views(), left_keys.num_columns(), _KIND[kind],
                                                         -1 if output_size is None else int(output_size),
                                                         _stream_ptr(stream), C.byref(out)))
-        cols = Table._from_handle(out).columns()
+        cols = Table._from_handle(out, stream).columns()
         return cols[0], cols[1]
 
     def _size(self, left_keys, kind, stream):
@@ -86,7 +86,7 @@ class HashJoin:
         out = C.c_void_p()
         _lib.check(_lib.load().cudf_amd_hash_join_match_counts(self._h, left_keys._views(), left_keys.num_columns(),
                                                                _KIND[kind], _stream_ptr(stream), C.byref(out)))
-        return JoinMatchContext(left_keys, Table._from_handle(out).columns()[0])
+        return JoinMatchContext(left_keys, Table._from_handle(out, stream).columns()[0])
 
     def inner_join_match_context(self, left_keys, stream=None):
         return self._match_context(left_keys, "inner", stream)
@@ -107,7 +107,7 @@ class HashJoin:
         _lib.check(_lib.load().cudf_amd_hash_join_probe_range(
             self._h, left._views(), left.num_columns(), None if counts is None else C.c_void_p(counts.data_ptr()),
             _KIND[kind], context.left_start_idx, context.left_end_idx, _stream_ptr(stream), C.byref(out)))
-        cols = Table._from_handle(out).columns()
+        cols = Table._from_handle(out, stream).columns()
         return cols[0], cols[1]
 
     def partitioned_inner_join(self, context, stream=None):
@@ -133,7 +133,7 @@ class HashJoin:
         out = C.c_void_p()
         _lib.check(_lib.load().cudf_amd_hash_join_finalize_full(lp, rp, sz, n, int(left_table_num_rows),
                                                                 int(right_table_num_rows), _stream_ptr(stream), C.byref(out)))
-        cols = Table._from_handle(out).columns()
+        cols = Table._from_handle(out, stream).columns()
         return cols[0], cols[1]
 
     def inner_join(self, left_keys, output_size=None, stream=None):

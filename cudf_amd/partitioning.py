@@ -14,14 +14,14 @@ def hash_partition(input: Table, columns_to_hash, num_partitions: int, seed: int
     out = C.c_void_p()
     _lib.check(_lib.load().cudf_amd_hash_partition(input._views(), input.num_columns(), cols, len(columns_to_hash),
                                                    num_partitions, seed, _stream_ptr(stream), C.byref(out), offs))
-    return Table._from_handle(out), list(offs)[:max(num_partitions, 0) + 1]
+    return Table._from_handle(out, stream), list(offs)[:max(num_partitions, 0) + 1]
 
 
 def murmurhash3_x86_32(input: Table, seed: int = 0, stream=None) -> Column:
     out = C.c_void_p()
     _lib.check(_lib.load().cudf_amd_murmurhash3_x86_32(input._views(), input.num_columns(), seed, _stream_ptr(stream),
                                                        C.byref(out)))
-    return Table._from_handle(out).columns()[0]
+    return Table._from_handle(out, stream).columns()[0]
 
 
 def gather(source_table: Table, gather_map: Column, bounds_policy: OutOfBoundsPolicy = OutOfBoundsPolicy.DONT_CHECK,
@@ -31,4 +31,4 @@ def gather(source_table: Table, gather_map: Column, bounds_policy: OutOfBoundsPo
     _lib.check(_lib.load().cudf_amd_gather(source_table._views(), source_table.num_columns(), C.byref(gm),
                                            1 if bounds_policy == OutOfBoundsPolicy.NULLIFY else 0, _stream_ptr(stream),
                                            C.byref(out)))
-    return Table._from_handle(out)
+    return Table._from_handle(out, stream)

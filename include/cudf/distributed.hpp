@@ -6,11 +6,17 @@
 // exchange is RCCL point-to-point inside one group per round: counts by ncclAllGather, payload by
 // ncclGroupStart { ncclSend / ncclRecv per peer } ncclGroupEnd, one buffer per column, messages of at most 1 GiB.
 // RCCL is resolved at run time (dlopen): the library loads and every other entry point works without it.
+// The five calls the exchange makes (all_gather, group_start, send, recv, group_end) sit behind `transport`; besides RCCL there
+// is a LOOPBACK transport - V virtual ranks inside one process on one device, each driven by its own host thread, sends and
+// receives matched into device copies at group_end - so that the exchange logic (counts, offsets, rounds of bounded messages,
+// the per-peer Send / Recv loop) runs with real peers on a one-GPU box.
 #pragma once
 #include <cudf/groupby.hpp>
 #include <cudf/table/table.hpp>
 #include <cudf/table/table_view.hpp>
 #include <cudf/utilities/default_stream.hpp>
+
+#include <hip/hip_runtime_api.h>
 
 #include <array>
 #include <cstdint>
@@ -24,22 +30,44 @@ namespace distributed {
 constexpr std::size_t UNIQUE_ID_BYTES = 128;  // ncclUniqueId
 using unique_id = std::array<char, UNIQUE_ID_BYTES>;
 
-// One rank's end of an RCCL communicator. Rank 0 calls make_unique_id() and hands the bytes to the other ranks through
+// What the exchange needs from a communication layer. Every call is stream-ordered on `stream` like its RCCL namesake; sends and
+// receives are only issued between group_start() and group_end() and complete (in stream order) after group_end().
+class transport {
+ public:
+  virtual ~transport()                                                                                  = default;
+  virtual void all_gather(void const* send, void* recv, std::size_t count_int64, hipStream_t stream)   = 0;
+  virtual void group_start()                                                                            = 0;
+  virtual void send(void const* buf, std::size_t bytes, int peer, hipStream_t stream)                   = 0;
+  virtual void recv(void* buf, std::size_t bytes, int peer, hipStream_t stream)                         = 0;
+  virtual void group_end()                                                                              = 0;
+  [[nodiscard]] virtual void* native_handle() const noexcept { return nullptr; }  // ncclComm_t of the RCCL transport
+};
+
+// One rank's end of a communicator. RCCL: rank 0 calls make_unique_id() and hands the bytes to the other ranks through
 // whatever control plane launched them (torch.distributed, MPI, a file); then every rank constructs its communicator.
+// Loopback: make_loopback(V) returns the V ends of an in-process world; every end must be driven by its own host thread.
 class communicator {
  public:
   static unique_id make_unique_id();
   communicator(unique_id const& id, int world_size, int rank);
+  static std::vector<std::unique_ptr<communicator>> make_loopback(int world_size);
   ~communicator();
   communicator(communicator const&)            = delete;
   communicator& operator=(communicator const&) = delete;
   [[nodiscard]] int rank() const noexcept { return _rank; }
   [[nodiscard]] int size() const noexcept { return _world; }
-  [[nodiscard]] void* handle() const noexcept { return _comm; }  // ncclComm_t
+  [[nodiscard]] void* handle() const noexcept { return _transport->native_handle(); }  // ncclComm_t (nullptr: loopback)
+  [[nodiscard]] transport& link() noexcept { return *_transport; }
+  // Largest single message of the payload exchange (default 1 GiB: RCCL 2.26 truncated larger ones silently); bigger slices
+  // travel in several rounds. Every rank of a communicator must use the same value.
+  [[nodiscard]] std::int64_t max_message_bytes() const noexcept { return _max_message_bytes; }
+  void set_max_message_bytes(std::int64_t bytes);
 
  private:
-  void* _comm{nullptr};
+  communicator(std::unique_ptr<transport> t, int world_size, int rank);
+  std::unique_ptr<transport> _transport;
   int _world{1}, _rank{0};
+  std::int64_t _max_message_bytes{std::int64_t{1} << 30};
 };
 
 // Destination rank of every row: (murmurhash3_x86_32 row hash of the key columns, seed 0) * world >> 32.
@@ -61,6 +89,25 @@ std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> shuf
   table_view const& keys, std::span<groupby::aggregation_request const> requests, communicator& comm,
   null_policy null_handling = null_policy::EXCLUDE, stream_ref stream = get_default_stream(),
   rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+
+// Inner join of two tables sharded by rows over the ranks (data flow of the reference's
+// cpp/libcudf_streaming/src/partition_utils.cpp:72-185 with a hash join as the local step): both sides are shuffled by key with the
+// same hash-range ownership, the GLOBAL row id (this rank's first row id + local index; first row id = rows of the lower ranks)
+// travels as a payload column, and the owner rank runs the local cudf::inner_join. Every matching (left row, right row) pair
+// of the whole tables is returned exactly once, by the rank that owns its key: two INT64 columns of global row ids.
+std::pair<std::unique_ptr<column>, std::unique_ptr<column>> shuffle_join(
+  table_view const& left_keys, table_view const& right_keys, communicator& comm, null_equality compare_nulls = null_equality::EQUAL,
+  stream_ref stream = get_default_stream(), rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+
+// Host-side bookkeeping of the payload exchange, exposed for tests (no device work): from the all-gathered count matrix
+// counts[p * world + q] = rows rank p sends to rank q, what rank `me` receives from each peer, where those slices start in its
+// receive buffers (world + 1 offsets), and the largest message between two DIFFERENT ranks in rows (every rank runs
+// ceil(biggest / rows per message) rounds).
+struct exchange_plan {
+  std::vector<std::int64_t> recv_count, recv_offset;
+  std::int64_t biggest{0};
+};
+exchange_plan plan_exchange(std::vector<std::int64_t> const& counts, int world, int me);
 
 }  // namespace distributed
 }  // namespace cudf

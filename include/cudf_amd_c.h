@@ -64,6 +64,11 @@ typedef struct cudf_amd_hash_join_s* cudf_amd_hash_join_t;
 
 const char* cudf_amd_last_error(void);
 const char* cudf_amd_version(void);
+/* ABI number of this header: bumped whenever a struct layout or the meaning of an argument changes, so that a consumer built
+ * against an older header can refuse to run. 2: cudf_amd_aggregation_request gained `params`; cudf_amd_hash_partition writes
+ * num_partitions + 1 offsets (the reference's current contract). 3: loopback communicators, message limit, shuffle_join. */
+#define CUDF_AMD_ABI_VERSION 3
+int32_t cudf_amd_abi_version(void);
 
 /* ---- device memory / stream plumbing for bindings without a device allocator of their own */
 cudf_amd_status cudf_amd_malloc(void** ptr, size_t bytes, void* stream);
@@ -177,6 +182,23 @@ typedef struct cudf_amd_comm_s* cudf_amd_comm_t;
 cudf_amd_status cudf_amd_comm_unique_id(uint8_t* out_id_128_bytes);
 cudf_amd_status cudf_amd_comm_create(const uint8_t* id_128_bytes, int32_t world_size, int32_t rank, cudf_amd_comm_t* out);
 void cudf_amd_comm_destroy(cudf_amd_comm_t comm);
+/* Loopback world (include/cudf/distributed.hpp `transport`): world_size virtual ranks inside this process on the current device;
+ * out_comms receives world_size communicators. Every rank must be driven by its own host thread (collectives rendezvous). */
+cudf_amd_status cudf_amd_comm_create_loopback(int32_t world_size, cudf_amd_comm_t* out_comms);
+/* Largest single message of the payload exchange in bytes (default 1 GiB); larger slices travel in several rounds. Every rank
+ * of a communicator must set the same value. */
+cudf_amd_status cudf_amd_comm_set_max_message_bytes(cudf_amd_comm_t comm, int64_t bytes);
+/* Host-side bookkeeping of the exchange (no device work; cudf::distributed::plan_exchange): counts[p * world + q] = rows rank p
+ * sends to rank q -> what `rank` receives from each peer (world entries), where the slices start in its receive buffers
+ * (world + 1 offsets), the largest message between two different ranks in rows. */
+cudf_amd_status cudf_amd_plan_exchange(const int64_t* counts, int32_t world_size, int32_t rank, int64_t* out_recv_count,
+                                       int64_t* out_recv_offset, int64_t* out_biggest);
+/* cudf::distributed::shuffle_join: inner join of two row-sharded tables; both sides shuffled by key, the owner rank joins.
+ * out_global_row_ids: a table of two INT64 columns (global left row id, global right row id), global id = rows of the lower
+ * ranks + local index. Collective. */
+cudf_amd_status cudf_amd_shuffle_join(cudf_amd_comm_t comm, const cudf_amd_column_view* left_keys, int32_t num_left,
+                                      const cudf_amd_column_view* right_keys, int32_t num_right, int32_t nulls_equal, void* stream,
+                                      cudf_amd_table_t* out_global_row_ids);
 cudf_amd_status cudf_amd_range_partition(const cudf_amd_column_view* input, int32_t num_columns, const int32_t* key_columns,
                                          int32_t num_key_columns, int32_t num_destinations, void* stream,
                                          cudf_amd_table_t* out_table, int32_t* out_offsets);

@@ -5,6 +5,7 @@
 // a non-owning ref onto a polymorphic resource with allocate/deallocate(bytes, stream).
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <atomic>
 #include <cstddef>
 
 namespace rmm {
@@ -62,15 +63,16 @@ class statistics_resource_adaptor final : public device_memory_resource {
   [[nodiscard]] std::size_t current_bytes() const { return _cur; }
   [[nodiscard]] std::size_t peak_bytes() const { return _peak; }
   [[nodiscard]] std::size_t allocation_count() const { return _count; }
-  void reset_peak() { _peak = _cur; }
+  void reset_peak() { _peak = _cur.load(); }
 
  private:
   void* do_allocate(std::size_t bytes, hipStream_t stream) override
   {
     void* p = _up->allocate(bytes, stream);
-    _cur += bytes;
+    std::size_t const now = _cur.fetch_add(bytes) + bytes;
     ++_count;
-    if (_cur > _peak) _peak = _cur;
+    std::size_t pk = _peak.load();
+    while (now > pk && !_peak.compare_exchange_weak(pk, now)) {}
     return p;
   }
   void do_deallocate(void* p, std::size_t bytes, hipStream_t stream) noexcept override
@@ -79,7 +81,7 @@ class statistics_resource_adaptor final : public device_memory_resource {
     _cur -= bytes;
   }
   device_memory_resource* _up;
-  std::size_t _cur{0}, _peak{0}, _count{0};
+  std::atomic<std::size_t> _cur{0}, _peak{0}, _count{0};  // (allocations come from any thread)
 };
 
 device_memory_resource* get_current_device_resource();

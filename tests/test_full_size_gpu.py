@@ -5,8 +5,9 @@ would take minutes per case here; it pins the same code paths at the sizes of te
       sums against a float64 scatter-add within the order-of-summation bound; on the dense-key path and on the hash path
   C3  500M x 50M inner join, 5% nulls, UNEQUAL: pair count = membership count, every pair joins equal valid keys, no pair twice;
       on the direct-address table and (sparse keys) on the hash table
-  C4  1B rows, keys (int64, int32 with nulls), float64 value with nulls, MEAN + MIN + MAX: group count = distinct valid key
-      pairs, global extremes exact, every mean inside [min, max]
+  C4  1B rows, keys (int64, int32 with nulls), float64 value with nulls, MEAN + MIN + MAX: the groups are exactly the distinct
+      valid key pairs, every group's MIN / MAX / validity bit-exact and its MEAN = sum / count of a torch per-group reference
+      (bincount, scatter_add_, scatter_reduce_) within the order-of-summation bound
 """
 import os
 
@@ -72,5 +73,6 @@ def test_c4_full_size(gpu):
     import bench_configs as BC
     run, check, rows, algo_bytes = BC.make_c4(1.0)
     checks = check(run())
-    assert checks["groups_ok"] and checks["global_max_ok"] and checks["global_min_ok"] and checks["mean_within_min_max"], checks
+    # per-group reference (counts by bincount, sums by scatter_add_, min / max by scatter_reduce_), not global properties
+    assert checks["all_ok"] and checks["global_max_ok"] and checks["global_min_ok"] and checks["mean_within_min_max"], checks
     torch.cuda.empty_cache()
