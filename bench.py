@@ -387,10 +387,11 @@ def main():
             traffic, traffic_note = None, None
             try:  # PMC traffic of this kernel at this workload, collected with rocprofv3 (see the file's "how"): quoted only
                 # if it was taken from the source tree this library is built from - otherwise it is stale and says so
-                with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
+                pmc_file = next(f for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                     doc = json.load(f)
                 if doc.get("sources_sha256") != _sources_sha256():
-                    traffic_note = "profiles/r2_pmc_traffic.json was collected from a different source tree: not quoted"
+                    traffic_note = f"profiles/{pmc_file} was collected from a different source tree: not quoted"
                 elif name in doc["kernels"] and n == 1_000_000_000 and groups == 1_000_000:
                     traffic = doc["kernels"][name]["hbm_bytes_per_launch"]
             except Exception as e:  # noqa: BLE001

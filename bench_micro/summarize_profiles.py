@@ -13,6 +13,43 @@ out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def config_traffic():
+    """PMC traffic per kernel NAME for the C3 / C3-sparse / C4 runs (pmc_<config>_<counter>/): pmc_traffic_configs.json."""
+    import re
+    doc = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --config <c> "
+                  "--steps 2 --warmup 1 --no-cpu-baseline`; per-launch averages over every dispatch of a kernel; read bytes = 2 x FETCH_SIZE "
+                  "(gfx950: 128-B requests tallied at 64 B), WRITE_SIZE as is; warm-up launches included in the average", "configs": {}}
+    for c in ("c3", "c3sparse", "c4"):
+        per = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            fs = glob.glob(os.path.join(out, f"pmc_{c}_{counter}", "**", "*counter_collection.csv"), recursive=True)
+            if not fs:
+                continue
+            acc = defaultdict(lambda: [0.0, set()])
+            for r in csv.DictReader(open(fs[0])):
+                if r.get("Counter_Name") != counter:
+                    continue
+                full = r.get("Kernel_Name", "")
+                m = re.search(r"(k_[a-z0-9_]+)(<[^(]*>)?", full)  # k_name<template arguments>
+                name = (m.group(1) + (m.group(2) or "")[:48]) if m else full[:64]
+                acc[name][0] += float(r["Counter_Value"])
+                acc[name][1].add(r.get("Dispatch_Id"))
+            for k, (tot, ids) in acc.items():
+                per.setdefault(k, {})[counter + "_KB_per_launch"] = tot / max(1, len(ids))
+                per[k]["launches"] = len(ids)
+        for k, d in per.items():
+            d["read_GB"] = round(2 * d.get("FETCH_SIZE_KB_per_launch", 0) * 1024 / 1e9, 3)
+            d["write_GB"] = round(d.get("WRITE_SIZE_KB_per_launch", 0) * 1024 / 1e9, 3)
+        doc["configs"][c] = {k: v for k, v in sorted(per.items(), key=lambda kv: -(kv[1]["read_GB"] + kv[1]["write_GB"]))[:10]}
+    json.dump(doc, open(os.path.join(out, "pmc_traffic_configs.json"), "w"), indent=1)
+    print(json.dumps({c: {k: (v["read_GB"], v["write_GB"]) for k, v in d.items()} for c, d in doc["configs"].items()})[:1500])
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "configs":
+    config_traffic()
+    sys.exit(0)
+
+
 def sources_sha256():
     """Hash of the kernel / host sources the library is built from: bench.py quotes the PMC traffic only for a matching tree."""
     h = hashlib.sha256()
@@ -49,7 +86,7 @@ lines = []
 if f:
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: -float(r.get("TotalDurationNs", r.get("Total_Duration", 0)) or 0))
-    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline   ({os.path.basename(f)})")
+    lines.append(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary   ({os.path.basename(f)})")
     lines.append(f"{'calls':>6} {'avg_ms':>10} {'total_ms':>10} {'pct':>6}  kernel")
     for r in rows[:14]:
         tot = float(r.get("TotalDurationNs", 0)) / 1e6

@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(1024, 8) k_aggregate_dense(dense_agg_args cons
     }
   }
   __syncthreads();
-  if (!last_chunk || nsplit > 1) {  // the image is carried to the next chunk, or merged with the partition's other shares
+  if (!last_chunk || nsplit > 1 || a.keep_images) {  // the image is carried to the next chunk, or merged with the partition's other shares / columns
     for (int i = threadIdx.x; i < a.image_bytes / 16; i += B)
       gstore(reinterpret_cast<u64x2*>(image) + i, reinterpret_cast<u64x2 const*>(lds_raw)[i]);
     return;
@@ -499,6 +499,8 @@ int dense_occ_acc(plan_dev const& plan)
   return -1;
 }
 std::size_t dense_table_bytes(plan_dev const& plan, int slots) { return make_dense_layout(plan, slots, dense_occ_acc(plan)).bytes; }
+uint32_t dense_acc_offset(plan_dev const& plan, int slots, int q) { return make_dense_layout(plan, slots, dense_occ_acc(plan)).off[q]; }
+uint32_t dense_occ_offset(plan_dev const& plan, int slots) { return make_dense_layout(plan, slots, dense_occ_acc(plan)).occ_off; }
 
 void store_args(dense_agg_args const& a, dense_agg_args* d_args, hipStream_t stream)
 {

@@ -272,6 +272,114 @@ __device__ __forceinline__ void decode_dense_local(plan_dev const& p, dense_map 
   }
 }
 
+// ---- the same loader with the SHAPE of the columns fixed at compile time: key widths, which columns carry a
+// validity mask, an 8-byte value. The run-time form above loads a (dummy) validity word for every column and row, switches on the
+// width at every load and does all digit arithmetic in 64 bits; here a column without a mask costs no load, a 4-byte key sits
+// in one register and its digit is 32-bit arithmetic. W1 == 0: one key column. Offsets, bases, lo / range / stride and the
+// signedness stay run-time (wave-uniform) values of `dense_local`.
+template <int W0_, bool M0_, int W1_, bool M1_, bool MV_>
+struct dense_shape {
+  static constexpr int W0 = W0_, W1 = W1_;
+  static constexpr bool M0 = M0_, M1 = M1_, MV = MV_;
+};
+template <int W>
+using key_reg_t = std::conditional_t<W == 8, uint64_t, uint32_t>;
+template <typename SHAPE, int RPT>
+struct dense_static_tile {
+  key_reg_t<SHAPE::W0> k0[RPT];
+  key_reg_t<SHAPE::W1 == 0 ? 4 : SHAPE::W1> k1[SHAPE::W1 != 0 ? RPT : 1];
+  uint32_t m0[SHAPE::M0 ? RPT : 1], m1[SHAPE::M1 ? RPT : 1], mv[SHAPE::MV ? RPT : 1];
+  uint64_t v[RPT];
+};
+template <int W>
+__device__ __forceinline__ key_reg_t<W> load_key_static(dense_col_local const& c, int64_t rowc)
+{
+  if constexpr (W == 8) return gload(reinterpret_cast<uint64_t const*>(c.head) + c.offset + rowc);
+  else if constexpr (W == 4) return gload(reinterpret_cast<uint32_t const*>(c.head) + c.offset + rowc);
+  else if constexpr (W == 2) return gload(reinterpret_cast<uint16_t const*>(c.head) + c.offset + rowc);
+  else return gload(c.head + c.offset + rowc);
+}
+template <typename SHAPE, int RPT>
+__device__ __forceinline__ void issue_dense_static(dense_local const& L, int64_t tile, int B, int64_t end, dense_static_tile<SHAPE, RPT>& t)
+{
+  int64_t rowc[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) rowc[k] = min(tile + static_cast<int64_t>(k) * B + threadIdx.x, end - 1);
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) t.k0[k] = load_key_static<SHAPE::W0>(L.kc[0], rowc[k]);
+  if constexpr (SHAPE::W1 != 0) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) t.k1[k] = load_key_static<SHAPE::W1>(L.kc[1], rowc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) t.v[k] = gload(reinterpret_cast<uint64_t const*>(L.vc.head) + L.vc.offset + rowc[k]);
+  if constexpr (SHAPE::M0) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) t.m0[k] = gload(L.kc[0].mask + ((L.kc[0].offset + rowc[k]) >> 5));
+  }
+  if constexpr (SHAPE::M1) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) t.m1[k] = gload(L.kc[1].mask + ((L.kc[1].offset + rowc[k]) >> 5));
+  }
+  if constexpr (SHAPE::MV) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) t.mv[k] = gload(L.vc.mask + ((L.vc.offset + rowc[k]) >> 5));
+  }
+}
+// one key column's digit: keep &= its validity bit, bad |= kept and out of range, idx32 += digit * stride
+template <int W, bool M>
+__device__ __forceinline__ void digit_static(dense_local const& L, int c, key_reg_t<W> raw, uint32_t mword, int64_t row, bool& keep, bool& bad,
+                                             uint32_t& idx32)
+{
+  if constexpr (M) keep = keep && ((mword >> ((L.kc[c].offset + row) & 31)) & 1u) != 0;  // NULL key: the row is dropped (EXCLUDE)
+  uint64_t v;
+  if constexpr (W == 8) {
+    v = raw;
+  } else {
+    // (a narrow column: sign- or zero-extension is one 32-bit operation and a select of the high word)
+    constexpr int SH   = 32 - 8 * W;
+    uint32_t const r32 = static_cast<uint32_t>(raw);
+    int32_t const sx   = static_cast<int32_t>(r32 << SH) >> SH;
+    v = L.is_signed[c] ? static_cast<uint64_t>(static_cast<int64_t>(sx)) : static_cast<uint64_t>(r32);
+  }
+  uint64_t const dig = v - L.lo[c];
+  bool const out     = dig >= L.range[c];
+  bad                = bad || (out && keep);
+  idx32 += out ? 0u : static_cast<uint32_t>(dig) * L.stride[c];
+}
+template <typename SHAPE, int RPT>
+__device__ __forceinline__ void decode_dense_static(dense_local const& L, int64_t tile, int B, int64_t end, dense_static_tile<SHAPE, RPT> const& t,
+                                                    bool (&keep)[RPT], uint32_t (&idx32)[RPT], uint32_t (&valid)[RPT], uint64_t (&vbits)[RPT], bool& bad)
+{
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    int64_t const row = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+    bool const inrange = row < end;
+    keep[k]  = inrange;
+    idx32[k] = 0;
+    digit_static<SHAPE::W0, SHAPE::M0>(L, 0, t.k0[k], SHAPE::M0 ? t.m0[k] : 0u, row, keep[k], bad, idx32[k]);
+    if constexpr (SHAPE::W1 != 0) digit_static<SHAPE::W1, SHAPE::M1>(L, 1, t.k1[k], SHAPE::M1 ? t.m1[k] : 0u, row, keep[k], bad, idx32[k]);
+    if constexpr (SHAPE::MV) valid[k] = inrange ? (t.mv[k] >> ((L.vc.offset + row) & 31)) & 1u : 0u;
+    else valid[k] = inrange ? 1u : 0u;
+    vbits[k] = t.v[k];  // (an 8-byte value is its own accumulator class: int64 / uint64 / float64 bits)
+  }
+}
+// does a composite dense plan have this shape? (two key columns at most, an 8-byte value of an 8-byte accumulator class)
+template <typename SHAPE>
+inline bool dense_shape_matches(plan_dev const& p, dense_map const& dm)
+{
+  if (dm.nkeys != (SHAPE::W1 != 0 ? 2 : 1)) return false;
+  device_column const& c0 = p.cols[dm.key[0].col];
+  device_column const& cv = p.cols[dm.value_col];
+  bool ok = c0.width == SHAPE::W0 && (c0.mask != nullptr) == SHAPE::M0 && cv.width == 8 && (cv.mask != nullptr) == SHAPE::MV &&
+            (cv.cls == cudf::detail::CLS_SINT || cv.cls == cudf::detail::CLS_UINT || cv.cls == cudf::detail::CLS_F64);
+  if constexpr (SHAPE::W1 != 0) {
+    device_column const& c1 = p.cols[dm.key[1].col];
+    ok = ok && c1.width == SHAPE::W1 && (c1.mask != nullptr) == SHAPE::M1;
+  }
+  return ok;
+}
+
 template <int RPT>
 __device__ __forceinline__ void load_dense_composite(plan_dev const& p, dense_map const& dm, int64_t tile, int B, int64_t end,
                                                      bool (&keep)[RPT], uint32_t (&idx32)[RPT], uint32_t (&valid)[RPT],

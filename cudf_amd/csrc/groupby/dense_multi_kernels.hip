@@ -1,0 +1,369 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 kernels of the dense-key hash-groupby path for SEVERAL value columns (engine.hpp ring_multi_args,
+// dense_multi_merge_args): the ring scatter of dense_ring_kernels.hip with one value stream per column next to the shared 16-bit
+// tag stream, and the fold of the per-column table images into partial records.
+//
+// df.groupby(k).agg({a: sum, b: sum}) used to fall off the dense path (24- / 32-byte hash records: 21.5 / 35.2 ms per 1B rows
+// on 1M groups against 6.7 ms for one column, profiles/r2_multi_value.txt). Here the input is still read ONCE: every partition
+// owns one ring per value column and one tag ring in LDS; a row reserves ONE position (one returning ds_add) that holds in all
+// of them; owner lanes flush whole aligned 128-byte granules of every stream. 160 KiB of LDS carry 128 partitions x
+// (nval x CAP x 8 + 128 x 2) bytes: CAP = 48 records for two columns, 32 for three (one column: 64), so the tile shrinks with
+// the ring - 2048 rows for two columns, 1024 for three - and loads stay two / four tiles ahead.
+// The reference does all (column, aggregation) pairs in one pass too (cpp/src/groupby/hash/compute_global_memory_aggs.cuh:139-147),
+// with one global atomic per pair and row.
+#include "device_common.hpp"
+
+namespace cudf::groupby::detail {
+namespace {
+
+// (DENSE: the key is loaded beside the NV streamed value columns; hash keys: the key IS stream 0)
+template <int NV, bool DENSE, int RPT>
+struct multi_tile {
+  uint64_t k[DENSE ? RPT : 1];
+  uint64_t v[NV][RPT];
+};
+
+// NV: 8-byte streams written. DENSE: dense keys - the streams are the value columns, the partition digit and the 16-bit tag come
+// from the dense map. Otherwise (sparse single 8-byte keys, hash_ring path of paths_hash.cpp): stream 0 is the KEY column, the
+// others the value columns, the digit is the top bits of the key hash and there are no tags - the aggregate (k_aggregate_k64)
+// hashes the key again. CAP: records per partition ring (a multiple of 16, not necessarily a power of two: positions are taken
+// modulo CAP).
+template <int NV, bool DENSE, int CAP, int RPT, int D>
+__global__ void __launch_bounds__(1024) k_dense_ring_scatter_multi(ring_multi_args const* __restrict__ ap)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int s_pending, s_abort;
+  ring_multi_args const& a = *ap;
+  plan_dev const& p        = a.plan;
+  constexpr int B          = 1024;
+  constexpr uint32_t G = 16, GT = 64, TPL = 8, TCAP = 128;  // records per value granule / per tag granule (both 128 bytes); tag ring length
+  static_assert(CAP % 16 == 0 && CAP + GT - G <= TCAP, "a tag waits for its granule of 64 while its value may already have left");
+  int const P = a.P;
+  uint64_t* rval  = reinterpret_cast<uint64_t*>(lds_raw);                         // [NV][P * CAP]
+  uint16_t* rtag  = reinterpret_cast<uint16_t*>(rval + static_cast<uint32_t>(NV) * P * CAP);  // [P * TCAP] (DENSE)
+  uint32_t* tail  = reinterpret_cast<uint32_t*>(rtag + (DENSE ? static_cast<uint32_t>(P) * TCAP : 0u));  // [P] next virtual position
+  uint32_t* limit = tail + P;                                                     // [P] head + CAP as of the last flush
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
+  int const PW = P / nwaves;  // partitions owned by a wave (1 ... 16): owner lane l < PW holds partition wave * PW + l
+  uint32_t head = 0, headt = 0;  // owner lanes: values / tags of the partition flushed so far
+  for (int d = threadIdx.x; d < P; d += B) {
+    tail[d]  = 0;
+    limit[d] = CAP;
+  }
+  if (threadIdx.x == 0) {
+    s_pending = 0;
+    s_abort   = 0;
+  }
+  __syncthreads();
+  constexpr int64_t T = static_cast<int64_t>(B) * RPT;
+  int const item      = blockIdx.x;
+  // workgroup w takes the row tiles w, w + slices, ...: sorted or clustered keys spread over every workgroup's regions
+  int64_t const begin = static_cast<int64_t>(item) * T, end = a.nrows, step = static_cast<int64_t>(a.slices) * T;
+  uint32_t const region_cap = static_cast<uint32_t>(a.region_cap);
+  uint64_t* const out_val   = a.out_val;
+  uint16_t* const out_tag   = a.out_tag;
+  int64_t const sstride     = a.stream_stride;
+  [[maybe_unused]] uint64_t const dense_lo = a.map.lo, dense_range = a.map.range;
+  [[maybe_unused]] uint32_t const mult = a.map.mult, bmask = DENSE ? (1u << a.map.bits) - 1u : 0u;
+  int const shift = a.shift;
+  [[maybe_unused]] uint32_t const pmask = static_cast<uint32_t>(P - 1), tmask = DENSE ? (1u << shift) - 1u : 0u;
+  [[maybe_unused]] uint64_t const* kbase = p.simple_base[0];
+  [[maybe_unused]] uint64_t const kmask0 = p.key_mask[0];
+  uint64_t const* vbase[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) vbase[j] = p.simple_base[(DENSE ? 1 : 0) + j];
+
+  auto issue = [&](int64_t tile, multi_tile<NV, DENSE, RPT>& r) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      int64_t const row = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+      if (row < end) {
+        if constexpr (DENSE) r.k[k] = gload(kbase + row);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) r.v[j][k] = gload(vbase[j] + row);
+      }
+    }
+  };
+  // flush every complete granule of this wave's partitions; final: also the partial last granule
+  auto flush = [&](bool final) {
+    uint32_t nrec = 0, nrect = 0;
+    int ab        = 0;
+    int const dmine = wave * PW + lane;
+    if (lane < PW) {
+      uint32_t const t = tail[dmine], lim = head + CAP;
+      uint32_t const c = static_cast<int32_t>(t - lim) < 0 ? t : lim;  // records that made it into the ring
+      uint32_t const complete = final ? c : (c & ~(G - 1u));
+      nrec  = complete - head;
+      nrect = (final ? c : (c & ~(GT - 1u))) - headt;
+      if (complete > region_cap) {
+        s_abort = 1;
+        ab      = 1;
+      }
+    }
+    // values: 8 lanes per granule (two values = 16 bytes per lane), 8 partitions per batch, one stream after the other
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      uint64_t const* ring = rval + static_cast<uint32_t>(j) * P * CAP;
+      uint64_t* const out  = out_val + static_cast<int64_t>(j) * sstride;
+      for (int b = 0; b * 8 < PW; ++b) {
+        int const pl = b * 8 + (lane >> 3), sub = lane & 7;
+        uint32_t const mr = __shfl(nrec, pl), mh = __shfl(head, pl);
+        int const mab     = __shfl(ab, pl);
+        int const d       = wave * PW + pl;
+        int64_t const rbase = (static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
+        for (uint32_t g = 0;; ++g) {
+          uint32_t const q = g * G + sub * 2;
+          bool const act   = pl < PW && q < mr && !mab;
+          if (__ballot(act) == 0) break;
+          if (act) {
+            uint32_t const pos = mh + q;  // (even: head is a multiple of 16; CAP is even: the pair does not wrap)
+            u64x2 const v      = *reinterpret_cast<u64x2 const*>(ring + static_cast<uint32_t>(d) * CAP + pos % CAP);
+            if (q + 1 < mr) gstore(reinterpret_cast<u64x2*>(out + rbase + pos), v);
+            else gstore(out + rbase + pos, static_cast<uint64_t>(v.x));
+          }
+        }
+      }
+    }
+    // tags: 8 lanes per granule (16 bytes = 8 tags per lane), 8 partitions per batch
+    for (int b = 0; DENSE && b * 8 < PW; ++b) {
+      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
+      uint32_t const mr = __shfl(nrect, pl), mh = __shfl(headt, pl);
+      int const mab     = __shfl(ab, pl);
+      int const d       = wave * PW + pl;
+      int64_t const rbase = (static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
+      for (uint32_t g = 0;; ++g) {
+        uint32_t const q = g * GT + sub * TPL;
+        bool const act   = pl < PW && q < mr && !mab;
+        if (__ballot(act) == 0) break;
+        if (act) {
+          uint32_t const pos  = mh + q;
+          uint16_t const* src = rtag + static_cast<uint32_t>(d) * TCAP + (pos & (TCAP - 1u));
+          if (q + TPL <= mr) {
+            gstore(reinterpret_cast<u32x4*>(out_tag + rbase + pos), *reinterpret_cast<u32x4 const*>(src));
+          } else {  // (the partial tail of the final flush)
+            for (uint32_t e = 0; q + e < mr; ++e) gstore(out_tag + rbase + pos + e, src[e]);
+          }
+        }
+      }
+    }
+    if (lane < PW) {
+      head += nrec;
+      headt += nrect;
+      limit[dmine] = head + CAP;
+    }
+  };
+  auto put = [&](uint32_t d, uint32_t pos, uint32_t tg, uint64_t const (&val)[NV]) {
+    uint32_t const w = d * CAP + pos % CAP;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) rval[static_cast<uint32_t>(j) * P * CAP + w] = val[j];
+    if constexpr (DENSE) rtag[d * TCAP + (pos & (TCAP - 1u))] = static_cast<uint16_t>(tg);
+  };
+
+  multi_tile<NV, DENSE, RPT> pre[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) issue(begin + j * step, pre[j]);
+  for (int64_t tile = begin; tile < end; tile += D * step) {
+#pragma unroll
+    for (int jt = 0; jt < D; ++jt) {
+      int64_t const t0 = tile + jt * step;
+      // ---- this tile's rows: partition digit, tag and values (waits for the tile's loads)
+      bool keep[RPT];
+      uint32_t d[RPT], tg[RPT];
+      uint64_t val[RPT][NV];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        keep[k] = t0 + static_cast<int64_t>(k) * B + threadIdx.x < end;
+        d[k]    = 0;
+        tg[k]   = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) val[k][j] = pre[jt].v[j][k];
+        if (keep[k]) {
+          if constexpr (DENSE) {
+            uint64_t idx = pre[jt].k[k] - dense_lo;
+            if (idx >= dense_range) {  // the sampled key range was wrong: this call is void (redone by hash)
+              atomicOr(a.overflow, 4);
+              idx = 0;
+            }
+            uint32_t const x = (static_cast<uint32_t>(idx) * mult) & bmask;
+            d[k]  = (x >> shift) & pmask;
+            tg[k] = (x & tmask) | (1u << 15);
+          } else {  // the engine's key hash (device_common.hpp hash_key_units), its top bits
+            uint64_t const h = mix64(0x9e3779b97f4a7c15ull ^ (val[k][0] & kmask0));
+            d[k]             = static_cast<uint32_t>(h >> shift) & pmask;
+          }
+        }
+      }
+      issue(t0 + D * step, pre[jt]);
+      if (t0 >= end) break;  // (uniform)
+      // ---- reserve ring positions; rows whose position lies beyond the ring wait for the flush
+      uint32_t pos[RPT], lim[RPT];
+      bool pend[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        pos[k] = 0;
+        lim[k] = 0;
+        if (keep[k]) {
+          pos[k] = atomicAdd(&tail[d[k]], 1u);
+          lim[k] = limit[d[k]];
+        }
+      }
+      bool any_pend = false;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        pend[k] = keep[k] && static_cast<int32_t>(pos[k] - lim[k]) >= 0;
+        if (keep[k] && !pend[k]) put(d[k], pos[k], tg[k], val[k]);
+        any_pend = any_pend || pend[k];
+      }
+      if (any_pend) s_pending = 1;
+      lds_barrier();
+      flush(false);
+      lds_barrier();
+      while (s_pending) {  // a ring was full: its granules are flushed by now, the waiting rows go in
+        lds_barrier();
+        if (threadIdx.x == 0) s_pending = 0;
+        lds_barrier();
+        any_pend = false;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          if (pend[k]) {
+            uint32_t const l2 = limit[d[k]];
+            if (static_cast<int32_t>(pos[k] - l2) < 0) {
+              put(d[k], pos[k], tg[k], val[k]);
+              pend[k] = false;
+            } else {
+              any_pend = true;
+            }
+          }
+        }
+        if (any_pend) s_pending = 1;
+        lds_barrier();
+        flush(false);
+        lds_barrier();
+        if (s_abort) break;
+      }
+      if (s_abort) {  // a region would overflow (skewed or clustered keys): the caller redoes the call
+        if (threadIdx.x == 0) atomicOr(a.overflow, 1);
+        return;
+      }
+    }
+  }
+  flush(true);
+  lds_barrier();
+  if (s_abort) {
+    if (threadIdx.x == 0) atomicOr(a.overflow, 1);
+    return;
+  }
+  if (lane < PW) a.region_count[static_cast<int64_t>(wave * PW + lane) * a.slices + item] = static_cast<int32_t>(head);
+}
+
+// ------------------------------------------------------------------ K_dense_merge_dump_multi
+// The table images of every value column (left by k_aggregate_dense, one launch per column) -> partial records of the whole
+// plan. Work item (d, j): slots [j, j + 1) * slots / dsplit of partition d; one thread per slot.
+__global__ void __launch_bounds__(1024) k_dense_merge_dump_multi(dense_multi_merge_args const* __restrict__ ap, int dsplit)
+{
+  __shared__ uint32_t s_dump;
+  dense_multi_merge_args const& a = *ap;
+  plan_dev const& p               = a.plan;
+  int const NACC = p.NACC, slots = a.slots, nsplit = a.nsplit, B = blockDim.x;
+  int const d = blockIdx.x / dsplit, per = slots / dsplit, s0 = (static_cast<int>(blockIdx.x) % dsplit) * per;
+  if (threadIdx.x == 0) s_dump = 0;
+  __syncthreads();
+  int const PU        = 1 + NACC;
+  uint64_t* out       = a.out_records + static_cast<int64_t>(blockIdx.x) * per * PU;
+  uint32_t const hi   = static_cast<uint32_t>(d) << (a.map.bits - a.map.log2P);
+  uint32_t const bmask = (1u << a.map.bits) - 1u;
+  for (int s = s0 + threadIdx.x; s < s0 + per; s += B) {
+    uint64_t acc[MAX_ACC];
+    bool occupied = false;
+    for (int q = 0; q < NACC; ++q) {
+      int const op = p.acc[q].op, c = a.acc_col[q];
+      bool const narrow = a.acc_narrow[q] != 0;
+      unsigned char const* images = reinterpret_cast<unsigned char const*>(a.tables[c]) + static_cast<int64_t>(d) * nsplit * a.image_bytes[c];
+      uint64_t v = narrow ? 0 : acc_identity(op);
+      for (int h = 0; h < nsplit; ++h) {
+        unsigned char const* img = images + static_cast<int64_t>(h) * a.image_bytes[c] + a.acc_off[q];
+        if (narrow) v += gload(reinterpret_cast<uint32_t const*>(img) + s);
+        else v = combine_values(op, v, gload(reinterpret_cast<uint64_t const*>(img) + s));
+      }
+      acc[q] = v;
+      if (q == a.occ_acc) occupied = v != 0;
+    }
+    if (a.occ_acc < 0) {
+      unsigned char const* images = reinterpret_cast<unsigned char const*>(a.tables[0]) + static_cast<int64_t>(d) * nsplit * a.image_bytes[0];
+      for (int h = 0; h < nsplit; ++h)
+        occupied = occupied || ((gload(reinterpret_cast<uint32_t const*>(images + static_cast<int64_t>(h) * a.image_bytes[0] + a.occ_off0) + (s >> 5)) >> (s & 31)) & 1u);
+    }
+    if (!occupied) continue;
+    uint32_t const pos = atomicAdd(&s_dump, 1u);
+    uint64_t* o        = out + static_cast<int64_t>(pos) * PU;
+    gstore(o, a.map.lo + (((hi | static_cast<uint32_t>(s)) * a.map.mult_inv) & bmask));
+    for (int q = 0; q < NACC; ++q) gstore(o + 1 + q, acc[q]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.out_count[blockIdx.x] = static_cast<int32_t>(s_dump);
+}
+
+template <int NV, bool DENSE, int CAP, int RPT, int D>
+void launch_multi_t(ring_multi_args const& a, ring_multi_args const* d_args, hipStream_t stream)
+{
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter_multi<NV, DENSE, CAP, RPT, D>)); });
+  std::size_t const lds = DENSE ? dense_ring_multi_lds_bytes(NV, a.P, CAP) : hash_ring_lds_bytes(NV, a.P, CAP);
+  cudf::detail::prof::scope prof_{"partition_scatter", stream};
+  hipLaunchKernelGGL((k_dense_ring_scatter_multi<NV, DENSE, CAP, RPT, D>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace
+
+std::size_t dense_ring_multi_lds_bytes(int nval, int P, int cap)
+{
+  return static_cast<std::size_t>(P) * (static_cast<std::size_t>(nval) * cap * 8 + 128 * 2 + 8);
+}
+int dense_ring_multi_cap(int nval) { return nval <= 2 ? 48 : 32; }
+std::size_t hash_ring_lds_bytes(int nstreams, int P, int cap) { return static_cast<std::size_t>(P) * (static_cast<std::size_t>(nstreams) * cap * 8 + 8); }
+
+void store_args(ring_multi_args const& a, ring_multi_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<ring_multi_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+void store_args(dense_multi_merge_args const& a, dense_multi_merge_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_args<dense_multi_merge_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_dense_ring_scatter_multi(ring_multi_args const& a, ring_multi_args const* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == a.nval && (a.nval == 2 || a.nval == 3),
+               "ring scatter: one plain key column and two or three plain value columns");
+  CUDF_EXPECTS(a.P >= 16 && a.P <= 256 && (a.P & (a.P - 1)) == 0 && a.cap == dense_ring_multi_cap(a.nval) &&
+                 dense_ring_multi_lds_bytes(a.nval, a.P, a.cap) + 64 <= 160 * 1024,
+               "ring scatter: fan-out 16 ... 256 within the LDS");
+  CUDF_EXPECTS(a.region_cap % 64 == 0 && a.shift >= 0 && a.shift <= 15 && a.slices >= 1 && a.stream_stride % 16 == 0 && a.nrows >= 1,
+               "ring scatter: region geometry");
+  if (a.nval == 2) return launch_multi_t<2, true, 48, 2, 2>(a, d_args, stream);
+  return launch_multi_t<3, true, 32, 1, 4>(a, d_args, stream);
+}
+
+void launch_hash_ring_scatter(ring_multi_args const& a, ring_multi_args const* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1 && a.nval == 2,
+               "hash ring scatter: one plain 8-byte key column and one plain 8-byte value column (two streams)");
+  CUDF_EXPECTS(a.P == 256 && a.cap == HASH_RING_CAP && hash_ring_lds_bytes(2, a.P, a.cap) + 64 <= 160 * 1024, "hash ring scatter: 256 partitions");
+  CUDF_EXPECTS(a.region_cap % 64 == 0 && a.shift >= 32 && a.shift < 64 && a.slices >= 1 && a.stream_stride % 16 == 0 && a.nrows >= 1,
+               "hash ring scatter: region geometry");
+  return launch_multi_t<2, false, HASH_RING_CAP, 2, 3>(a, d_args, stream);
+}
+
+void launch_dense_merge_dump_multi(dense_multi_merge_args const& a, dense_multi_merge_args const* d_args, int dsplit, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.ncols >= 2 && a.ncols <= RING_MAX_VALUES && a.nsplit >= 1 && dsplit >= 1 && a.slots % dsplit == 0 && a.map.nkeys == 0,
+               "dense keys, several value columns: merge geometry");
+  cudf::detail::prof::scope prof_{"aggregate_merge", stream};
+  hipLaunchKernelGGL(k_dense_merge_dump_multi, dim3(a.nitems * dsplit), dim3(1024), 0, stream, d_args, dsplit);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cudf::groupby::detail

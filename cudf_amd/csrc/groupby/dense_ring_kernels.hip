@@ -19,34 +19,41 @@
 namespace cudf::groupby::detail {
 namespace {
 
+constexpr int STATIC_TILES_AHEAD = 2;  // tiles of loads in flight with a compile-time column shape (the run-time loader: 1)
 constexpr int RING_SRC_SIMPLE  = 0;  // one plain 8-byte integer key column, one plain 8-byte value column
 constexpr int RING_SRC_COLS    = 1;  // composite dense keys (dense_loader.hpp)
 constexpr int RING_SRC_REGIONS = 2;  // level 2: the regions of a level-1 partition
+constexpr int RING_SRC_COLS_STATIC = 3;  // composite dense keys whose column shape is a template argument (dense_loader.hpp dense_shape)
 
 // The loads of one tile, issued D tiles ahead of their use.
-template <int SRC, int RPT>
+template <int SRC, int RPT, typename SHAPE = void>
 struct ring_tile;
 template <int RPT>
-struct ring_tile<RING_SRC_SIMPLE, RPT> {
+struct ring_tile<RING_SRC_SIMPLE, RPT, void> {
   uint64_t k[RPT], v[RPT];
 };
 template <int RPT>
-struct ring_tile<RING_SRC_COLS, RPT> {
+struct ring_tile<RING_SRC_COLS, RPT, void> {
   dense_raw_tile<RPT> t;
 };
 template <int RPT>
-struct ring_tile<RING_SRC_REGIONS, RPT> {
+struct ring_tile<RING_SRC_REGIONS, RPT, void> {
   uint64_t v[RPT];
   uint32_t t[RPT];
+};
+template <int RPT, typename SHAPE>
+struct ring_tile<RING_SRC_COLS_STATIC, RPT, SHAPE> {
+  dense_static_tile<SHAPE, RPT> t;
 };
 
 // TAG: uint16_t for the last level (a table has at most 2^15 slots: slot | validity << 15), uint32_t for the first of two levels
 // (the bits of the scrambled index below its digit | validity << 31).
 // HOT: heavy-hitter keys are aggregated in a small LDS table behind the rings and leave the scatter (a key with percents of the
 // rows would overflow its partition's regions and leave one aggregate workgroup with its rows alone).
-template <int SRC, int RPT, int D, typename TAG, bool HOT = false>
+template <int SRC, int RPT, int D, typename TAG, bool HOT = false, typename SHAPE = void>
 __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args const* __restrict__ ap)
 {
+  constexpr bool COLS = SRC == RING_SRC_COLS || SRC == RING_SRC_COLS_STATIC;
   static_assert(!HOT || SRC == RING_SRC_SIMPLE, "heavy hitters: one plain key column and one plain value column");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int s_pending, s_abort;
@@ -152,10 +159,12 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
     while (reg + 1 < nreg && s_pre[reg + 1] <= v) ++reg;
     return rfirst + static_cast<int64_t>(reg) * rstride + (v - s_pre[reg]);
   };
-  [[maybe_unused]] dense_local const L = SRC == RING_SRC_COLS ? make_dense_local(p, a.map, a.ones) : dense_local{};
-  auto issue = [&](int64_t tile, ring_tile<SRC, RPT>& r) {
+  [[maybe_unused]] dense_local const L = COLS ? make_dense_local(p, a.map, a.ones) : dense_local{};
+  auto issue = [&](int64_t tile, ring_tile<SRC, RPT, SHAPE>& r) {
     if constexpr (SRC == RING_SRC_COLS) {
       issue_dense_local<RPT>(L, tile, B, end, r.t);
+    } else if constexpr (SRC == RING_SRC_COLS_STATIC) {
+      issue_dense_static<SHAPE, RPT>(L, tile, B, end, r.t);
     } else {
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
@@ -237,7 +246,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
     }
   };
 
-  ring_tile<SRC, RPT> pre[D];
+  ring_tile<SRC, RPT, SHAPE> pre[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) issue(begin + j * step, pre[j]);
   for (int64_t tile = begin; tile < end; tile += D * step) {
@@ -248,14 +257,19 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
       bool keep[RPT];
       uint32_t d[RPT], tg[RPT];
       uint64_t val[RPT];
-      if constexpr (SRC == RING_SRC_COLS) {
+      if constexpr (COLS) {
         uint32_t idx32[RPT], valid[RPT];
         bool bad = false;
         if (t0 < end) {  // (uniform)
           // (tried: decode one half of the tile and at once issue the same half of the tile after next into the registers that
           // frees, so that loads stay in flight through the decode phase - C4's first level 11.9 ms against 9.4 ms)
-          decode_dense_local<RPT>(p, a.map, L, t0, B, end, pre[j].t, keep, idx32, valid, val, bad);
-          issue_dense_local<RPT>(L, t0 + D * step, B, end, pre[j].t);
+          if constexpr (SRC == RING_SRC_COLS) {
+            decode_dense_local<RPT>(p, a.map, L, t0, B, end, pre[j].t, keep, idx32, valid, val, bad);
+            issue_dense_local<RPT>(L, t0 + D * step, B, end, pre[j].t);
+          } else {
+            decode_dense_static<SHAPE, RPT>(L, t0, B, end, pre[j].t, keep, idx32, valid, val, bad);
+            issue_dense_static<SHAPE, RPT>(L, t0 + D * step, B, end, pre[j].t);
+          }
           if (bad) atomicOr(a.overflow, 4);
 #pragma unroll
           for (int k = 0; k < RPT; ++k) {
@@ -307,7 +321,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
           }
         }
       }
-      if constexpr (SRC != RING_SRC_COLS) issue(t0 + D * step, pre[j]);
+      if constexpr (!COLS) issue(t0 + D * step, pre[j]);
       if (t0 >= end) break;  // (uniform)
       // ---- reserve ring positions; rows whose position lies beyond the ring wait for the flush
       uint32_t pos[RPT], lim[RPT];
@@ -389,24 +403,43 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
   }
 }
 
-template <int SRC, int RPT, int D, typename TAG, bool HOT = false>
+template <int SRC, int RPT, int D, typename TAG, bool HOT = false, typename SHAPE = void>
 void launch_ring_tag(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
 {
   static std::once_flag attr_once;  // (the API is re-entrant across objects: two threads may launch this kernel first)
-  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D, TAG, HOT>)); });
+  std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter<SRC, RPT, D, TAG, HOT, SHAPE>)); });
   // rings (values + tags), 2 KiB for the ring counters of up to 256 partitions, then the heavy-hitter table
   std::size_t const lds = static_cast<std::size_t>(DENSE_RING_SLOTS) * 16 + 2048 + (HOT ? static_cast<std::size_t>(HOT_SLOTS) * (8 + 8 + 4) : 0);
   int const items       = a.from_columns ? a.slices : a.nseg * a.slices;
   cudf::detail::prof::scope prof_{a.from_columns ? "partition_scatter" : "partition_scatter_level2", stream};
-  hipLaunchKernelGGL((k_dense_ring_scatter<SRC, RPT, D, TAG, HOT>), dim3(items), dim3(1024), lds, stream, d_args);
+  hipLaunchKernelGGL((k_dense_ring_scatter<SRC, RPT, D, TAG, HOT, SHAPE>), dim3(items), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
-template <int SRC, int RPT, int D>
+template <int SRC, int RPT, int D, typename SHAPE = void>
 void launch_ring_t(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
 {
-  if (a.tag16) return launch_ring_tag<SRC, RPT, D, uint16_t>(a, d_args, stream);
-  if constexpr (SRC != RING_SRC_REGIONS) return launch_ring_tag<SRC, RPT, D, uint32_t>(a, d_args, stream);
+  if (a.tag16) return launch_ring_tag<SRC, RPT, D, uint16_t, false, SHAPE>(a, d_args, stream);
+  if constexpr (SRC != RING_SRC_REGIONS) return launch_ring_tag<SRC, RPT, D, uint32_t, false, SHAPE>(a, d_args, stream);
   CUDF_FAIL("ring scatter: the last level writes 16-bit tags");
+}
+// composite dense keys: the column shapes with a loader of their own (dense_loader.hpp dense_shape), else the run-time loader
+using shape_c4          = dense_shape<8, false, 4, true, true>;   // BASELINE configs[3]: (int64, nullable int32) keys, nullable 8-byte value
+using shape_k32         = dense_shape<4, false, 0, false, false>; // one 4-byte key, plain 8-byte value
+using shape_k32_vnull   = dense_shape<4, false, 0, false, true>;
+using shape_k64_vnull   = dense_shape<8, false, 0, false, true>;  // one 8-byte key, nullable 8-byte value
+using shape_k64_k32     = dense_shape<8, false, 4, false, false>; // (int64, int32) keys and an 8-byte value, no nulls
+template <typename SHAPE>
+bool try_static_shape(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream)
+{
+  if (!dense_shape_matches<SHAPE>(a.plan, a.map)) return false;
+  // Two tiles of loads in flight where the shape's registers allow it (one key column: 106-123 VGPRs, no scratch; 1B rows on 1M
+  // groups, int32 key 7.9 -> 6.3 ms, int64 key with a nullable value 8.1 -> 7.2 ms). Two key columns with masks (C4's shape) spill
+  // 32-48 bytes with two tiles and run no faster than the run-time loader (13.6 ms); with one tile C4's first level takes 6.06
+  // instead of 7.2 ms (profiles/r3_c4_static_ab.txt). CUDF_AMD_GB_STATIC_SHAPES=1 forces one tile, 0 the run-time loader.
+  constexpr bool WIDE = SHAPE::W1 != 0 && (SHAPE::M0 || SHAPE::M1);
+  if (WIDE || a.static_shapes == 1) launch_ring_t<RING_SRC_COLS_STATIC, 4, 1, SHAPE>(a, d_args, stream);
+  else launch_ring_t<RING_SRC_COLS_STATIC, 4, STATIC_TILES_AHEAD, SHAPE>(a, d_args, stream);
+  return true;
 }
 
 }  // namespace
@@ -426,7 +459,14 @@ void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* 
   if (a.from_columns) {
     // (composite loader: 4 rows per thread, one tile ahead. Measured on C4's first level: two tiles ahead spill - 14.3 ms against
     // 9.4 - and 2 or 3 rows per thread with two or three tiles ahead take 11.3-13.1 ms: the per-tile barriers and flush do not amortise)
-    if (a.map.nkeys > 0) return launch_ring_t<RING_SRC_COLS, 4, 1>(a, d_args, stream);
+    if (a.map.nkeys > 0) {
+      if (a.static_shapes &&
+          (try_static_shape<shape_c4>(a, d_args, stream) || try_static_shape<shape_k32>(a, d_args, stream) ||
+           try_static_shape<shape_k32_vnull>(a, d_args, stream) || try_static_shape<shape_k64_vnull>(a, d_args, stream) ||
+           try_static_shape<shape_k64_k32>(a, d_args, stream)))
+        return;
+      return launch_ring_t<RING_SRC_COLS, 4, 1>(a, d_args, stream);
+    }
     CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1, "ring scatter: one plain key column and one plain value column");
     if (a.hot_n > 0) {
       CUDF_EXPECTS(a.tag16 && a.hot_n <= HOT_MAX_KEYS, "ring scatter: heavy hitters on a single level");

@@ -178,6 +178,16 @@ constexpr uint64_t SIG_MEAN_MIN_MAX_F =
   make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1), sig_acc(MIN_F64, SRC_VALUE, 0, -1),
            sig_acc(MAX_F64, SRC_VALUE, 0, -1));
 
+// two / three plain float64 value columns: {a: SUM + COUNT (or MEAN), b: SUM (, c: SUM)} and the plain sums
+constexpr uint64_t SIG_SUMF_CNT_SUMF =
+  make_sig(3, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1), sig_acc(ADD_F64, SRC_VALUE, 1, -1));
+constexpr uint64_t SIG_SUMF_SUMF = make_sig(2, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_F64, SRC_VALUE, 1, -1));
+constexpr uint64_t SIG_SUMF_CNT_SUMF_SUMF =
+  make_sig(4, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_I64, SRC_ONE, -1, -1), sig_acc(ADD_F64, SRC_VALUE, 1, -1),
+           sig_acc(ADD_F64, SRC_VALUE, 2, -1));
+constexpr uint64_t SIG_SUMF_SUMF_SUMF =
+  make_sig(3, sig_acc(ADD_F64, SRC_VALUE, 0, -1), sig_acc(ADD_F64, SRC_VALUE, 1, -1), sig_acc(ADD_F64, SRC_VALUE, 2, -1));
+
 // ------------------------------------------------------------------ record building from columns
 // Validity words of one row: keynulls bit c = key column c NULL; valvalid bit v = value column v valid.
 __device__ __forceinline__ void row_validity(plan_dev const& p, int64_t row, uint32_t& keynulls, uint32_t& valvalid)

@@ -288,6 +288,8 @@ struct dense_agg_args {
   // [h * slices / nsplit, (h + 1) * slices / nsplit)); every workgroup leaves its table image in `tables` and
   // launch_dense_merge_dump folds the nsplit images of a partition into the partial records.
   int32_t nsplit;
+  int32_t keep_images;  // 1: every workgroup leaves its table image in `tables` even with nsplit == 1 (several value columns:
+                        // launch_dense_merge_dump_multi folds the columns' images)
   int32_t const* region_count;
   int64_t region_cap;
   int32_t slices;
@@ -350,6 +352,7 @@ struct dense_ring_args {
   int32_t* region_count;
   int32_t* overflow;   // bit 0: a region overflowed; bit 2: a key outside the dense range
   uint32_t const* ones;  // composite keys: one all-ones word, read in place of the validity word of a column without a mask
+  int32_t static_shapes; // composite keys: take the loader compiled for the columns' shape where there is one (CUDF_AMD_GB_STATIC_SHAPES)
   // Heavy hitters (one plain key, SUM / COUNT plans: hot_plan_ok): rows whose key is one of hot_keys[0 .. hot_n) are aggregated
   // (SUM of the value, row COUNT) in an LDS table of HOT_SLOTS entries behind the rings and never scattered; workgroup w writes
   // its non-empty entries as partial records [key | accumulators in plan order] to hot_out[w * HOT_SLOTS ...], their number to
@@ -362,6 +365,84 @@ struct dense_ring_args {
 constexpr int DENSE_RING_SLOTS = 8192;  // value-ring slots of a workgroup (all partitions); the tag rings are twice as long: 128 KiB of LDS
 void store_args(dense_ring_args const& a, dense_ring_args* d_args, hipStream_t stream);
 void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* d_args, hipStream_t stream);
+// ---- several value columns on the dense path (dense_multi_kernels.hip): one plain 8-byte integer key column and 2-3 plain 8-byte
+// value columns. The ring scatter writes one VALUE STREAM PER COLUMN next to the shared 16-bit tag stream (a row costs
+// 2 + 8 * nval bytes in the record buffer); region (d, w) lies at [(d * slices + w) * region_cap, + region_count) of every stream,
+// value stream j at out_val + j * stream_stride. The aggregate then runs once per COLUMN over (tags, value stream j) with that
+// column's accumulators only (a sub-plan: its table image is slots x 8-12 bytes, as for one column) and
+// launch_dense_merge_dump_multi folds the columns' images into partial records [key | accumulators of the whole plan].
+// The reference aggregates every (column, aggregation) pair of a call in one pass over the rows
+// (cpp/src/groupby/hash/compute_global_memory_aggs.cuh:139-147); this is the same single pass over the INPUT.
+constexpr int RING_MAX_VALUES = 3;
+struct ring_multi_args {
+  plan_dev plan;         // simple plan: simple_base[0] = the key column, simple_base[1 + j] = value column j
+  dense_map map;
+  int64_t nrows;
+  int32_t nval;          // value streams: 2 or 3
+  int32_t P;             // partitions: a power of two, 16 ... 256 (16 waves x P / 16 owner lanes)
+  int32_t cap;           // records per partition ring: 48 (nval = 2) or 32 (nval = 3); the tag rings hold 128
+  int32_t shift;         // digit = scrambled index >> shift, tag = its low `shift` bits | 1 << 15
+  int32_t slices;
+  uint64_t* out_val;
+  int64_t stream_stride; // records between the value streams
+  uint16_t* out_tag;
+  int64_t region_cap;    // a multiple of 64 records
+  int32_t* region_count;
+  int32_t* overflow;     // bit 0: a region overflowed; bit 2: a key outside the dense range
+};
+void store_args(ring_multi_args const& a, ring_multi_args* d_args, hipStream_t stream);
+void launch_dense_ring_scatter_multi(ring_multi_args const& a, ring_multi_args const* d_args, hipStream_t stream);
+std::size_t dense_ring_multi_lds_bytes(int nval, int P, int cap);
+int dense_ring_multi_cap(int nval);  // ring capacity per partition for nval value streams at 128 partitions
+
+// ---- sparse single 8-byte keys (the hash-table side of the same scatter): launch_hash_ring_scatter writes TWO streams - the
+// key column (stream 0 at out_val) and the value column (stream 1 at out_val + stream_stride) - partitioned on the top bits of the
+// engine's key hash (shift >= 56 for 256 partitions), no tags; `map` and `out_tag` are unused. k_aggregate_k64 (hash_ring_kernels.hip)
+// aggregates a partition in an LDS table whose slot state IS the key word (no state words, one LDS round trip per probe).
+constexpr int HASH_RING_P = 256, HASH_RING_CAP = 32;
+void launch_hash_ring_scatter(ring_multi_args const& a, ring_multi_args const* d_args, hipStream_t stream);
+std::size_t hash_ring_lds_bytes(int nstreams, int P, int cap);
+struct k64_agg_args {
+  plan_dev plan;
+  uint64_t const* rec_key;   // region (d, w) at [(d * slices + w) * region_cap, + region_count[d * slices + w]) of both streams
+  uint64_t const* rec_val;
+  int32_t const* region_count;
+  int64_t region_cap;
+  int32_t slices;
+  int32_t cap;               // table slots (a multiple of 2); slot `cap` is reserved for the key that equals the empty marker
+  int32_t fill_limit;        // groups per table before the item reports overflow (bit 1 of *overflow)
+  uint64_t* out_records;     // item d at [d * (cap + 1) * (1 + NACC) ...], out_count[d] records
+  int32_t* out_count;
+  int32_t* overflow;
+  int32_t nitems;
+};
+int k64_table_slots(plan_dev const& plan, std::size_t lds_bytes);  // slots of a k_aggregate_k64 table in lds_bytes of LDS
+void store_args(k64_agg_args const& a, k64_agg_args* d_args, hipStream_t stream);
+void launch_aggregate_k64(k64_agg_args const& a, k64_agg_args const* d_args, hipStream_t stream);
+
+struct dense_multi_merge_args {
+  plan_dev plan;         // the WHOLE plan (its NACC accumulators in order)
+  dense_map map;
+  int32_t ncols;         // value columns
+  int32_t nsplit;        // images per (partition, column)
+  int32_t slots;
+  int32_t occ_acc;       // accumulator of the whole plan that counts every row (SRC_ONE), or -1: occupancy bitmap of column 0's images
+  uint32_t occ_off0;     // byte offset of that bitmap in an image of column 0
+  uint64_t const* tables[RING_MAX_VALUES];  // column c: [partition][nsplit] images of image_bytes[c]
+  int32_t image_bytes[RING_MAX_VALUES];
+  int8_t acc_col[MAX_ACC];     // accumulator q lives in the images of column acc_col[q] ...
+  int8_t acc_narrow[MAX_ACC];  // ... as a 4-byte count (1) or an 8-byte value (0) ...
+  uint32_t acc_off[MAX_ACC];   // ... at this byte offset
+  uint64_t* out_records;       // work item (d, j): [(d * dsplit + j) * (slots / dsplit) * (1 + NACC) ...]
+  int32_t* out_count;
+  int32_t nitems;              // partitions
+};
+void store_args(dense_multi_merge_args const& a, dense_multi_merge_args* d_args, hipStream_t stream);
+void launch_dense_merge_dump_multi(dense_multi_merge_args const& a, dense_multi_merge_args const* d_args, int dsplit, hipStream_t stream);
+// byte offset of accumulator q / of the occupancy bitmap in the table image of `plan` (dense_kernels.hip make_dense_layout)
+uint32_t dense_acc_offset(plan_dev const& plan, int slots, int q);
+uint32_t dense_occ_offset(plan_dev const& plan, int slots);
+
 // Minimum and maximum of a plain 8-byte integer key column over the strided sample of launch_estimate (signed compare
 // for signed keys): out[0] = min, out[1] = max as bit patterns. `out` must hold {max value, min value} of the ordering before.
 void launch_key_range(plan_dev const* d_plan, int64_t nrows, int64_t sample, int is_signed, uint64_t* out, hipStream_t stream);

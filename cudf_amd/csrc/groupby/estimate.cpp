@@ -32,11 +32,13 @@ aggregate_call::aggregate_call(table_view const& keys, null_policy policy, std::
   ag.fill_limit = static_cast<int32_t>(ag.cap * 0.6);
   CUDF_EXPECTS(ag.cap >= 64, "Aggregation state per group too large for an LDS table.");
   d_overflow = sc.alloc<int32_t>(1);
-  // Dense-key candidate: one plain 8-byte integer key column, one plain 8-byte value column, no ARGMIN / ARGMAX
+  // Dense-key candidate: one plain 8-byte integer key column, one plain 8-byte value column (or two / three of them: one value
+  // stream per column, paths_dense.cpp try_dense_ring_multi), no ARGMIN / ARGMAX
   dense_signed    = p.cols[0].cls == cudf::detail::CLS_SINT;
   // (the dense-key, heavy-hitter and pre-aggregation paths are for big inputs; CUDF_AMD_GB_BIG_MIN_ROWS lets the fuzz tests walk
   // them at sizes a CPU checker can follow)
-  dense_candidate = p.simple && p.KU == 1 && p.NPAY == 1 && p.narg == 0 && n >= env.big_min_rows && env.dense;
+  dense_candidate = p.simple && p.KU == 1 && p.narg == 0 && n >= env.big_min_rows && env.dense &&
+                    (p.NPAY == 1 || (p.NPAY >= 2 && p.NPAY <= RING_MAX_VALUES && env.dense_multi));
   // Composite dense keys: 1-4 integer key columns of any width (rows with a NULL key are dropped: no nullable key under
   // null_policy::INCLUDE), exactly one value column, no ARGMIN / ARGMAX
   dense_composite = !dense_candidate && p.nkeycols <= DENSE_MAX_KEYS && hp.value_cols.size() == 1 && p.narg == 0 &&
@@ -290,6 +292,7 @@ outcome aggregate_call::run_attempt(int attempt)
     o = try_preaggregate(ap);                              // A: sorted / clustered rows
     if (o == outcome::skip) o = try_dense_ring();          // D: dense keys, ring scatter
     if (o == outcome::skip) o = try_dense_wc();            // D: dense keys, write-combining scatter
+    if (o == outcome::skip) o = try_hash_ring(ap);         // P: sparse single 8-byte keys, ring scatter + key-word tables
     if (o == outcome::skip) o = run_partitioned(ap);       // P: radix partition on hash bits
   }
   if (o == outcome::retry_counted && env.debug)

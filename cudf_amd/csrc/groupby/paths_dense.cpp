@@ -85,6 +85,7 @@ outcome aggregate_call::try_dense_ring()
   // (heavy hitters in the sample: only the single-level ring scatter of one plain key takes them out of the partition)
   bool const ring_env = env.dense_ring && !env.chunked;
   if (!(allow_dense && env.forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !env.exact)) return outcome::skip;
+  if (dense_candidate && p.NPAY > 1) return ring_env ? try_dense_ring_multi() : outcome::skip;  // one value stream per column
       dense_map dm{};
       bool dense_ok = dense_map_from_sample(dm);
       int bits = 14;
@@ -125,6 +126,7 @@ outcome aggregate_call::try_dense_ring()
             dense_ring_args ra{};
             ra.plan         = p;
             ra.map          = dm;
+            ra.static_shapes = static_cast<int32_t>(env.static_shapes);
             ra.from_columns = 1;
             ra.nrows        = n;
             ra.P            = static_cast<int32_t>(PD);
@@ -252,12 +254,162 @@ outcome aggregate_call::try_dense_ring()
   return outcome::skip;
 }
 
+// ---- several value columns (dense_multi_kernels.hip): one ring-scatter pass over the input writes one value stream per column
+// next to the shared 16-bit tags; the dense aggregate then runs once per COLUMN over (tags, that column's values) with the
+// column's accumulators only - its table image is as small as for a single column, so the fan-out stays at 128 - and
+// k_dense_merge_dump_multi folds the columns' images into the partial records of the whole plan.
+// Reference: all (column, aggregation) pairs of a call in one pass (compute_global_memory_aggs.cuh:139-147).
+outcome aggregate_call::try_dense_ring_multi()
+{
+  int const nval = p.NPAY;
+  dense_map dm{};
+  if (!dense_map_from_sample(dm)) return outcome::skip;
+  int bits = 14;
+  while (bits < 31 && (uint64_t{1} << bits) < dm.range) ++bits;
+  // ---- per-column sub-plans: the accumulators that read column c; the row counts (no column of their own) go with the column
+  // whose accumulators take the fewest bytes, so that no table grows past the one-column size without need
+  plan_dev sub[RING_MAX_VALUES];
+  dense_multi_merge_args ma{};
+  int acc_bytes[RING_MAX_VALUES] = {0, 0, 0};
+  for (int q = 0; q < p.NACC; ++q)
+    if (p.acc[q].pay >= 0 && p.acc[q].pay < nval) acc_bytes[p.acc[q].pay] += acc_is_narrow(p.acc[q].op, p.acc[q].src) ? 4 : 8;
+  int count_col = 0;
+  for (int c = 1; c < nval; ++c)
+    if (acc_bytes[c] < acc_bytes[count_col]) count_col = c;
+  for (int c = 0; c < nval; ++c) {
+    plan_dev& sp = sub[c];
+    sp           = p;
+    sp.NPAY      = 1;
+    sp.NACC      = 0;
+    sp.unit[1]        = p.unit[1 + c];
+    sp.simple_base[1] = p.simple_base[1 + c];
+    for (int q = 0; q < p.NACC; ++q) {
+      acc_desc const& d = p.acc[q];
+      if (!(d.pay == c || (d.pay < 0 && c == count_col))) continue;
+      acc_desc e = d;
+      if (e.pay >= 0) e.pay = 0;
+      ma.acc_col[q]    = static_cast<int8_t>(c);
+      ma.acc_narrow[q] = acc_is_narrow(d.op, d.src) ? 1 : 0;
+      ma.acc_off[q]    = static_cast<uint32_t>(sp.NACC);  // (its index in the sub-plan for now: the byte offset once the tables are sized)
+      sp.acc[sp.NACC++] = e;
+    }
+    if (sp.NACC == 0) return outcome::skip;  // (a value column without an accumulator of its own: not a plan this path expects)
+  }
+  int const rlog2P = 7;
+  int const slots  = 1 << std::max(bits - rlog2P, 0);
+  std::size_t image[RING_MAX_VALUES];
+  bool fits = true;
+  for (int c = 0; c < nval; ++c) {
+    image[c] = dense_table_bytes(sub[c], slots);
+    fits     = fits && image[c] <= 150 * 1024;
+  }
+  int const cap = dense_ring_multi_cap(nval);
+  int64_t const PD = int64_t{1} << rlog2P, S = 256;
+  bool const ok = fits && dm.range <= (uint64_t{1} << bits) && bits <= 30 && bits - rlog2P >= 6 && bits - rlog2P <= 15 &&
+                  static_cast<double>(dm.range) <= 8.0 * std::max(est_groups, 4096.0) &&
+                  dense_ring_multi_lds_bytes(nval, static_cast<int>(PD), cap) + 64 <= 160 * 1024;
+  if (!ok) return outcome::skip;
+  path        = hash_path::DENSE_DIRECT;
+  dm.mult     = 0x9E3779B1u;  // odd: index -> (index * mult) mod 2^bits is a bijection
+  uint32_t inv = dm.mult;     // Newton: inv = mult^-1 mod 2^32
+  for (int it = 0; it < 5; ++it) inv *= 2u - dm.mult * inv;
+  dm.mult_inv = inv;
+  dm.bits     = bits;
+  dm.log2P    = rlog2P;
+  int const DPU = 1 + p.NACC;
+  // (workgroup w takes the row tiles w, w + S, ...: the busiest workgroup has ceil(tiles / S) of them)
+  int64_t const ring_tile = nval == 2 ? 2 * 1024 : 1024, wg_rows = std::min<int64_t>(n, ((n + ring_tile - 1) / ring_tile + S - 1) / S * ring_tile);
+  double const mean       = static_cast<double>(wg_rows) / static_cast<double>(PD);
+  double const keys_per_p = std::max(1.0, 0.5 * est_groups / static_cast<double>(PD));
+  double const rel_sigma  = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, mean));
+  int64_t const capR      = (static_cast<int64_t>(mean * (1.0 + 6.0 * std::min(rel_sigma, 1.0)) + 64.0) + 63) / 64 * 64;
+  ring_multi_args ra{};
+  ra.plan          = p;
+  ra.map           = dm;
+  ra.nrows         = n;
+  ra.nval          = nval;
+  ra.P             = static_cast<int32_t>(PD);
+  ra.cap           = cap;
+  ra.shift         = bits - rlog2P;
+  ra.slices        = static_cast<int32_t>(S);
+  ra.region_cap    = capR;
+  ra.stream_stride = S * PD * capR;
+  ra.region_count  = sc.alloc<int32_t>(static_cast<size_t>(S * PD));
+  ra.overflow      = d_overflow;
+  ra.out_val       = sc.alloc<uint64_t>(static_cast<size_t>(ra.stream_stride) * nval);
+  ra.out_tag       = sc.alloc<uint16_t>(static_cast<size_t>(ra.stream_stride));
+  ring_multi_args* d_ra = sc.alloc<ring_multi_args>(1);
+  store_args(ra, d_ra, s);
+  launch_dense_ring_scatter_multi(ra, d_ra, s);
+  int32_t const ntables = static_cast<int32_t>(PD);
+  int const dsplit      = 2;  // (merge items: two per partition, 256 workgroups)
+  // (one aggregate launch per column: a partition's regions are shared out to two workgroups so that every launch has 256 of
+  // them - with one per partition half of the CUs idled: 3.45 instead of 1.76 ms per column at 1B rows)
+  int const nsplit      = static_cast<int>(std::clamp<int64_t>(env.dense_nsplit >= 0 ? env.dense_nsplit : 256 / ntables, 1, 16));
+  nitems  = ntables * dsplit;
+  partial = sc.alloc<uint64_t>(static_cast<size_t>(ntables) * slots * DPU);
+  d_count = sc.alloc<int32_t>(nitems);
+  for (int c = 0; c < nval; ++c) {
+    dense_agg_args da{};
+    da.plan         = sub[c];
+    da.map          = dm;
+    da.rec_val      = ra.out_val + static_cast<int64_t>(c) * ra.stream_stride;
+    da.rec_tag      = ra.out_tag;
+    da.region_count = ra.region_count;
+    da.region_cap   = capR;
+    da.slices       = static_cast<int32_t>(S);
+    da.nsplit       = nsplit;
+    da.keep_images  = 1;
+    da.slots        = slots;
+    da.image_bytes  = static_cast<int32_t>(image[c]);
+    da.occ_acc      = dense_occ_acc(sub[c]);
+    da.KU           = 1;
+    da.tables       = sc.alloc<uint64_t>(static_cast<size_t>(ntables) * nsplit * image[c] / 8);
+    da.out_records  = partial;  // (not written: the images are folded by the merge below)
+    da.out_count    = d_count;
+    da.overflow     = d_overflow;
+    da.nitems       = ntables;
+    da.block        = 1024;
+    dense_agg_args* d_da = sc.alloc<dense_agg_args>(1);
+    store_args(da, d_da, s);
+    launch_aggregate_dense(da, d_da, true, true, s);
+    ma.tables[c]      = da.tables;
+    ma.image_bytes[c] = da.image_bytes;
+  }
+  for (int q = 0; q < p.NACC; ++q) ma.acc_off[q] = dense_acc_offset(sub[ma.acc_col[q]], slots, static_cast<int>(ma.acc_off[q]));
+  ma.plan        = p;
+  ma.map         = dm;
+  ma.ncols       = nval;
+  ma.nsplit      = nsplit;
+  ma.slots       = slots;
+  ma.occ_acc     = dense_occ_acc(p);
+  ma.occ_off0    = dense_occ_offset(sub[0], slots);
+  ma.out_records = partial;
+  ma.out_count   = d_count;
+  ma.nitems      = ntables;
+  dense_multi_merge_args* d_ma = sc.alloc<dense_multi_merge_args>(1);
+  store_args(ma, d_ma, s);
+  launch_dense_merge_dump_multi(ma, d_ma, dsplit, s);
+  final_cap          = slots / dsplit;
+  int32_t const h_ov = overflow_and_counts();
+  if (env.debug)
+    fprintf(stderr, "[cudf_amd] dense keys (ring, %d value columns): lo=%lld range=%llu bits=%d P=%ld slots=%d ring cap=%d capR=%ld overflow=%d\n", nval,
+            (long long)dm.lo, (unsigned long long)dm.range, bits, (long)PD, slots, cap, (long)capR, h_ov);
+  if (h_ov == 0) return outcome::done;
+  // a region overflowed (skewed or clustered keys) or a key lay outside the sampled range: redo by hash
+  allow_dense = false;
+  final_cap   = 0;
+  fresh_scratch();
+  return outcome::retry_free;
+}
+
 // ---- write-combining scatter with 16-byte records (CUDF_AMD_GB_DENSE_RING=0, or a geometry the rings do not take), optionally
 // chunk by chunk through the Infinity Cache (CUDF_AMD_GB_CHUNKED=1: profiles/r2_mall_pipeline.txt)
 outcome aggregate_call::try_dense_wc()
 {
   bool const ring_env = env.dense_ring && !env.chunked;
   if (!(allow_dense && env.forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !env.exact)) return outcome::skip;
+  if (dense_candidate && p.NPAY > 1) return outcome::skip;  // (16-byte records carry one value)
       dense_map dm{};
       bool dense_ok = dense_map_from_sample(dm);
       int bits = 14;

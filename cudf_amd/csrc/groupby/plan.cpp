@@ -62,7 +62,9 @@ planner_env planner_env::load()
   e.no_simple         = env_i64("CUDF_AMD_GB_NO_SIMPLE", 0) != 0;
   e.vec16             = env_i64("CUDF_AMD_GB_VEC16", 0) != 0;
   e.trace             = env_i64("CUDF_AMD_GB_TRACE", 0) != 0;
-  e.hash_ring         = env_i64("CUDF_AMD_GB_HASH_RING", 1) != 0;
+  // (off by default: measured SLOWER than the write-combining scatter + tagged tables - profiles/r3_sparse_ring.txt)
+  e.hash_ring         = env_i64("CUDF_AMD_GB_HASH_RING", 0) != 0;
+  e.static_shapes     = env_i64("CUDF_AMD_GB_STATIC_SHAPES", 2);
   return e;
 }
 

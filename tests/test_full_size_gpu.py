@@ -58,6 +58,43 @@ def test_c2_full_size_hash_tables(gpu, monkeypatch):
     _c2(monkeypatch, dense=False)
 
 
+@pytest.mark.parametrize("nval", [2, 3])
+def test_c2_full_size_several_value_columns(gpu, nval):
+    """C2's rows with two / three float64 value columns ({a: SUM + COUNT, b: SUM, c: SUM}) on the dense path: one value stream per
+    column through the ring scatter. Per-group torch reference as for C2."""
+    import torch
+    import cudf_amd
+    from cudf_amd import aggregation as agg, groupby as gb
+    from cudf_amd.types import NullPolicy
+    dev = torch.device("cuda", 0)
+    n, groups = 1_000_000_000, 1_000_000
+    g = torch.Generator(device=dev).manual_seed(42)
+    k = torch.randint(0, groups, (n,), generator=g, device=dev, dtype=torch.int64)
+    vals = []
+    for j in range(nval):
+        g.manual_seed(43 + j)
+        vals.append(torch.rand(n, generator=g, device=dev, dtype=torch.float64))
+    reqs = [gb.GroupByRequest(cudf_amd.Column.from_torch(vals[0]), [agg.sum(), agg.count(NullPolicy.EXCLUDE)])]
+    reqs += [gb.GroupByRequest(cudf_amd.Column.from_torch(v), [agg.sum()]) for v in vals[1:]]
+    grp = gb.GroupBy(cudf_amd.Table([cudf_amd.Column.from_torch(k)]))
+    uk, res = grp.aggregate(reqs, stream=torch.cuda.current_stream())
+    assert grp.last_path.name == "DENSE_DIRECT"
+    keys = uk.columns()[0].to_torch()
+    exp_c = torch.bincount(k, minlength=groups)
+    present = exp_c > 0
+    assert keys.numel() == int(present.sum())
+    assert bool((torch.sort(keys).values == torch.nonzero(present).flatten()).all())
+    assert bool((res[0].columns()[1].to_torch().to(torch.int64) == exp_c[keys]).all())
+    m = float(exp_c.max())
+    for j in range(nval):
+        s = res[j].columns()[0].to_torch()
+        exp_s = torch.zeros(groups, dtype=torch.float64, device=dev).scatter_add_(0, k, vals[j])
+        assert float((s - exp_s[keys]).abs().max()) <= m * m * np.finfo(np.float64).eps, f"column {j}"
+        del s, exp_s
+    del k, vals, keys, uk, res, exp_c
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("sparse", [False, True])
 def test_c3_full_size(gpu, sparse):
     import torch

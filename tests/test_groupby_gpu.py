@@ -273,9 +273,13 @@ def test_narrow_key_nullable_value_partitioned(G, oracle, kt, vt):
                           expect_path="PARTITIONED_LDS")
 
 
-def test_optimistic_partition_and_its_fallback(G, oracle):
-    """n >= 4M rows takes the optimistic single-pass partition (no histogram pass). Uniform keys must stay on it;
-    a heavy-hitter key overflows its fixed-capacity region and must be repaired by the exact pipeline."""
+@pytest.mark.parametrize("hash_ring", ["1", "0"])
+def test_optimistic_partition_and_its_fallback(G, oracle, monkeypatch, hash_ring):
+    """n >= 4M rows takes the optimistic single-pass partition (no histogram pass): through the ring scatter + key-word tables
+    (one plain 8-byte key, one plain 8-byte value) or - CUDF_AMD_GB_HASH_RING=0 - through the write-combining scatter + tagged
+    tables. Uniform keys must stay on it; a heavy-hitter key overflows its fixed-capacity region and must be repaired by the
+    exact pipeline."""
+    monkeypatch.setenv("CUDF_AMD_GB_HASH_RING", hash_ring)
     rng = np.random.default_rng(17)
     n = 5_000_000
     k = rng.integers(0, 200_000, n, dtype=np.int64)
@@ -284,6 +288,46 @@ def test_optimistic_partition_and_its_fallback(G, oracle):
     k2 = k.copy()
     k2[rng.random(n) < 0.5] = 7  # half of all rows carry one key
     _check_against_oracle(G, oracle, [k2], [(v, ["sum", "count_all", "max"])], expect_path="PARTITIONED_LDS")
+
+
+@pytest.mark.parametrize("groups,vt,kinds", [(900_000, "float64", ["sum", "count_valid"]), (1_100_000, "int64", ["sum", "count_all", "mean"]),
+                                             (40_000, "float64", ["min", "max", "mean"]), (300_000, "float64", ["sum_of_squares", "product", "count_valid", "max", "sum"]),
+                                             (5_000, "uint64", ["sum"])])
+def test_sparse_keys_ring_scatter_and_key_word_tables(G, oracle, monkeypatch, groups, vt, kinds):
+    """Sparse int64 keys (no small range: never the direct-address tables), one plain 8-byte value column, n >= 4M: the ring scatter
+    writes a key stream and a value stream into 256 hash partitions and k_aggregate_k64 aggregates each in an LDS table whose slot
+    state is the key word (hash_ring_kernels.hip). The keys include the table's empty marker and 0 / -1 / INT64_MIN / INT64_MAX.
+    Same call with CUDF_AMD_GB_HASH_RING=0 (tagged tables behind the write-combining scatter) must agree."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    monkeypatch.setenv("CUDF_AMD_GB_HASH_RING", "1")  # (off by default: measured slower than the tagged tables, profiles/r3_sparse_ring.txt)
+    rng = np.random.default_rng(groups)
+    n = 4_400_000
+    pool = rng.integers(-2**62, 2**62, groups, dtype=np.int64)
+    pool[:6] = [0, -1, np.iinfo(np.int64).min, np.iinfo(np.int64).max, np.int64(np.uint64(0x9e3779b97f4a7c15).astype(np.int64)), 1]
+    k = pool[rng.integers(0, groups, n)]
+    npt = NP_OF_TYPE_ID[TYPE_ID[vt]]
+    v = (rng.random(n) * 2 - 1).astype(npt) if vt == "float64" else rng.integers(0, 1000, n).astype(npt)
+    if "product" in kinds:
+        v = np.where(rng.random(n) < 0.999, 1.0, 1.0 + 2.0 ** -20)
+    _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), kinds)], expect_path="PARTITIONED_LDS")
+    assert G.last_path.name == "PARTITIONED_LDS"
+    monkeypatch.setenv("CUDF_AMD_GB_HASH_RING", "0")
+    _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), kinds)], expect_path="PARTITIONED_LDS")
+
+
+def test_sparse_keys_ring_scatter_overflows_fall_back(G, oracle, monkeypatch):
+    """The sparse-key ring path rules itself out and the partition pipeline repairs the call: a skewed sample that hides most of
+    the groups (the key-word tables overflow), and keys clustered in the row order (a region overflows)."""
+    monkeypatch.setenv("CUDF_AMD_GB_HASH_RING", "1")
+    rng = np.random.default_rng(909)
+    n = 4_500_000
+    # 95 % of the rows on 2000 keys, the rest on 1.5M more: the sample estimates far too few groups
+    k = np.where(rng.random(n) < 0.95, rng.integers(0, 2000, n), rng.integers(0, 1_500_000, n)).astype(np.int64) * 1_000_003
+    v = rng.random(n)
+    _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_valid"])], expect_path="PARTITIONED_LDS")
+    # runs of 300 equal keys: whole keys land in one workgroup's tile
+    k2 = (np.arange(n, dtype=np.int64) // 300 % 120_000) * 1_000_003
+    _check_against_oracle(G, oracle, [k2], [(v, ["sum", "max"])], expect_path="PARTITIONED_LDS")
 
 
 @pytest.mark.parametrize("ring", ["1", "0"])
@@ -539,14 +583,19 @@ def test_fuzz_against_oracle(G, oracle, seed, monkeypatch):
         monkeypatch.setenv("CUDF_AMD_GB_LDS_KB", os.environ["CUDF_AMD_FUZZ_LDS_KB"])
     # (half of the big-path seeds keep to what the dense tables take: integer keys, one value column, no ARGMIN / ARGMAX, EXCLUDE)
     dense_shape = big_paths and seed % 6 == 1
-    nkeys = int(rng.integers(1, 3)) if dense_shape else int(rng.integers(1, 4))
+    # (and half of THOSE draw 2-3 plain 8-byte value columns behind one plain 8-byte integer key: one value stream per column)
+    dense_multi = dense_shape and seed % 12 == 1
+    nkeys = 1 if dense_multi else (int(rng.integers(1, 3)) if dense_shape else int(rng.integers(1, 4)))
     spread = int(rng.choice([40, 3000, 60_000])) if big_paths else int(rng.choice([3, 40, 3000]))
     key_types = [t for t in _FUZZ_KEY_TYPES if not dense_shape or t.startswith(("int", "uint"))]
-    keys = [column(str(rng.choice(key_types)), spread, bool(rng.random() < 0.4), int(rng.choice([0, 0, 5]))) for _ in range(nkeys)]
+    if dense_multi:
+        keys = [column(str(rng.choice(["int64", "uint64"])), spread, False, 0)]
+    else:
+        keys = [column(str(rng.choice(key_types)), spread, bool(rng.random() < 0.4), int(rng.choice([0, 0, 5]))) for _ in range(nkeys)]
     requests = []
-    for _ in range(1 if dense_shape else int(rng.integers(1, 3))):
-        vt = str(rng.choice(_FUZZ_VAL_TYPES))
-        vals = column(vt, 9, bool(rng.random() < 0.5), int(rng.choice([0, 0, 3])))
+    for _ in range(int(rng.integers(2, 4)) if dense_multi else (int(rng.integers(1, 4)) if dense_shape else int(rng.integers(1, 3)))):
+        vt = str(rng.choice(["int64", "uint64", "float64"] if dense_multi else _FUZZ_VAL_TYPES))
+        vals = column(vt, 9, False, 0) if dense_multi else column(vt, 9, bool(rng.random() < 0.5), int(rng.choice([0, 0, 3])))
         aggs = [a for a in _FUZZ_AGGS if not dense_shape or not a.startswith("arg")]
         kinds = [str(k) for k in rng.choice(aggs, size=int(rng.integers(1, 5)), replace=False)]
         requests.append((vals, kinds))
@@ -628,6 +677,48 @@ def test_two_value_columns_at_1024_partitions(G, oracle):
     vals = [rng.random(n), rng.integers(-100, 100, n, dtype=np.int64), rng.random(n)]
     _check_against_oracle(G, oracle, [k], [(vals[0], ["sum", "mean"]), (vals[1], ["sum", "mean"])], expect_path="PARTITIONED_LDS")
     _check_against_oracle(G, oracle, [k], [(vals[0], ["sum"]), (vals[1], ["max", "count_valid"]), (vals[2], ["min"])], expect_path="PARTITIONED_LDS")
+
+
+@pytest.mark.parametrize("groups", [700, 6_000, 250_000, 1_000_000])
+@pytest.mark.parametrize("plan", ["sum_count_sum", "two_sums", "three_means", "mixed_types", "minmax_var"])
+def test_dense_keys_several_value_columns(G, oracle, monkeypatch, plan, groups):
+    """One plain int64 key column spanning a small range and TWO or THREE plain 8-byte value columns, n >= 4M: the dense path carries
+    one value stream per column (ring scatter: dense_multi_kernels.hip; few groups: one direct-address table per workgroup with
+    every column's accumulators) instead of falling to 24- / 32-byte hash records. The same call with CUDF_AMD_GB_DENSE_MULTI=0
+    must take the hash tables and agree."""
+    rng = np.random.default_rng(500 + groups % 97)
+    n = 4_300_000
+    k = rng.integers(0, groups, n, dtype=np.int64) - 77_000
+    a, b, c = rng.random(n), rng.random(n) * 3.0 - 1.0, rng.integers(-1000, 1000, n, dtype=np.int64)
+    u = rng.integers(0, 1 << 40, n, dtype=np.uint64)
+    requests = {"sum_count_sum": [(a, ["sum", "count_valid"]), (b, ["sum"])],
+                "two_sums": [(a, ["sum"]), (b, ["sum"])],
+                "three_means": [(a, ["mean"]), (b, ["mean"]), (c, ["mean", "sum"])],
+                "mixed_types": [(c, ["sum", "min"]), (u, ["max", "count_all"]), (a, ["sum", "max"])],
+                "minmax_var": [(a, ["min", "max", "sum_of_squares"]), (b, ["mean", "count_all", "max"])]}[plan]
+    # (three 8-byte accumulators of ONE column over 8192 slots do not fit a table: that plan keeps the hash tables at 1M groups)
+    too_wide = plan == "minmax_var" and groups >= 1_000_000
+    _check_against_oracle(G, oracle, [k], requests, expect_path=None if too_wide else "DENSE_DIRECT")
+    assert too_wide or G.last_path.name == "DENSE_DIRECT"
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE_MULTI", "0")
+    _check_against_oracle(G, oracle, [k], requests)
+    assert G.last_path.name != "DENSE_DIRECT"
+
+
+def test_dense_keys_several_value_columns_fall_back(G, oracle):
+    """Two value columns on the dense path: a key outside the sampled range voids the ring attempt (the call is redone by hash);
+    rows sorted by key take the local pre-aggregation; a repeated value column is ONE column (the single-column dense path)."""
+    rng = np.random.default_rng(577)
+    n = 4_300_000
+    k = rng.integers(0, 400_000, n, dtype=np.int64)
+    a, b = rng.random(n), rng.random(n)
+    k2 = k.copy()
+    k2[n // 3 + 777] = 10**13
+    _check_against_oracle(G, oracle, [k2], [(a, ["sum", "count_valid"]), (b, ["sum"])])
+    assert G.last_path.name == "PARTITIONED_LDS"
+    ks = np.sort(k)
+    _check_against_oracle(G, oracle, [ks], [(a, ["sum", "count_valid"]), (b, ["sum", "max"])])
+    _check_against_oracle(G, oracle, [k], [(a, ["sum"]), (a, ["count_valid", "max"])], expect_path="DENSE_DIRECT")
 
 
 @pytest.mark.parametrize("shape", ["plain", "int32_key_nullable_value", "two_keys", "sorted", "one_hot_key", "outlier"])
