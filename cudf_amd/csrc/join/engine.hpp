@@ -68,8 +68,9 @@ struct join_args {
   // probe rows are rows [probe_row_base, ...) of a larger left table (partitioned_*_join): added to emitted indices
   int64_t probe_row_base;
   // Dense build keys (one 8-byte integer key column whose valid values span a small range; NULLs never match): a
-  // direct-address table instead of the hash table. dense_head[key - dense_lo] = the LAST build row with that key (-1: none),
-  // dense_next[row] = the previous build row with the same key (-1: none): equal keys form a chain through dense_next.
+  // direct-address table instead of the hash table. Unique build keys (dense_has_dups == 0): dense_head[key - dense_lo] = the build
+  // row with that key (-1: none). Some key repeats (dense_has_dups == 1): dense_head[i] .. dense_head[i + 1] bound key i's list of
+  // build rows in dense_next (launch_dense_csr). During the build, dense_next[row] = the previous build row with the same key.
   // A probe is one range test (keys outside [lo, lo + range) touch no memory at all) and one 4-byte load; no hash, no tag, no
   // key comparison. The reference probes cuco::static_multiset for every row (retrieve_impl.cuh:29-133).
   int32_t* dense_head;
@@ -78,7 +79,15 @@ struct join_args {
   uint64_t dense_range;
   int32_t dense_has_dups;  // some key occurs more than once on the build side (chains longer than one)
   int32_t* dense_dups;     // build only: device flag behind dense_has_dups
+  // Hot build keys (row lists of more than BIG_LIST rows): the retrieve pass only RESERVES the output range of such a probe row in
+  // its workgroup's share and appends {probe row, first list entry, entries, output position} to this work list; k_dense_big_emit
+  // then writes those pairs with the WHOLE grid (1000 probes of a key with 100,000 build rows that sat in one workgroup's chunk
+  // of probe rows kept that one workgroup busy for 120 ms). big_count[0] = entries appended (may exceed BIG_LIST_CAP: the rows
+  // beyond it were emitted by their own wave).
+  uint32_t* big_list;      // BIG_LIST_CAP x 4 words
+  uint32_t* big_count;
 };
+constexpr uint32_t BIG_LIST = 1024, BIG_LIST_CAP = 1u << 16;
 constexpr uint32_t MATCH_NONE  = 0xffffffffu;
 constexpr uint32_t MATCH_MULTI = 0x80000000u;
 
@@ -88,12 +97,22 @@ void launch_build(join_args const& a, join_args* d_args, hipStream_t stream);
 void launch_key_minmax(join_args const& a, join_args* d_args, int is_signed, uint64_t* out, hipStream_t stream);
 // fills dense_head / dense_next (dense_head preset to -1); sets *dense_dups when a key repeats
 void launch_dense_build(join_args const& a, join_args* d_args, hipStream_t stream);
+// Some build key repeats: ROW LISTS instead of chains. dense_head (dense_csr_entries(range) zeroed words) becomes the exclusive
+// prefix of the keys' row counts - key i's build rows are dense_next[dense_head[i], dense_head[i + 1]) - so that a probe row
+// learns its match count from two adjacent words and a hot key's pairs are emitted 64 at a time by the whole wave (a chain had
+// to be walked link by link by one lane: 149 ms for 1000 probes of a key with 100,000 build rows). cursor: `range` zeroed words
+// (scratch), tile_sums: dense_csr_entries(range) / 8192 words (scratch).
+// Reference: cuco::static_multiset keeps duplicates as separate entries along the probe sequence (hash_join.cu:62-99).
+std::size_t dense_csr_entries(uint64_t range);
+void launch_dense_csr(join_args const& a, join_args* d_args, int32_t* cursor, uint32_t* tile_sums, hipStream_t stream);
 // probe-side radix partition (write-combining scatter, common/wc_scatter.hpp) into a.precs / a.region_count
 void launch_probe_partition(join_args const& a, join_args* d_args, hipStream_t stream);
 void launch_count(join_args const& a, join_args* d_args, hipStream_t stream);
 // exclusive scan of block_counts in place (block_counts[nblocks] = total pairs)
 void launch_scan(join_args const& a, hipStream_t stream);
 void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream);
+// after launch_retrieve with a.big_list != nullptr: the pairs of the work list, by the whole grid
+void launch_dense_big_emit(join_args const& a, join_args* d_args, hipStream_t stream);
 // full join: appends (JoinNoMatch, r) for every build row with build_matched[r] == 0
 void launch_complement(join_args const& a, join_args* d_args, hipStream_t stream);
 // finalize_partitioned_full_join: build_matched[r] = 1 for every r != JoinNoMatch in right_indices[0..n)

@@ -136,6 +136,16 @@ class hash_join_impl {
         CUDF_HIP_TRY(hipMemcpyAsync(&h_dups, dups.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
         CUDF_HIP_TRY(hipStreamSynchronize(s));
         _dense_has_dups = h_dups != 0;
+        if (_dense_has_dups) {  // row lists instead of chains (engine.hpp launch_dense_csr)
+          std::size_t const entries = join::dense_csr_entries(_dense_range);
+          _dense_head = rmm::device_buffer{entries * sizeof(int32_t), s, mr};
+          CUDF_HIP_TRY(hipMemsetAsync(_dense_head.data(), 0, _dense_head.size(), s));
+          rmm::device_buffer cursor{_dense_range * sizeof(int32_t), s, tmp}, sums{entries / 8192 * sizeof(uint32_t) + 16, s, tmp};
+          CUDF_HIP_TRY(hipMemsetAsync(cursor.data(), 0, cursor.size(), s));
+          join_args c = base_args(right, 0);
+          join::launch_dense_csr(c, static_cast<join_args*>(d_args.data()), static_cast<int32_t*>(cursor.data()), static_cast<uint32_t*>(sums.data()), s);
+          CUDF_HIP_TRY(hipStreamSynchronize(s));
+        }
         return;
       }
     }
@@ -340,7 +350,15 @@ class hash_join_impl {
       CUDF_HIP_TRY(hipMemsetAsync(matched.data(), 0, matched.size(), s));
       a.build_matched = static_cast<uint8_t*>(matched.data());
     }
+    rmm::device_buffer big{};
+    if (_dense && _dense_has_dups) {  // work list for probe rows that hit a hot build key (engine.hpp join_args::big_list)
+      big = rmm::device_buffer{(5 * static_cast<std::size_t>(join::BIG_LIST_CAP) + 4) * sizeof(uint32_t), s, cudf::get_current_device_resource_ref()};
+      a.big_list  = static_cast<uint32_t*>(big.data());
+      a.big_count = a.big_list + 5 * static_cast<std::size_t>(join::BIG_LIST_CAP);
+      CUDF_HIP_TRY(hipMemsetAsync(a.big_count, 0, sizeof(uint32_t), s));
+    }
     join::launch_retrieve(a, static_cast<join_args*>(d_args.data()), s);
+    if (a.big_list != nullptr) join::launch_dense_big_emit(a, static_cast<join_args*>(d_args.data()), s);
     if (kind == join_kind::FULL_JOIN) {
       rmm::device_buffer d_args2{sizeof(join_args), s, cudf::get_current_device_resource_ref()};
       join::launch_complement(a, static_cast<join_args*>(d_args2.data()), s);

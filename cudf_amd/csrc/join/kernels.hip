@@ -574,14 +574,17 @@ __global__ void __launch_bounds__(256) k_dense_count(join_args const* __restrict
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) head[k] = in[k] ? gload(a.dense_head + idx[k]) : -1;
+    // (some build key repeats: dense_head holds the OFFSETS of the keys' row lists - engine.hpp - and a key's row count is the
+    // difference to its neighbour; a chain walk per probe row took 149 ms for 1000 probes of a key with 100,000 build rows)
+    int32_t next_off[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) next_off[k] = (dups && in[k]) ? gload(a.dense_head + idx[k] + 1) : 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       if (!live[k]) continue;
-      unsigned int cnt = head[k] >= 0 ? 1u : 0u;
-      if (dups && cnt) {  // the rest of the key's chain
-        for (int32_t r = gload(a.dense_next + head[k]); r >= 0; r = gload(a.dense_next + r)) ++cnt;
-      }
-      gstore(a.match_cache + j[k], cnt == 0 ? MATCH_NONE : (static_cast<uint32_t>(head[k]) | (cnt > 1 ? MATCH_MULTI : 0u)));
+      unsigned int const cnt = dups ? (in[k] ? static_cast<unsigned int>(next_off[k] - head[k]) : 0u) : (head[k] >= 0 ? 1u : 0u);
+      uint32_t const what    = dups ? static_cast<uint32_t>(idx[k]) : static_cast<uint32_t>(head[k]);  // the key's list / its one build row
+      gstore(a.match_cache + j[k], cnt == 0 ? MATCH_NONE : (what | (cnt > 1 ? MATCH_MULTI : 0u)));
       unsigned int const emitted = (cnt == 0 && kind != 0) ? 1u : cnt;
       if (a.row_counts != nullptr) gstore(a.row_counts + j[k], static_cast<size_type>(emitted));
       local_count += emitted;
@@ -621,6 +624,7 @@ __global__ void __launch_bounds__(256) k_dense_retrieve(join_args const* __restr
     }
   };
   int64_t const begin = static_cast<int64_t>(blockIdx.x) * a.chunk, end = min(n, begin + a.chunk);
+  bool const dups = a.dense_has_dups != 0;
   for (int64_t j0 = begin; j0 < end; j0 += blockDim.x) {
     int64_t const j  = j0 + threadIdx.x;
     bool const live  = j < end;
@@ -629,17 +633,213 @@ __global__ void __launch_bounds__(256) k_dense_retrieve(join_args const* __restr
     bool const multi = !none && (c & MATCH_MULTI);
     size_type const prow = static_cast<size_type>(j + a.probe_row_base);
     int32_t r = static_cast<int32_t>(c & ~MATCH_MULTI);
-    emit(live && !none, prow, r);  // the head of the chain (the only match of most rows)
+    if (!dups) {  // unique build keys: the cache holds the one build row
+      emit(live && !none, prow, r);
+      if (kind != 0) emit(live && none, prow, JoinNoMatch);
+      continue;
+    }
+    // Row lists (some build key repeats): the cache holds the key's index; its rows are dense_next[off, off + cnt).
+    uint32_t const off = none ? 0u : static_cast<uint32_t>(gload(a.dense_head + r));
+    uint32_t const cnt = none ? 0u : (multi ? static_cast<uint32_t>(gload(a.dense_head + r + 1)) - off : 1u);
+    emit(live && !none, prow, none ? JoinNoMatch : gload(a.dense_next + off));
     if (kind != 0) emit(live && none, prow, JoinNoMatch);
-    bool walking = multi;
-    while (__any(walking)) {
-      if (walking) {
-        r       = gload(a.dense_next + r);
-        walking = r >= 0;
+    // very long lists (a hot build key): only the output range is reserved here, the pairs are written by the whole grid
+    // (k_dense_big_emit) - the rows that hit a hot key may all sit in ONE workgroup's chunk of probe rows
+    bool huge = a.big_list != nullptr && cnt > BIG_LIST;
+    if (huge) {
+      uint32_t const w = atomicAdd(a.big_count, 1u);
+      if (w < BIG_LIST_CAP) {
+        unsigned long long const base = atomicAdd(&s_cursor, static_cast<unsigned long long>(cnt - 1));
+        gstore(reinterpret_cast<u32x4*>(a.big_list) + w, u32x4{static_cast<uint32_t>(prow), off + 1u, cnt - 1u, static_cast<uint32_t>(base)});
+        gstore(a.big_list + 4u * BIG_LIST_CAP + w, static_cast<uint32_t>(base >> 32));
+      } else {
+        huge = false;  // (the list is full: this wave emits the row's pairs itself)
       }
-      emit(walking, prow, r);
+    }
+    // short lists: every lane walks its own; long lists: the WAVE emits 64 pairs per step, coalesced
+    bool const big = cnt > 64 && !huge;
+    uint32_t t     = 1;
+    bool walking   = cnt > 1 && !big && !huge;
+    while (__any(walking)) {
+      int32_t const br = walking ? gload(a.dense_next + off + t) : JoinNoMatch;
+      emit(walking, prow, br);
+      ++t;
+      walking = walking && t < cnt;
+    }
+    unsigned long long bigm = __ballot(big);
+    while (bigm != 0) {
+      int const src = __ffsll(static_cast<long long>(bigm)) - 1;
+      bigm &= bigm - 1;
+      uint32_t const boff = __shfl(off, src), bcnt = __shfl(cnt, src);
+      size_type const bp  = __shfl(prow, src);
+      for (uint32_t base = 1; base < bcnt; base += 64) {
+        uint32_t const tt = base + static_cast<uint32_t>(lane);
+        bool const w      = tt < bcnt;
+        emit(w, bp, w ? gload(a.dense_next + boff + tt) : JoinNoMatch);
+      }
     }
   }
+}
+
+// The pairs of the work list of hot-key probe rows (join_args::big_list): every workgroup takes its share of every entry's chunks.
+__global__ void __launch_bounds__(256) k_dense_big_emit(join_args const* __restrict__ ap)
+{
+  join_args const& a   = *ap;
+  uint32_t const items = min(gload(a.big_count), BIG_LIST_CAP);
+  constexpr uint32_t CH = 2048;  // pairs per chunk
+  for (uint32_t it = 0; it < items; ++it) {
+    u32x4 const e   = gload(reinterpret_cast<u32x4 const*>(a.big_list) + it);
+    uint64_t const base = (static_cast<uint64_t>(gload(a.big_list + 4u * BIG_LIST_CAP + it)) << 32) | e.w;
+    uint32_t const chunks = (e.z + CH - 1) / CH;
+    for (uint32_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+      for (uint32_t t = c * CH + threadIdx.x; t < min(e.z, (c + 1) * CH); t += blockDim.x) {
+        int32_t const br = gload(a.dense_next + e.y + t);
+        uint64_t const o = base + t;
+        if (o < a.out_capacity) {
+          gstore(a.out_probe + o, static_cast<size_type>(e.x));
+          gstore(a.out_build + o, br);
+        }
+        if (a.kind == 2) gstore(a.build_matched + br, uint8_t{1});
+      }
+    }
+  }
+}
+
+// ---- row lists for duplicated dense build keys: counts (k_dense_csr_count) -> exclusive scan in place (k_scan_u32_*) -> lists
+// (k_dense_csr_fill). dense_head: [padded range + 1] counts, then offsets; dense_next: the build rows grouped by key.
+__global__ void __launch_bounds__(256) k_dense_csr_count(join_args const* __restrict__ ap)
+{
+  join_args const& a   = *ap;
+  int64_t const n      = a.build.nrows;
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint64_t const* keys = static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset;
+  bool const masked    = a.check_nulls && a.build.col[0].mask != nullptr;
+  int const lane = threadIdx.x & 63;
+  int64_t const rounds = (n + stride - 1) / stride;
+  int64_t i            = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  for (int64_t it = 0; it < rounds; ++it, i += stride) {  // (every lane runs every round: the ballots below are wave-wide)
+    bool pending       = i < n && !(masked && !col_is_valid(a.build.col[0], i));
+    uint64_t const idx = pending ? gload(keys + i) - a.dense_lo : 0;
+    // same-address global atomics serialise (a build key with 100,000 rows): the first keys of the wave are counted once per
+    // key, by one lane
+    for (int round = 0; round < 2; ++round) {
+      unsigned long long const todo = __ballot(pending);
+      if (todo == 0) break;
+      int const lead                = __ffsll(static_cast<long long>(todo)) - 1;
+      uint64_t const lidx           = __shfl(static_cast<unsigned long long>(idx), lead);
+      unsigned long long const same = __ballot(pending && idx == lidx);
+      if (lane == lead) atomicAdd(a.dense_head + lidx, __popcll(same));
+      if (idx == lidx) pending = false;
+    }
+    if (pending) atomicAdd(a.dense_head + idx, 1);
+  }
+}
+__global__ void __launch_bounds__(256) k_dense_csr_fill(join_args const* __restrict__ ap, int32_t* cursor)
+{
+  join_args const& a   = *ap;
+  int64_t const n      = a.build.nrows;
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  uint64_t const* keys = static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset;
+  bool const masked    = a.check_nulls && a.build.col[0].mask != nullptr;
+  int const lane = threadIdx.x & 63;
+  int64_t const rounds = (n + stride - 1) / stride;
+  int64_t i            = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  for (int64_t it = 0; it < rounds; ++it, i += stride) {
+    bool const valid   = i < n && !(masked && !col_is_valid(a.build.col[0], i));
+    bool pending       = valid;
+    uint64_t const idx = valid ? gload(keys + i) - a.dense_lo : 0;
+    int32_t pos        = 0;
+    for (int round = 0; round < 2; ++round) {  // (wave-aggregated as in k_dense_csr_count: one atomic per key, ranks by popcount)
+      unsigned long long const todo = __ballot(pending);
+      if (todo == 0) break;
+      int const lead                = __ffsll(static_cast<long long>(todo)) - 1;
+      uint64_t const lidx           = __shfl(static_cast<unsigned long long>(idx), lead);
+      unsigned long long const same = __ballot(pending && idx == lidx);
+      int32_t base                  = 0;
+      if (lane == lead) base = atomicAdd(cursor + lidx, __popcll(same));
+      base = __shfl(base, lead);
+      if (pending && idx == lidx) {
+        pos     = base + __popcll(same & ((1ull << lane) - 1));
+        pending = false;
+      }
+    }
+    if (pending) pos = atomicAdd(cursor + idx, 1);
+    if (valid) gstore(a.dense_next + gload(a.dense_head + idx) + pos, static_cast<int32_t>(i));
+  }
+}
+// Exclusive scan of n uint32 (n a multiple of SCAN_TILE, at most 2^29 + SCAN_TILE) in place, three launches: tile sums, scan of the
+// tile sums by one workgroup, tile-local scan + tile offset.
+constexpr int SCAN_TILE = 1024 * 8;
+__global__ void __launch_bounds__(1024) k_scan_u32_sums(uint32_t const* __restrict__ v, uint32_t* __restrict__ sums)
+{
+  __shared__ uint32_t s_w[16];
+  u32x4 const* p = reinterpret_cast<u32x4 const*>(v + static_cast<int64_t>(blockIdx.x) * SCAN_TILE) + threadIdx.x * 2;
+  u32x4 const a = gload(p), b = gload(p + 1);
+  uint32_t t    = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < 16; ++w) tot += s_w[w];
+    sums[blockIdx.x] = tot;
+  }
+}
+__global__ void __launch_bounds__(1024) k_scan_u32_tiles(uint32_t* sums, int32_t ntiles)
+{
+  __shared__ uint32_t s_w[16];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < ntiles; base += 1024) {
+    int const i      = base + threadIdx.x;
+    uint32_t const x = i < ntiles ? sums[i] : 0;
+    uint32_t inc     = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t const t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += s_w[w];
+    uint32_t const carry = s_carry;
+    if (i < ntiles) sums[i] = carry + woff + inc - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(1024) k_scan_u32_apply(uint32_t* __restrict__ v, uint32_t const* __restrict__ sums)
+{
+  __shared__ uint32_t s_w[16];
+  u32x4* p = reinterpret_cast<u32x4*>(v + static_cast<int64_t>(blockIdx.x) * SCAN_TILE) + threadIdx.x * 2;
+  u32x4 a = gload(p), b = gload(p + 1);
+  uint32_t const mine = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t const t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint32_t run = gload(sums + blockIdx.x) + inc - mine;
+  for (int w = 0; w < wave; ++w) run += s_w[w];
+  u32x4 oa, ob;
+  oa.x = run; run += a.x;
+  oa.y = run; run += a.y;
+  oa.z = run; run += a.z;
+  oa.w = run; run += a.w;
+  ob.x = run; run += b.x;
+  ob.y = run; run += b.y;
+  ob.z = run; run += b.z;
+  ob.w = run;
+  gstore(p, oa);
+  gstore(p + 1, ob);
 }
 
 // exclusive scan of the per-block pair counts (nblocks <= 65536): one workgroup
@@ -755,6 +955,20 @@ void launch_dense_build(join_args const& a, join_args* d_args, hipStream_t strea
   hipLaunchKernelGGL(k_dense_build, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
+std::size_t dense_csr_entries(uint64_t range) { return static_cast<std::size_t>((range + 1 + SCAN_TILE - 1) / SCAN_TILE) * SCAN_TILE; }
+void launch_dense_csr(join_args const& a, join_args* d_args, int32_t* cursor, uint32_t* tile_sums, hipStream_t stream)
+{
+  // a.dense_head: dense_csr_entries(range) zeroed words; cursor: `range` zeroed words; tile_sums: entries / SCAN_TILE words
+  hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_build", stream};
+  int32_t const ntiles = static_cast<int32_t>(dense_csr_entries(a.dense_range) / SCAN_TILE);
+  hipLaunchKernelGGL(k_dense_csr_count, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args);
+  hipLaunchKernelGGL(k_scan_u32_sums, dim3(ntiles), dim3(1024), 0, stream, reinterpret_cast<uint32_t const*>(a.dense_head), tile_sums);
+  hipLaunchKernelGGL(k_scan_u32_tiles, dim3(1), dim3(1024), 0, stream, tile_sums, ntiles);
+  hipLaunchKernelGGL(k_scan_u32_apply, dim3(ntiles), dim3(1024), 0, stream, reinterpret_cast<uint32_t*>(a.dense_head), tile_sums);
+  hipLaunchKernelGGL(k_dense_csr_fill, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args, cursor);
+  CUDF_HIP_TRY(hipGetLastError());
+}
 void launch_probe_partition(join_args const& a, join_args* d_args, hipStream_t stream)
 {
   hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
@@ -798,6 +1012,13 @@ void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream)
   else if (a.single64 && a.slot_words == 2) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64_INLINE, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else if (a.single64) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   else hipLaunchKernelGGL((k_probe_retrieve<MODE_GENERIC, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+void launch_dense_big_emit(join_args const& a, join_args* d_args, hipStream_t stream)
+{
+  (void)a;
+  cudf::detail::prof::scope prof_{"join_retrieve", stream};
+  hipLaunchKernelGGL(k_dense_big_emit, dim3(2048), dim3(256), 0, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 void launch_mark_matched(size_type const* right_indices, std::size_t n, uint8_t* build_matched, hipStream_t stream)

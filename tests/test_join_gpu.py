@@ -387,6 +387,46 @@ def test_dense_key_join_against_oracle(G, oracle, monkeypatch, kind, shape):
     assert kat.sorted_pairs(li2, ri2) == kat.sorted_pairs(el, er)
 
 
+@pytest.mark.parametrize("kind", ["inner", "left", "full"])
+def test_dense_key_join_hot_build_key(G, oracle, monkeypatch, kind):
+    """A build key with thousands of rows that hundreds of probe rows hit: the keys' ROW LISTS (offsets + rows grouped by key,
+    launch_dense_csr) let the whole wave emit a hot key's pairs 64 at a time; a chain walked link by link by one lane took
+    149 ms for 1000 probes of a key with 100,000 build rows (profiles/r2_join_matrix.txt). Lists of 1, 2, 64, 65 and 5000 rows;
+    NULL build rows never match; the match counts of the join_match_context agree."""
+    import cudf_amd
+    from cudf_amd import join as J
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(93)
+    nr, nl = 60_000, 40_000
+    rk = rng.permutation(nr).astype(np.int64) + 500
+    rk[:5000] = 777            # the hot key
+    rk[5000:5064] = 1_111      # a list of exactly 64 rows (+ possibly the permutation's own 1111)
+    rk[5064:5129] = 2_222      # 65 rows
+    rk[5129:5131] = 3_333
+    rv = rng.random(nr) > 0.05
+    lk = rng.integers(0, nr + 20_000, nl, dtype=np.int64)
+    lk[:300] = 777
+    lk[300:340] = 1_111
+    lk[340:380] = 2_222
+    lk[380:400] = 3_333
+    lv = rng.random(nl) > 0.05
+    left, right = [(lk, lv)], [(rk, rv)]
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
+    li, ri = G.join(left, right, nulls_equal=False, kind=kind)
+    el, er = oracle.join(left, right, nulls_equal=False, kind=kind)
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+    if kind == "inner":
+        # (cudf::inner_join builds on the smaller side: probe the hot BUILD key through a hash_join object as well)
+        hj = J.HashJoin(cudf_amd.Table([G.to_device((rk, rv))]), NullEquality.UNEQUAL)
+        pl, pr = hj.inner_join(cudf_amd.Table([G.to_device((lk, lv))]))
+        assert kat.sorted_pairs(pl.to_numpy()[0], pr.to_numpy()[0]) == kat.sorted_pairs(el, er)
+        hj = J.HashJoin(cudf_amd.Table([G.to_device((rk, rv))]), NullEquality.UNEQUAL)
+        ctx = hj.inner_join_match_context(cudf_amd.Table([G.to_device((lk, lv))]))
+        counts = ctx._match_counts.to_numpy()[0]
+        assert np.array_equal(counts, np.bincount(el, minlength=nl))
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_fuzz_dense_joins_against_oracle(G, oracle, monkeypatch, seed):
     """Seeded shapes on the dense path (CUDF_AMD_JOIN_DENSE_MIN_ROWS=1): sizes 0 .. 60K, key ranges from a handful of values to
