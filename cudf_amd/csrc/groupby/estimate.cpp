@@ -63,7 +63,10 @@ void aggregate_call::estimate()
     // 1M sampled rows for big inputs; small inputs sample 1/16 of their rows (at least 64K): the estimate only picks the
     // strategy, and a 1M-row sample costs more than the aggregation of a 1M-row input
     int64_t const sample = std::min<int64_t>(n, std::clamp<int64_t>(n / 16, int64_t{1} << 16, int64_t{1} << 20));
-    int const bits_log2  = 24;
+    // (linear counting wants the bitmap at a sixteenth of its load: 2^24 bits for the 1M-row sample of a big input, 2^20 for the
+    // 64K-row sample of a 1M-row input - whose memset and population count were a 2 MB pass each for nothing)
+    int bits_log2 = 16;
+    while (bits_log2 < 24 && (int64_t{1} << bits_log2) < 16 * sample) ++bits_log2;
     uint32_t* bitmap     = sc.alloc<uint32_t>((size_t{1} << bits_log2) / 32);
     uint32_t* d_set      = sc.alloc<uint32_t>(1);
     plan_dev* d_plan = sc.alloc<plan_dev>(1);
@@ -303,6 +306,9 @@ outcome aggregate_call::run_attempt(int attempt)
 
 void aggregate_call::run()
 {
+  // (Tried in round 3 and removed: for 64K <= n < 32M rows, path S first without the sample pass. 1M rows on 1000 groups 232 ->
+  // 179 us, but a failed try is not cheap - 1M rows on 500K groups 214 -> 365 us, 10M rows on 1M groups 346 -> 724 us:
+  // profiles/r3_small_call_latency.txt.)
   estimate();
   for (int attempt = 0;;) {
     CUDF_EXPECTS(attempt < 4, "hash groupby: could not fit the groups into LDS tables (pathological key distribution).");
