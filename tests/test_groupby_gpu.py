@@ -562,7 +562,7 @@ def test_fuzz_against_oracle(G, oracle, seed, monkeypatch):
     big_paths = seed % 3 == 1
     if big_paths:
         monkeypatch.setenv("CUDF_AMD_GB_BIG_MIN_ROWS", "1000")
-            n = int(rng.choice([80_000, 300_000, 700_000]))
+        n = int(rng.choice([80_000, 300_000, 700_000]))
         if seed % 4 != 3:
             monkeypatch.setenv("CUDF_AMD_GB_LDS_KB", str(int(rng.choice([16, 32, 159]))))  # (the groups must not fit one table)
 
