@@ -491,8 +491,11 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
       // (testing only every fourth batch, with a sticky flag, measured SLOWER: 3.61 vs 3.51 ms on C2's aggregate)
       bool crowded = false;
       if constexpr (INPUT != IN_PARTIAL_RECORDS) {
+        // (from 8 lanes on the first row's slot: runs of 64 equal keys that straddle a row set leave lane 0's key as few as
+        // a handful of lanes - with the old threshold of 32 such batches went row by row into two slots: 1B rows in runs of 64
+        // took 12.6 ms in this pass against 5.3 ms for runs of 1000)
         int const first = __builtin_amdgcn_readfirstlane(sl[0]);
-        crowded         = __popcll(__ballot(keep[0] && sl[0] == first && first >= 0)) >= 32;
+        crowded         = __popcll(__ballot(keep[0] && sl[0] == first && first >= 0)) >= 8;
       }
       bool combined[R];  // (one inlined copy of accumulate: a second one cost the generic shapes 8-10 %)
 #pragma unroll
@@ -500,15 +503,19 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
       if (crowded) {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-          bool const act                = keep[k] && sl[k] >= 0;
-          unsigned long long const am   = __ballot(act);
-          if (am == 0) continue;
-          int const lead_slot           = __shfl(sl[k], __ffsll(static_cast<long long>(am)) - 1);
-          bool const mine               = act && sl[k] == lead_slot;
-          unsigned long long const same = __ballot(mine);
-          if (__popcll(same) < 16) continue;
-          accumulate_wave(base + k * 64 + lane, lead_slot, mine, lane == __ffsll(static_cast<long long>(same)) - 1, pay[k], valvalid[k]);
-          combined[k] = mine;
+          // up to three slots per row set, most crowded lanes first in row order (clustered rows: a row set of 64 consecutive rows
+          // holds two or three runs); what is left goes row by row
+          for (int round = 0; round < 3; ++round) {
+            bool const act                = keep[k] && sl[k] >= 0 && !combined[k];
+            unsigned long long const am   = __ballot(act);
+            if (am == 0) break;
+            int const lead_slot           = __shfl(sl[k], __ffsll(static_cast<long long>(am)) - 1);
+            bool const mine               = act && sl[k] == lead_slot;
+            unsigned long long const same = __ballot(mine);
+            if (__popcll(same) < 8) break;
+            accumulate_wave(base + k * 64 + lane, lead_slot, mine, lane == __ffsll(static_cast<long long>(same)) - 1, pay[k], valvalid[k]);
+            combined[k] = combined[k] || mine;
+          }
         }
       }
 #pragma unroll
