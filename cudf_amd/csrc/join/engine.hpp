@@ -91,6 +91,74 @@ constexpr uint32_t BIG_LIST = 1024, BIG_LIST_CAP = 1u << 16;
 constexpr uint32_t MATCH_NONE  = 0xffffffffu;
 constexpr uint32_t MATCH_MULTI = 0x80000000u;
 
+// ---- LDS radix join (radix_kernels.hip; round 3): one 8-byte integer key whose NULLs never match, inner join, big inputs.
+// BOTH sides are partitioned on the top bits of the key hash - two ring-scatter levels (the groupby's ring scatter: per-partition
+// rings in LDS, one returning ds_add per row, whole 128-byte granules only) of {key (8 B), row id (4 B)} rows in two streams -
+// into partitions whose BUILD rows fit an open-addressing table in LDS (8192 slots of key + row, load ~0.35); one workgroup per
+// partition then builds that table and streams the partition's probe rows past it: every probe is an LDS access instead of a
+// random 16-byte read into a GB-sized table (475M of them at the fabric's 45 G requests/s were 15.6 of C3-sparse's 19.5 ms).
+// Pairs come out partition-major (the reference promises no order either). Replaces, for such joins, cuco::static_multiset
+// build + probe (cpp/src/join/hash_join/hash_join.cu:62-149, retrieve_impl.cuh:29-133, size_impl.cuh:26-61).
+// Region (q, w) of a level with S slices lies at [(q * S + w) * region_cap, + region_count[q * S + w]) of both streams.
+constexpr int RADIX_RING_SLOTS = 8192;  // key-ring slots of a scatter workgroup (all partitions); the row rings are twice as long
+struct radix_scatter_args {
+  int32_t level;      // 1: rows of a key column; 2: the regions of level-1 partition `seg`
+  // level 1
+  uint64_t const* keys;        // element i = key of row i
+  bitmask_type const* mask;    // validity of the key column (bit mask_offset + i), nullptr: no NULLs; NULL rows are dropped
+  int64_t mask_offset;
+  int64_t nrows;
+  // level 2: work item (seg, s) reads the level-1 regions (seg, w), w = s, s + slices, ... < in_slices as one virtual row range
+  uint64_t const* in_key;
+  uint32_t const* in_row;
+  int32_t const* in_region_count;
+  int64_t in_region_cap;
+  int32_t in_slices;
+  int32_t nseg;
+  // both
+  int32_t P;          // fan-out: a power of two, 16 ... 256
+  int32_t capl;       // log2 of the ring capacity per partition: P << capl = RADIX_RING_SLOTS
+  int32_t shift;      // digit = (key hash >> shift) & (P - 1)
+  int32_t slices;
+  uint64_t* out_key;
+  uint32_t* out_row;
+  int64_t region_cap; // a multiple of 32 records
+  int32_t* region_count;
+  int32_t* overflow;  // bit 0: a region overflowed
+};
+struct radix_join_args {
+  uint64_t const* b_key;   // build partitions: regions (q, s), s < b_slices
+  uint32_t const* b_row;
+  int32_t const* b_count;
+  int64_t b_cap;
+  int32_t b_slices;
+  uint64_t const* p_key;   // probe partitions
+  uint32_t const* p_row;
+  int32_t const* p_count;
+  int64_t p_cap;
+  int32_t p_slices;
+  int32_t nparts;
+  int32_t cap;             // LDS table slots (a power of two)
+  int32_t fill_limit;      // build rows a table takes before the partition reports overflow
+  unsigned long long* pair_counts;  // [nparts + 1]: pairs per partition (count pass), then their exclusive prefix (launch_scan)
+  // The count pass also STAGES the pairs it finds - {probe row, build row} as one 8-byte word, partition q's pairs at
+  // stage[q * stage_cap ...) - so that the retrieve pass is a copy (launch_radix_emit_staged) instead of a second build + probe;
+  // a partition with more pairs than stage_cap (duplicated keys) sets bit 2 of *overflow and is joined again by the retrieve pass.
+  uint64_t* stage;
+  int64_t stage_cap;
+  size_type* out_probe;
+  size_type* out_build;
+  uint64_t out_capacity;
+  int64_t probe_row_base;
+  int32_t* overflow;       // bit 1: a build partition does not fit its table; bit 2: a partition's pairs did not fit its stage
+};
+void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_args, hipStream_t stream);
+// the largest number of rows of one partition (regions summed over its slices) -> *out_max (preset to 0)
+void launch_radix_partition_max(int32_t const* region_count, int32_t nparts, int32_t slices, int32_t* out_max, hipStream_t stream);
+void launch_radix_join(radix_join_args const& a, radix_join_args* d_args, bool retrieve, hipStream_t stream);
+// copies the staged pairs of every partition that fit its stage to out_probe / out_build (pair_counts holds the exclusive prefix)
+void launch_radix_emit_staged(radix_join_args const& a, radix_join_args* d_args, hipStream_t stream);
+
 void launch_build(join_args const& a, join_args* d_args, hipStream_t stream);
 // minimum and maximum of the valid keys of the (single 8-byte integer) build column: out[0] = min, out[1] = max (bit patterns);
 // out must hold {max value, min value} of the ordering before (launch_key_minmax initialises it)

@@ -13,6 +13,8 @@
 #include <cudf/utilities/error.hpp>
 
 #include <algorithm>
+#include <mutex>
+#include <optional>
 #include <cmath>
 #include <cstdlib>
 #include <stdexcept>
@@ -86,7 +88,7 @@ class hash_join_impl {
  public:
   hash_join_impl(table_view const& right, bool has_nulls, null_equality compare_nulls, double load_factor,
                  stream_ref stream, rmm::device_async_resource_ref mr)
-    : _right{right}, _has_nulls{has_nulls}, _nulls_equal{compare_nulls}, _is_empty{right.num_rows() == 0}
+    : _right{right}, _has_nulls{has_nulls}, _nulls_equal{compare_nulls}, _is_empty{right.num_rows() == 0}, _mr{mr}
   {
     CUDF_EXPECTS(0 != right.num_columns(), "Hash join right table is empty", std::invalid_argument);
     load_factor = checked_load_factor(load_factor);
@@ -95,11 +97,7 @@ class hash_join_impl {
     auto const rows   = static_cast<uint64_t>(right.num_rows());
     // `load_factor` is the caller's upper bound (reference default 0.5). The probe is bound by random memory requests
     // and a multiset walk ends at the first empty slot: 2.5 slots at load 0.5, 1.4 at 0.25 - so the table is kept
-    // at <= 0.25 unless that would take more than 1/8 of the device memory.
-    double const target_load = std::min(load_factor, 0.01 * static_cast<double>(env_flag("CUDF_AMD_JOIN_MAX_LOAD_PCT", 25)));
-    uint64_t capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / target_load));
-    if (capacity * 8 > (uint64_t{36} << 30)) capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / load_factor));
-    capacity          = std::clamp<uint64_t>(capacity, rows + 1, (uint64_t{1} << 32) - 2);  // always one empty slot
+    // at <= 0.25 unless that would take more than 1/8 of the device memory (build_classic).
     // CUDF_AMD_JOIN_PARTITIONED=1 (experimental): one 8-byte integer key whose NULLs can never
     // match is stored inline (16-byte slots), big tables are sliced by the top hash bits and big inner-join probe
     // sides are radix-partitioned on the same bits. Default: 8-byte slots, direct windowed probe.
@@ -149,6 +147,26 @@ class hash_join_impl {
         return;
       }
     }
+    _key64        = key64;
+    _classic_load = load_factor;
+    // LDS radix join (engine.hpp): the build side partitioned into LDS-sized partitions; the open-addressing table in HBM is then
+    // only built if a call needs it (left / full joins, match contexts, small probe sides, a probe side that overflows a region)
+    if (key64 && try_radix_build(right, stream)) return;
+    build_classic(stream);
+  }
+
+ private:
+  // The open-addressing multiset in HBM (slots of {hash tag | build row}, linear window + key-dependent stride): what every probe
+  // used before the radix join and what everything but big inner joins on one 8-byte key still uses.
+  void build_classic(stream_ref stream) const
+  {
+    auto const rows     = static_cast<uint64_t>(_right.num_rows());
+    double const target_load = std::min(_classic_load, 0.01 * static_cast<double>(env_flag("CUDF_AMD_JOIN_MAX_LOAD_PCT", 25)));
+    uint64_t capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / target_load));
+    if (capacity * 8 > (uint64_t{36} << 30)) capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / _classic_load));
+    capacity          = std::clamp<uint64_t>(capacity, rows + 1, (uint64_t{1} << 32) - 2);  // always one empty slot
+    bool const key64  = _key64;
+    auto mr           = _mr;
     _slot_words      = (key64 && env_flag("CUDF_AMD_JOIN_PARTITIONED", 0)) ? 2 : 1;
     // big inline-key tables are sliced by the top hash bits (~2-4 MB per slice, what one XCD's L2 holds) so that a
     // radix-partitioned probe side walks one slice at a time
@@ -164,15 +182,189 @@ class hash_join_impl {
     _slice            = capacity >> _part_bits;
     _table            = rmm::device_buffer{capacity * sizeof(uint64_t) * _slot_words, stream.value(), mr};
     CUDF_HIP_TRY(hipMemsetAsync(_table.data(), 0xff, capacity * sizeof(uint64_t) * _slot_words, stream.value()));
-    join_args a = base_args(right, 0);
+    join_args a = base_args(_right, 0);
     rmm::device_buffer d_args{sizeof(join_args), stream.value(), cudf::get_current_device_resource_ref()};
     rmm::device_buffer skip{sizeof(uint64_t) * join::BUILD_SKIP_ENTRIES, stream.value(), cudf::get_current_device_resource_ref()};
     CUDF_HIP_TRY(hipMemsetAsync(skip.data(), 0xff, skip.size(), stream.value()));  // no home slot is 2^40 - 1
     a.build_skip = static_cast<uint64_t*>(skip.data());
     join::launch_build(a, static_cast<join_args*>(d_args.data()), stream.value());
     CUDF_HIP_TRY(hipStreamSynchronize(stream.value()));  // d_args goes out of scope; build is done for probes on any stream
+    _classic_built = true;
+  }
+  // ---- LDS radix join, build side (engine.hpp): two ring-scatter levels of {key, row id}; false if the build side does not take it
+  // (too small or too big for 2048 ... 32768 partitions, a region or a partition that overflows: heavily duplicated keys)
+  struct radix_side {
+    rmm::device_buffer key1, row1, cnt1, key2, row2, cnt2;
+    int64_t cap2{0};
+    int32_t slices2{0};
+  };
+  bool radix_partition(uint64_t const* keys, bitmask_type const* mask, int64_t mask_offset, int64_t nrows, int64_t valid_rows, radix_side& out,
+                       stream_ref stream, rmm::device_async_resource_ref mr2) const
+  {
+    hipStream_t const s = stream.value();
+    auto tmp            = cudf::get_current_device_resource_ref();
+    int64_t const P1 = 128, P2 = _rx_nparts / P1, S1 = std::clamp<int64_t>((nrows + 4095) / 4096, 1, 256), slices2 = 4;
+    auto cap_for = [](double mean) {  // six sigmas of a Poisson cell on top of its mean, whole 32-record granules
+      return (static_cast<int64_t>(mean + 6.0 * std::sqrt(std::max(mean, 1.0)) + 64.0) + 31) / 32 * 32;
+    };
+    int64_t const tiles = (nrows + 4095) / 4096, wg_rows = std::min<int64_t>(nrows, (tiles + S1 - 1) / S1 * 4096);
+    int64_t const cap1  = cap_for(static_cast<double>(wg_rows) / static_cast<double>(P1));
+    int64_t const cap2  = cap_for(static_cast<double>(valid_rows) / static_cast<double>(_rx_nparts * slices2) * 1.02);
+    rmm::device_buffer ovf{sizeof(int32_t), s, tmp}, d_args{sizeof(join::radix_scatter_args), s, tmp};
+    CUDF_HIP_TRY(hipMemsetAsync(ovf.data(), 0, sizeof(int32_t), s));
+    out.key1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1 * cap1) * 8, s, tmp};
+    out.row1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1 * cap1) * 4, s, tmp};
+    out.cnt1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1) * 4, s, tmp};
+    out.key2 = rmm::device_buffer{static_cast<std::size_t>(_rx_nparts * slices2 * cap2) * 8, s, mr2};
+    out.row2 = rmm::device_buffer{static_cast<std::size_t>(_rx_nparts * slices2 * cap2) * 4, s, mr2};
+    out.cnt2 = rmm::device_buffer{static_cast<std::size_t>(_rx_nparts * slices2) * 4, s, mr2};
+    out.cap2    = cap2;
+    out.slices2 = static_cast<int32_t>(slices2);
+    CUDF_HIP_TRY(hipMemsetAsync(out.cnt1.data(), 0, out.cnt1.size(), s));
+    CUDF_HIP_TRY(hipMemsetAsync(out.cnt2.data(), 0, out.cnt2.size(), s));
+    auto log2i = [](int64_t v) { int l = 0; while ((int64_t{1} << l) < v) ++l; return l; };
+    join::radix_scatter_args a1{};
+    a1.level        = 1;
+    a1.keys         = keys;
+    a1.mask         = mask;
+    a1.mask_offset  = mask_offset;
+    a1.nrows        = nrows;
+    a1.P            = static_cast<int32_t>(P1);
+    a1.capl         = 13 - log2i(P1);
+    a1.shift        = 64 - log2i(P1);
+    a1.slices       = static_cast<int32_t>(S1);
+    a1.out_key      = static_cast<uint64_t*>(out.key1.data());
+    a1.out_row      = static_cast<uint32_t*>(out.row1.data());
+    a1.region_cap   = cap1;
+    a1.region_count = static_cast<int32_t*>(out.cnt1.data());
+    a1.overflow     = static_cast<int32_t*>(ovf.data());
+    join::launch_radix_scatter(a1, static_cast<join::radix_scatter_args*>(d_args.data()), s);
+    join::radix_scatter_args a2{};
+    a2.level           = 2;
+    a2.in_key          = a1.out_key;
+    a2.in_row          = a1.out_row;
+    a2.in_region_count = a1.region_count;
+    a2.in_region_cap   = cap1;
+    a2.in_slices       = static_cast<int32_t>(S1);
+    a2.nseg            = static_cast<int32_t>(P1);
+    a2.P               = static_cast<int32_t>(P2);
+    a2.capl            = 13 - log2i(P2);
+    a2.shift           = 64 - log2i(P1) - log2i(P2);
+    a2.slices          = static_cast<int32_t>(slices2);
+    a2.out_key         = static_cast<uint64_t*>(out.key2.data());
+    a2.out_row         = static_cast<uint32_t*>(out.row2.data());
+    a2.region_cap      = cap2;
+    a2.region_count    = static_cast<int32_t*>(out.cnt2.data());
+    a2.overflow        = a1.overflow;
+    rmm::device_buffer d_args2{sizeof(join::radix_scatter_args), s, tmp};
+    join::launch_radix_scatter(a2, static_cast<join::radix_scatter_args*>(d_args2.data()), s);
+    int32_t h_ovf = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    out.key1 = rmm::device_buffer{};  // (the first level's regions go back to the pool)
+    out.row1 = rmm::device_buffer{};
+    out.cnt1 = rmm::device_buffer{};
+    return h_ovf == 0;
+  }
+  bool try_radix_build(table_view const& right, stream_ref stream)
+  {
+    if (env_flag("CUDF_AMD_JOIN_RADIX", 1) == 0) return false;
+    auto const& col     = right.column(0);
+    int64_t const rows  = right.num_rows();
+    int64_t const valid = rows - (col.nullable() ? col.null_count() : 0);
+    // partitions: a power of two with at most ~3500 build rows each (LDS tables of 8192 slots: load <= 0.43), 128 x (16 ... 256)
+    int64_t nparts = 2048;
+    while (nparts < 32768 && valid > nparts * 3500) nparts <<= 1;
+    if (valid < env_flag("CUDF_AMD_JOIN_RADIX_MIN_BUILD", 3 << 20) || valid > nparts * 3500) return false;
+    _rx_nparts = static_cast<int32_t>(nparts);
+    hipStream_t const s = stream.value();
+    if (!radix_partition(col.data<uint64_t>(), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, valid, _rx_build, stream, _mr))
+      return false;
+    // every partition must fit its LDS table
+    auto tmp = cudf::get_current_device_resource_ref();
+    rmm::device_buffer mx{sizeof(int32_t), s, tmp};
+    CUDF_HIP_TRY(hipMemsetAsync(mx.data(), 0, sizeof(int32_t), s));
+    join::launch_radix_partition_max(static_cast<int32_t const*>(_rx_build.cnt2.data()), _rx_nparts, _rx_build.slices2, static_cast<int32_t*>(mx.data()), s);
+    int32_t h_max = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_max, mx.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    if (h_max > RADIX_FILL_LIMIT) {
+      _rx_build = radix_side{};
+      return false;
+    }
+    _radix = true;
+    return true;
+  }
+  static constexpr int32_t RADIX_TABLE_SLOTS = 8192, RADIX_FILL_LIMIT = 5200;
+
+  // inner join of a big probe side against the radix-partitioned build side; nullopt: this probe side does not take it
+  std::optional<join_index_pair> radix_probe(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr, int64_t row_base) const
+  {
+    auto const& col = left.column(0);
+    bool const probe_nulls = _has_nulls && col.has_nulls();
+    if (!is_single64(left) || (probe_nulls && _nulls_equal == null_equality::EQUAL)) return std::nullopt;
+    int64_t const rows  = left.num_rows();
+    int64_t const valid = rows - (col.nullable() ? col.null_count() : 0);
+    if (rows < env_flag("CUDF_AMD_JOIN_RADIX_MIN_PROBE", 8 << 20) || rows > (int64_t{1} << 31) - 1) return std::nullopt;
+    hipStream_t const s = stream.value();
+    auto tmp            = cudf::get_current_device_resource_ref();
+    radix_side probe;
+    if (!radix_partition(col.data<uint64_t>(), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, valid, probe, stream, tmp)) return std::nullopt;
+    rmm::device_buffer counts{(static_cast<std::size_t>(_rx_nparts) + 1) * sizeof(unsigned long long), s, tmp}, ovf{sizeof(int32_t), s, tmp},
+      d_args{sizeof(join::radix_join_args), s, tmp};
+    CUDF_HIP_TRY(hipMemsetAsync(ovf.data(), 0, sizeof(int32_t), s));
+    join::radix_join_args a{};
+    a.b_key = static_cast<uint64_t const*>(_rx_build.key2.data());
+    a.b_row = static_cast<uint32_t const*>(_rx_build.row2.data());
+    a.b_count = static_cast<int32_t const*>(_rx_build.cnt2.data());
+    a.b_cap = _rx_build.cap2;
+    a.b_slices = _rx_build.slices2;
+    a.p_key = static_cast<uint64_t const*>(probe.key2.data());
+    a.p_row = static_cast<uint32_t const*>(probe.row2.data());
+    a.p_count = static_cast<int32_t const*>(probe.cnt2.data());
+    a.p_cap = probe.cap2;
+    a.p_slices = probe.slices2;
+    a.nparts = _rx_nparts;
+    a.cap = RADIX_TABLE_SLOTS;
+    a.fill_limit = RADIX_FILL_LIMIT;
+    a.pair_counts = static_cast<unsigned long long*>(counts.data());
+    a.probe_row_base = row_base;
+    a.overflow = static_cast<int32_t*>(ovf.data());
+    a.stage_cap = probe.cap2 * probe.slices2;  // (as many pairs as the partition has room for probe rows: enough unless keys repeat a lot)
+    rmm::device_buffer stage{static_cast<std::size_t>(_rx_nparts) * static_cast<std::size_t>(a.stage_cap) * sizeof(uint64_t), s, tmp};
+    a.stage = static_cast<uint64_t*>(stage.data());
+    join::launch_radix_join(a, static_cast<join::radix_join_args*>(d_args.data()), false, s);
+    join_args sc{};
+    sc.block_counts = a.pair_counts;
+    sc.nblocks      = _rx_nparts;
+    join::launch_scan(sc, s);
+    unsigned long long total = 0;
+    int32_t h_ovf            = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(&total, a.pair_counts + _rx_nparts, sizeof(total), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    if ((h_ovf & 3) != 0) return std::nullopt;
+    CUDF_EXPECTS(total <= static_cast<unsigned long long>(std::numeric_limits<size_type>::max()),
+                 "Join result exceeds the maximum column size; use the *_join_size API and chunk the probe side.", std::overflow_error);
+    auto out_l = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(total), s, mr);
+    auto out_r = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(total), s, mr);
+    a.out_probe    = out_l->data();
+    a.out_build    = out_r->data();
+    a.out_capacity = total;
+    rmm::device_buffer d_args2{sizeof(join::radix_join_args), s, tmp};
+    join::launch_radix_emit_staged(a, static_cast<join::radix_join_args*>(d_args2.data()), s);
+    if ((h_ovf & 4) != 0) join::launch_radix_join(a, static_cast<join::radix_join_args*>(d_args2.data()), true, s);
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    return join_index_pair{std::move(out_l), std::move(out_r)};
   }
 
+  void ensure_classic(stream_ref stream) const
+  {
+    std::lock_guard<std::mutex> g{_classic_mu};
+    if (!_classic_built && !_is_empty && !_dense) build_classic(stream);
+  }
+
+ public:
   [[nodiscard]] std::size_t join_size(table_view const& left, join_kind kind, stream_ref stream,
                                       std::vector<uint8_t>* /*unused*/ = nullptr) const
   {
@@ -188,6 +380,7 @@ class hash_join_impl {
       auto r = probe(left, kind, std::nullopt, stream, cudf::get_current_device_resource_ref());
       return r.first->size();
     }
+    ensure_classic(stream);
     join_args a = base_args(left, kind == join_kind::INNER_JOIN ? 0 : 1);
     rmm::device_buffer counts{(static_cast<std::size_t>(a.nblocks) + 1) * sizeof(unsigned long long), stream.value(),
                               cudf::get_current_device_resource_ref()};
@@ -220,6 +413,7 @@ class hash_join_impl {
       CUDF_HIP_TRY(hipStreamSynchronize(s));
       return out;
     }
+    ensure_classic(stream);
     join_args a = base_args(left, kind == join_kind::INNER_JOIN ? 0 : 1);
     rmm::device_buffer counts{(static_cast<std::size_t>(a.nblocks) + 1) * sizeof(unsigned long long), s,
                               cudf::get_current_device_resource_ref()};
@@ -276,6 +470,15 @@ class hash_join_impl {
     }
     int const k = kind == join_kind::INNER_JOIN ? 0 : kind == join_kind::LEFT_JOIN ? 1 : 2;
     hipStream_t const s = stream.value();
+    if (_radix && k == 0) {  // big inner joins on one 8-byte key: both sides in LDS-sized partitions (engine.hpp)
+      auto r = radix_probe(left, stream, mr, row_base);
+      if (r.has_value()) {
+        if (output_size.has_value())
+          CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
+        return std::move(*r);
+      }
+    }
+    ensure_classic(stream);
     rmm::device_buffer d_args{sizeof(join_args), s, cudf::get_current_device_resource_ref()};
     // ---- size: given, or counted with one probe pass (reference: compute_join_output_size, size_impl.cuh:26-61)
     // The count pass always runs: its per-workgroup counts place every pair without global atomics (the pass
@@ -456,11 +659,21 @@ class hash_join_impl {
   null_equality _nulls_equal;
   bool _is_empty;
   device_table _build_dev{};
-  uint64_t _capacity{0};
-  int32_t _slot_words{1};
-  int32_t _part_bits{0};
-  uint64_t _slice{0};
-  rmm::device_buffer _table{};
+  rmm::device_async_resource_ref _mr;
+  bool _key64{false};
+  double _classic_load{0.5};
+  // the open-addressing table in HBM: built by the constructor, or on first need when the build side took the radix partitions
+  mutable std::mutex _classic_mu;
+  mutable bool _classic_built{false};
+  mutable uint64_t _capacity{0};
+  mutable int32_t _slot_words{1};
+  mutable int32_t _part_bits{0};
+  mutable uint64_t _slice{0};
+  mutable rmm::device_buffer _table{};
+  // LDS radix join: the build side in LDS-sized partitions
+  bool _radix{false};
+  int32_t _rx_nparts{0};
+  radix_side _rx_build{};
   bool _dense{false}, _dense_has_dups{false};
   uint64_t _dense_lo{0}, _dense_range{0};
   rmm::device_buffer _dense_head{}, _dense_next{};

@@ -1,0 +1,617 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 kernels of the LDS radix join (engine.hpp radix_scatter_args / radix_join_args).
+//
+// k_radix_scatter: the ring scatter of the groupby's dense path (groupby/dense_ring_kernels.hip) for {key, row id} rows: every
+// partition owns a ring of key slots and a ring of row-id slots in LDS; a row reserves its position with ONE returning LDS atomic;
+// after a barrier the owner lanes flush every complete 128-byte granule (16 keys / 32 row ids); a second barrier ends the
+// 4096-row tile. 12 bytes per row leave the workgroup, in two streams.
+// k_radix_join: one workgroup per partition builds an open-addressing multiset of the partition's build rows in LDS (keys as the
+// slots' state, probed in aligned pairs = one ds_read_b128) and streams the partition's probe rows past it - count pass and
+// retrieve pass (the reference's size_impl.cuh:26-61 / retrieve_impl.cuh:29-133 structure), pairs allocated from a
+// workgroup-local cursor by 64-lane ballots.
+#include "engine.hpp"
+#include "../common/profiler.hpp"
+
+#include <cudf/join/join.hpp>
+#include <cudf/utilities/error.hpp>
+
+#include <mutex>
+
+namespace cudf::detail::join {
+namespace {
+
+template <typename T>
+__global__ void k_store_radix_args(T v, T* dst)
+{
+  *dst = v;
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ uint64_t radix_hash(uint64_t key) { return mix64(0x9e3779b97f4a7c15ull ^ key); }
+
+constexpr int RADIX_MAX_REGION_LIST = 256;
+
+template <int LEVEL, int RPT, int D>
+__global__ void __launch_bounds__(1024) k_radix_scatter(radix_scatter_args const* __restrict__ ap)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int s_pending, s_abort;
+  __shared__ int32_t s_pre[RADIX_MAX_REGION_LIST + 1];
+  radix_scatter_args const& a = *ap;
+  constexpr int B = 1024;
+  constexpr uint32_t G = 16, GT = 32, TPL = 4;  // keys / row ids per 128-byte granule; row ids per lane of a flush (16 bytes)
+  int const P = a.P, capl = a.capl;
+  uint32_t const CAP = 1u << capl, cmask = CAP - 1u, tcmask = (CAP << 1) - 1u;
+  uint64_t* rkey  = reinterpret_cast<uint64_t*>(lds_raw);                        // [P << capl]
+  uint32_t* rrow  = reinterpret_cast<uint32_t*>(rkey + RADIX_RING_SLOTS);         // [P << (capl + 1)]
+  uint32_t* tail  = rrow + 2 * RADIX_RING_SLOTS;                                  // [P] next virtual position
+  uint32_t* limit = tail + P;                                                     // [P] head + CAP as of the last flush
+  int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
+  int const PW = P / nwaves;  // partitions owned by a wave (1 ... 16)
+  uint32_t head = 0, headt = 0;
+  for (int d = threadIdx.x; d < P; d += B) {
+    tail[d]  = 0;
+    limit[d] = CAP;
+  }
+  if (threadIdx.x == 0) {
+    s_pending = 0;
+    s_abort   = 0;
+  }
+  constexpr int64_t T = static_cast<int64_t>(B) * RPT;
+  int item = blockIdx.x, seg = 0;
+  int64_t begin, end, step;
+  int nreg = 0;
+  int64_t rfirst = 0, rstride = 0;
+  if constexpr (LEVEL == 2) {
+    seg     = blockIdx.x / a.slices;
+    item    = blockIdx.x % a.slices;
+    nreg    = (a.in_slices - item + a.slices - 1) / a.slices;
+    rfirst  = (static_cast<int64_t>(seg) * a.in_slices + item) * a.in_region_cap;
+    rstride = static_cast<int64_t>(a.slices) * a.in_region_cap;
+    if (threadIdx.x == 0) {
+      int32_t run = 0;
+      for (int j = 0; j < nreg; ++j) {
+        s_pre[j] = run;
+        int64_t const c = a.in_region_count[static_cast<int64_t>(seg) * a.in_slices + item + static_cast<int64_t>(j) * a.slices];
+        run += static_cast<int32_t>(min(max(c, int64_t{0}), a.in_region_cap));
+      }
+      s_pre[nreg] = run;
+    }
+    __syncthreads();
+    begin = 0;
+    end   = s_pre[nreg];
+    step  = T;
+  } else {
+    begin = static_cast<int64_t>(item) * T;  // workgroup w takes the row tiles w, w + slices, ...
+    end   = a.nrows;
+    step  = static_cast<int64_t>(a.slices) * T;
+    __syncthreads();
+  }
+  int64_t const region0     = static_cast<int64_t>(seg) * P * a.slices;
+  uint32_t const region_cap = static_cast<uint32_t>(a.region_cap);
+  int const shift           = a.shift;
+  uint32_t const pmask      = static_cast<uint32_t>(P - 1);
+  int reg_hint[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) reg_hint[k] = 0;
+  auto record_of = [&](int64_t v, int& reg) -> int64_t {  // (a thread's rows ascend from tile to tile: the region only moves forward)
+    while (reg + 1 < nreg && s_pre[reg + 1] <= v) ++reg;
+    return rfirst + static_cast<int64_t>(reg) * rstride + (v - s_pre[reg]);
+  };
+  struct tile_regs {
+    uint64_t k[RPT];
+    uint32_t r[RPT];  // level 1: the validity word of the row; level 2: the row id
+  };
+  auto issue = [&](int64_t tile, tile_regs& t) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      int64_t const row = tile + static_cast<int64_t>(k) * B + threadIdx.x;
+      if (row < end) {
+        if constexpr (LEVEL == 1) {
+          t.k[k] = gload(a.keys + row);
+          t.r[k] = a.mask != nullptr ? gload(a.mask + ((a.mask_offset + row) >> 5)) : 0xffffffffu;
+        } else {
+          int64_t const ri = record_of(row, reg_hint[k]);
+          t.k[k]           = gload(a.in_key + ri);
+          t.r[k]           = gload(a.in_row + ri);
+        }
+      }
+    }
+  };
+  auto flush = [&](bool final) {
+    uint32_t nrec = 0, nrect = 0;
+    int ab        = 0;
+    int const dmine = wave * PW + lane;
+    if (lane < PW) {
+      uint32_t const t = tail[dmine], lim = head + CAP;
+      uint32_t const c = static_cast<int32_t>(t - lim) < 0 ? t : lim;
+      uint32_t const complete = final ? c : (c & ~(G - 1u));
+      nrec  = complete - head;
+      nrect = (final ? c : (c & ~(GT - 1u))) - headt;
+      if (complete > region_cap) {
+        s_abort = 1;
+        ab      = 1;
+      }
+    }
+    for (int b = 0; b * 8 < PW; ++b) {  // keys: 8 lanes per granule (two keys per lane), 8 partitions per batch
+      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
+      uint32_t const mr = __shfl(nrec, pl), mh = __shfl(head, pl);
+      int const mab     = __shfl(ab, pl);
+      int const d       = wave * PW + pl;
+      int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
+      for (uint32_t g = 0;; ++g) {
+        uint32_t const q = g * G + sub * 2;
+        bool const act   = pl < PW && q < mr && !mab;
+        if (__ballot(act) == 0) break;
+        if (act) {
+          uint32_t const pos = mh + q;
+          u64x2 const v      = *reinterpret_cast<u64x2 const*>(rkey + (static_cast<uint32_t>(d) << capl) + (pos & cmask));
+          if (q + 1 < mr) gstore(reinterpret_cast<u64x2*>(a.out_key + rbase + pos), v);
+          else gstore(a.out_key + rbase + pos, static_cast<uint64_t>(v.x));
+        }
+      }
+    }
+    for (int b = 0; b * 8 < PW; ++b) {  // row ids: 8 lanes per granule (four ids per lane)
+      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
+      uint32_t const mr = __shfl(nrect, pl), mh = __shfl(headt, pl);
+      int const mab     = __shfl(ab, pl);
+      int const d       = wave * PW + pl;
+      int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
+      for (uint32_t g = 0;; ++g) {
+        uint32_t const q = g * GT + sub * TPL;
+        bool const act   = pl < PW && q < mr && !mab;
+        if (__ballot(act) == 0) break;
+        if (act) {
+          uint32_t const pos  = mh + q;
+          uint32_t const* src = rrow + (static_cast<uint32_t>(d) << (capl + 1)) + (pos & tcmask);
+          if (q + TPL <= mr) {
+            gstore(reinterpret_cast<u32x4*>(a.out_row + rbase + pos), *reinterpret_cast<u32x4 const*>(src));
+          } else {
+            for (uint32_t e = 0; q + e < mr; ++e) gstore(a.out_row + rbase + pos + e, src[e]);
+          }
+        }
+      }
+    }
+    if (lane < PW) {
+      head += nrec;
+      headt += nrect;
+      limit[dmine] = head + CAP;
+    }
+  };
+  auto put = [&](uint32_t d, uint32_t pos, uint64_t key, uint32_t rowid) {
+    rkey[(d << capl) + (pos & cmask)]        = key;
+    rrow[(d << (capl + 1)) + (pos & tcmask)] = rowid;
+  };
+
+  tile_regs pre[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) issue(begin + j * step, pre[j]);
+  for (int64_t tile = begin; tile < end; tile += D * step) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      int64_t const t0 = tile + j * step;
+      bool keep[RPT];
+      uint32_t d[RPT], rowid[RPT];
+      uint64_t key[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        int64_t const row = t0 + static_cast<int64_t>(k) * B + threadIdx.x;
+        keep[k]           = row < end;
+        key[k]            = pre[j].k[k];
+        if constexpr (LEVEL == 1) {
+          rowid[k] = static_cast<uint32_t>(row);
+          keep[k]  = keep[k] && ((pre[j].r[k] >> ((a.mask_offset + row) & 31)) & 1u);  // a NULL key joins nothing (UNEQUAL)
+        } else {
+          rowid[k] = pre[j].r[k];
+        }
+        d[k] = keep[k] ? static_cast<uint32_t>(radix_hash(key[k]) >> shift) & pmask : 0u;
+      }
+      issue(t0 + D * step, pre[j]);
+      if (t0 >= end) break;  // (uniform)
+      uint32_t pos[RPT], lim[RPT];
+      bool pend[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        pos[k] = 0;
+        lim[k] = 0;
+        if (keep[k]) {
+          pos[k] = atomicAdd(&tail[d[k]], 1u);
+          lim[k] = limit[d[k]];
+        }
+      }
+      bool any_pend = false;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        pend[k] = keep[k] && static_cast<int32_t>(pos[k] - lim[k]) >= 0;
+        if (keep[k] && !pend[k]) put(d[k], pos[k], key[k], rowid[k]);
+        any_pend = any_pend || pend[k];
+      }
+      if (any_pend) s_pending = 1;
+      lds_barrier();
+      flush(false);
+      lds_barrier();
+      while (s_pending) {  // a ring was full: its granules are flushed by now, the waiting rows go in
+        lds_barrier();
+        if (threadIdx.x == 0) s_pending = 0;
+        lds_barrier();
+        any_pend = false;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          if (pend[k]) {
+            if (static_cast<int32_t>(pos[k] - limit[d[k]]) < 0) {
+              put(d[k], pos[k], key[k], rowid[k]);
+              pend[k] = false;
+            } else {
+              any_pend = true;
+            }
+          }
+        }
+        if (any_pend) s_pending = 1;
+        lds_barrier();
+        flush(false);
+        lds_barrier();
+        if (s_abort) break;
+      }
+      if (s_abort) {
+        if (threadIdx.x == 0) atomicOr(a.overflow, 1);
+        return;
+      }
+    }
+  }
+  flush(true);
+  lds_barrier();
+  if (s_abort) {
+    if (threadIdx.x == 0) atomicOr(a.overflow, 1);
+    return;
+  }
+  if (lane < PW) a.region_count[region0 + static_cast<int64_t>(wave * PW + lane) * a.slices + item] = static_cast<int32_t>(head);
+}
+
+__global__ void __launch_bounds__(256) k_radix_partition_max(int32_t const* region_count, int32_t nparts, int32_t slices, int32_t* out_max)
+{
+  int const q = blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t tot = 0;
+  if (q < nparts)
+    for (int s = 0; s < slices; ++s) tot += max(region_count[static_cast<int64_t>(q) * slices + s], 0);
+  for (int o = 32; o > 0; o >>= 1) tot = max(tot, __shfl_down(tot, o));
+  if ((threadIdx.x & 63) == 0 && tot > 0) atomicMax(out_max, tot);
+}
+
+// ------------------------------------------------------------------ the join of one partition in LDS
+constexpr uint64_t RJ_EMPTY = 0x7f4a7c159e3779b9ull;  // (the key that equals it takes the side list below)
+constexpr int RJ_SPECIAL   = 256;
+
+// bucket of a key in a partition's table: the partition is the top bits of mix64, the table takes a cheap multiplicative hash of
+// the two key words (two 32-bit multiplies instead of mix64's eight: the join kernel is bound by instruction issue, not by memory)
+__device__ __forceinline__ uint32_t table_hash(uint64_t key)
+{
+  return static_cast<uint32_t>(key) * 0x9e3779b1u + static_cast<uint32_t>(key >> 32) * 0x85ebca77u;
+}
+constexpr int RJ_RPT = 4;  // probe records a thread loads before it walks the table for them (HBM latency: ~48 KB in flight per CU)
+
+template <bool RETRIEVE>
+__global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __restrict__ ap)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ unsigned long long s_cursor;
+  __shared__ uint32_t s_spec_n, s_nbuild;
+  __shared__ int32_t s_spec_rows[RJ_SPECIAL];
+  radix_join_args const& a = *ap;
+  constexpr int B = 1024;
+  int const q = blockIdx.x, cap = a.cap;
+  // retrieve pass: only the partitions whose pairs did not fit their stage are joined again (k_radix_emit_staged copies the rest)
+  if constexpr (RETRIEVE) {
+    if (a.pair_counts[q + 1] - a.pair_counts[q] <= static_cast<unsigned long long>(a.stage_cap)) return;
+  }
+  uint64_t* keys = reinterpret_cast<uint64_t*>(lds_raw);          // [cap + 2]: the table and a spare bucket that stays empty
+  uint32_t* rows = reinterpret_cast<uint32_t*>(keys + cap + 2);   // [cap]
+  uint32_t const bmask = static_cast<uint32_t>(cap / 2 - 1);      // buckets of two slots: one ds_read_b128
+  int const bshift     = __builtin_clz(bmask);                    // bucket = the top bits of table_hash
+  for (int s = threadIdx.x; s < cap / 2 + 1; s += B) reinterpret_cast<u64x2*>(keys)[s] = u64x2{RJ_EMPTY, RJ_EMPTY};
+  if (threadIdx.x == 0) {
+    s_cursor = RETRIEVE ? a.pair_counts[q] : 0ull;
+    s_spec_n = 0;
+    s_nbuild = 0;
+  }
+  bool const upstream_ok = (*a.overflow & 3) == 0;
+  // ---- build: the partition's build rows into the table (a multiset: equal keys take separate slots along the probe sequence)
+  auto insert = [&](uint64_t key, uint32_t row) {
+    if (key == RJ_EMPTY) {
+      uint32_t const at = atomicAdd(&s_spec_n, 1u);
+      if (at < RJ_SPECIAL) s_spec_rows[at] = static_cast<int32_t>(row);
+      return;
+    }
+    uint32_t bkt = table_hash(key) >> bshift;
+    for (int guard = 0; guard < 2 * cap; ++guard) {
+      u64x2 const pr = *reinterpret_cast<u64x2 const volatile*>(keys + 2u * bkt);
+      int const e    = pr.x == RJ_EMPTY ? 0 : (pr.y == RJ_EMPTY ? 1 : -1);
+      if (e < 0) {
+        bkt = (bkt + 1) & bmask;
+        continue;
+      }
+      if (atomicCAS(reinterpret_cast<unsigned long long*>(keys + 2u * bkt + e), static_cast<unsigned long long>(RJ_EMPTY),
+                    static_cast<unsigned long long>(key)) == RJ_EMPTY) {
+        rows[2u * bkt + e] = row;
+        return;
+      }
+      // (lost the slot: read the bucket again)
+    }
+  };
+  // (the first 1024 rows of up to four slices are loaded before the table is ready: one round trip to HBM instead of four)
+  uint64_t bk[4];
+  uint32_t br[4];
+  bool bv[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    bv[s] = false;
+    if (upstream_ok && s < a.b_slices) {
+      int64_t const reg = static_cast<int64_t>(q) * a.b_slices + s;
+      int32_t const cnt = min(max(a.b_count[reg], 0), static_cast<int32_t>(a.b_cap));
+      bv[s]             = static_cast<int32_t>(threadIdx.x) < cnt;
+      if (bv[s]) {
+        bk[s] = gload(a.b_key + reg * a.b_cap + threadIdx.x);
+        br[s] = gload(a.b_row + reg * a.b_cap + threadIdx.x);
+      }
+    }
+  }
+  __syncthreads();  // (the table is empty everywhere)
+  uint32_t nb = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    if (bv[s]) {
+      insert(bk[s], br[s]);
+      ++nb;
+    }
+  for (int s = 0; upstream_ok && s < a.b_slices; ++s) {
+    int64_t const reg  = static_cast<int64_t>(q) * a.b_slices + s;
+    int32_t const cnt  = min(max(a.b_count[reg], 0), static_cast<int32_t>(a.b_cap));
+    int64_t const base = reg * a.b_cap;
+    for (int32_t i = threadIdx.x + (s < 4 ? B : 0); i < cnt; i += B) {
+      insert(gload(a.b_key + base + i), gload(a.b_row + base + i));
+      ++nb;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) nb += __shfl_down(nb, o);
+  if ((threadIdx.x & 63) == 0 && nb) atomicAdd(&s_nbuild, nb);
+  __syncthreads();
+  // a partition whose build rows do not fit (a heavily duplicated key, a wrong size estimate): the caller falls back
+  if (static_cast<int>(s_nbuild) > a.fill_limit || s_spec_n > RJ_SPECIAL) {
+    if (threadIdx.x == 0) {
+      atomicOr(a.overflow, 2);
+      if (!RETRIEVE) a.pair_counts[q] = 0;
+    }
+    return;
+  }
+  uint32_t const nspec = s_spec_n;
+  // ---- probe: the partition's probe rows past the table; a wave reserves the positions of its pairs with one LDS atomic
+  int const lane             = threadIdx.x & 63;
+  uint64_t const below       = (1ull << lane) - 1ull;
+  uint64_t* const stage      = a.stage + static_cast<int64_t>(q) * a.stage_cap;
+  auto put = [&](unsigned long long o, size_type prow, size_type brow) {
+    if constexpr (RETRIEVE) {
+      if (o < a.out_capacity) {
+        gstore(a.out_probe + o, prow);
+        gstore(a.out_build + o, brow);
+      }
+    } else {
+      if (o < static_cast<unsigned long long>(a.stage_cap))
+        gstore(stage + o, static_cast<uint64_t>(static_cast<uint32_t>(prow)) | (static_cast<uint64_t>(static_cast<uint32_t>(brow)) << 32));
+    }
+  };
+  auto emit2 = [&](size_type prow, bool w0, size_type b0, bool w1, size_type b1) {  // (every lane of the wave calls it)
+    unsigned long long const m0 = __ballot(w0), m1 = __ballot(w1);
+    if ((m0 | m1) == 0) return;
+    int const n0            = __popcll(m0);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&s_cursor, static_cast<unsigned long long>(n0 + __popcll(m1)));
+    base = __shfl(base, 0);
+    if (w0) put(base + __popcll(m0 & below), prow, b0);
+    if (w1) put(base + n0 + __popcll(m1 & below), prow, b1);
+  };
+  // one record of every lane the wave-uniform way: pairs are emitted while the chains are walked (any number of matches per row)
+  auto walk_and_emit = [&](bool live, uint64_t key, size_type prow) {
+    bool const special = live && key == RJ_EMPTY;
+    bool walking       = live && !special;
+    uint32_t bkt       = table_hash(key) >> bshift;
+    while (__any(walking)) {
+      u64x2 pr{RJ_EMPTY, RJ_EMPTY};
+      if (walking) pr = *reinterpret_cast<u64x2 const*>(keys + 2u * bkt);
+      bool const w0 = walking && pr.x == key, w1 = walking && pr.x != RJ_EMPTY && pr.y == key;
+      emit2(prow, w0, w0 ? static_cast<size_type>(rows[2u * bkt]) : 0, w1, w1 ? static_cast<size_type>(rows[2u * bkt + 1]) : 0);
+      walking = walking && pr.x != RJ_EMPTY && pr.y != RJ_EMPTY;  // an entry takes the first empty slot of its sequence
+      bkt     = (bkt + 1) & bmask;
+    }
+    if (nspec != 0 && __any(special))
+      for (uint32_t t = 0; t < nspec; ++t) emit2(prow, special, s_spec_rows[t], false, 0);
+  };
+  struct batch {
+    uint64_t k[RJ_RPT];
+    uint32_t w[RJ_RPT];
+  };
+  for (int s = 0; upstream_ok && s < a.p_slices; ++s) {
+    int64_t const reg  = static_cast<int64_t>(q) * a.p_slices + s;
+    int32_t const cnt  = min(max(a.p_count[reg], 0), static_cast<int32_t>(a.p_cap));
+    int64_t const base = reg * a.p_cap;
+    auto issue = [&](int32_t i0, batch& t) {
+#pragma unroll
+      for (int j = 0; j < RJ_RPT; ++j) {
+        int32_t const i = i0 + j * B + static_cast<int32_t>(threadIdx.x);
+        t.k[j]          = 0;
+        t.w[j]          = 0;
+        if (i < cnt) {
+          t.k[j] = gload(a.p_key + base + i);
+          t.w[j] = gload(a.p_row + base + i);
+        }
+      }
+    };
+    batch nxt;
+    issue(0, nxt);
+    for (int32_t i0 = 0; i0 < cnt; i0 += B * RJ_RPT) {  // (every lane runs every round: the ballots below are wave-wide)
+      batch const cur = nxt;
+      issue(i0 + B * RJ_RPT, nxt);  // (the next records are on their way while these walk the table)
+      // the four records of a lane walk their chains together - four independent LDS reads per step instead of one - and only
+      // note the first match and the number of matches
+      // Straight-line steps: a lane that is not walking reads the spare bucket behind the table (always empty) with a key no
+      // slot can equal, so that a step needs no branch: a bucket's second slot is taken only after its first, hence "the bucket
+      // is full" = "its second slot is not empty", and a key in the second slot implies the first is taken.
+      bool live[RJ_RPT];
+      uint64_t wk[RJ_RPT];
+      uint32_t bkt[RJ_RPT], at[RJ_RPT], nmatch[RJ_RPT], mslot[RJ_RPT], brow[RJ_RPT];
+      bool slow = false, any_walking = false;
+      uint32_t const spare = static_cast<uint32_t>(cap / 2);
+#pragma unroll
+      for (int j = 0; j < RJ_RPT; ++j) {
+        live[j]            = i0 + j * B + static_cast<int32_t>(threadIdx.x) < cnt;
+        bool const walking = live[j] && cur.k[j] != RJ_EMPTY;
+        slow               = slow || (live[j] && cur.k[j] == RJ_EMPTY && nspec != 0);
+        wk[j]              = walking ? cur.k[j] : ~RJ_EMPTY;
+        bkt[j]             = table_hash(cur.k[j]) >> bshift;
+        at[j]              = walking ? bkt[j] : spare;
+        nmatch[j]          = 0;
+        mslot[j]           = 0;
+        any_walking        = any_walking || walking;
+      }
+      while (any_walking) {
+        u64x2 pr[RJ_RPT];
+#pragma unroll
+        for (int j = 0; j < RJ_RPT; ++j) pr[j] = *reinterpret_cast<u64x2 const*>(keys + 2u * at[j]);
+        any_walking = false;
+#pragma unroll
+        for (int j = 0; j < RJ_RPT; ++j) {
+          bool const m0 = pr[j].x == wk[j], m1 = pr[j].y == wk[j], full = pr[j].y != RJ_EMPTY;
+          mslot[j]      = (m0 || m1) ? 2u * at[j] + (m0 ? 0u : 1u) : mslot[j];
+          nmatch[j] += (m0 ? 1u : 0u) + (m1 ? 1u : 0u);
+          bkt[j]      = (bkt[j] + 1) & bmask;
+          at[j]       = full ? bkt[j] : spare;
+          wk[j]       = full ? wk[j] : ~RJ_EMPTY;
+          any_walking = any_walking || full;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RJ_RPT; ++j) brow[j] = rows[mslot[j]];  // (meaningful where nmatch == 1)
+#pragma unroll
+      for (int j = 0; j < RJ_RPT; ++j) slow = slow || nmatch[j] > 1;
+      if (!__any(slow)) {
+        // at most one pair per record: one reservation for the wave's pairs of all four records
+        unsigned long long m[RJ_RPT];
+        int tot = 0;
+#pragma unroll
+        for (int j = 0; j < RJ_RPT; ++j) {
+          m[j] = __ballot(nmatch[j] == 1);
+          tot += __popcll(m[j]);
+        }
+        if (tot != 0) {
+          unsigned long long pos = 0;
+          if (lane == 0) pos = atomicAdd(&s_cursor, static_cast<unsigned long long>(tot));
+          pos = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(pos >> 32))) << 32) |
+                __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(pos));
+#pragma unroll
+          for (int j = 0; j < RJ_RPT; ++j) {
+            if (nmatch[j] == 1) put(pos + __popcll(m[j] & below), static_cast<size_type>(cur.w[j] + a.probe_row_base), static_cast<size_type>(brow[j]));
+            pos += __popcll(m[j]);
+          }
+        }
+      } else {
+        // a row with several matches, or the marker key: these records again, wave-uniform
+#pragma unroll
+        for (int j = 0; j < RJ_RPT; ++j) {
+          if (i0 + j * B >= cnt) break;  // (uniform)
+          walk_and_emit(live[j], cur.k[j], static_cast<size_type>(cur.w[j] + a.probe_row_base));
+        }
+      }
+    }
+  }
+  if constexpr (!RETRIEVE) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.pair_counts[q] = s_cursor;
+      if (s_cursor > static_cast<unsigned long long>(a.stage_cap)) atomicOr(a.overflow, 4);
+    }
+  }
+}
+
+// the staged pairs of every partition that fit its stage -> the output columns
+__global__ void __launch_bounds__(256) k_radix_emit_staged(radix_join_args const* __restrict__ ap)
+{
+  radix_join_args const& a = *ap;
+  int const q                  = blockIdx.x;
+  unsigned long long const off = a.pair_counts[q], n = a.pair_counts[q + 1] - off;
+  if (n > static_cast<unsigned long long>(a.stage_cap)) return;
+  uint64_t const* src = a.stage + static_cast<int64_t>(q) * a.stage_cap;
+  for (unsigned long long i0 = 0; i0 < n; i0 += 1024) {
+    uint64_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned long long const i = i0 + j * 256 + threadIdx.x;
+      v[j]                       = i < n ? gload(src + i) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned long long const i = i0 + j * 256 + threadIdx.x, o = off + i;
+      if (i < n && o < a.out_capacity) {
+        gstore(a.out_probe + o, static_cast<size_type>(static_cast<uint32_t>(v[j])));
+        gstore(a.out_build + o, static_cast<size_type>(static_cast<uint32_t>(v[j] >> 32)));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.P >= 16 && a.P <= 256 && (a.P & (a.P - 1)) == 0 && (a.P << a.capl) == RADIX_RING_SLOTS && a.capl >= 5 && a.shift >= 32 && a.shift < 64 &&
+                 a.region_cap % 32 == 0 && a.slices >= 1,
+               "radix join scatter: geometry");
+  CUDF_EXPECTS(a.level == 1 || (a.in_slices + a.slices - 1) / a.slices <= RADIX_MAX_REGION_LIST, "radix join scatter: region list too long");
+  std::size_t const lds = static_cast<std::size_t>(RADIX_RING_SLOTS) * 16 + 2048;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    for (void const* fn : {reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2>), reinterpret_cast<void const*>(&k_radix_scatter<2, 4, 2>)}) {
+      hipFuncAttributes attr{};
+      CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
+      CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
+    }
+  });
+  hipLaunchKernelGGL(k_store_radix_args<radix_scatter_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{a.level == 1 ? "join_partition" : "join_partition_level2", stream};
+  if (a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else hipLaunchKernelGGL((k_radix_scatter<2, 4, 2>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_radix_partition_max(int32_t const* region_count, int32_t nparts, int32_t slices, int32_t* out_max, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_radix_partition_max, dim3((nparts + 255) / 256), dim3(256), 0, stream, region_count, nparts, slices, out_max);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_radix_join(radix_join_args const& a, radix_join_args* d_args, bool retrieve, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.cap >= 64 && (a.cap & (a.cap - 1)) == 0 && a.cap * 12 + 2048 <= 160 * 1024 && a.nparts >= 1 && a.fill_limit >= 1 && a.fill_limit < a.cap &&
+                 a.stage != nullptr && a.stage_cap >= 1,
+               "radix join: table geometry");
+  std::size_t const lds = static_cast<std::size_t>(a.cap) * 12 + 16;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
+    for (void const* fn : {reinterpret_cast<void const*>(&k_radix_join<false>), reinterpret_cast<void const*>(&k_radix_join<true>)}) {
+      hipFuncAttributes attr{};
+      CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
+      CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
+    }
+  });
+  hipLaunchKernelGGL(k_store_radix_args<radix_join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{retrieve ? "join_retrieve" : "join_count", stream};
+  if (retrieve) hipLaunchKernelGGL(k_radix_join<true>, dim3(a.nparts), dim3(1024), lds, stream, d_args);
+  else hipLaunchKernelGGL(k_radix_join<false>, dim3(a.nparts), dim3(1024), lds, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_radix_emit_staged(radix_join_args const& a, radix_join_args* d_args, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_store_radix_args<radix_join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_retrieve", stream};
+  hipLaunchKernelGGL(k_radix_emit_staged, dim3(a.nparts), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cudf::detail::join

@@ -448,3 +448,105 @@ def test_fuzz_dense_joins_against_oracle(G, oracle, monkeypatch, seed):
             li, ri = G.join(left, right, nulls_equal=eq, kind=kind)
             el, er = oracle.join(left, right, nulls_equal=eq, kind=kind)
             assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er), (kind, eq)
+
+
+# ---------------------------------------------------------------- LDS radix join (big sparse single-int64-key inner joins)
+_RJ_EMPTY = np.array([0x7f4a7c159e3779b9], dtype=np.uint64).view(np.int64)[0]  # the radix join's empty-slot marker (radix_kernels.hip)
+
+
+@pytest.fixture
+def force_radix_join(monkeypatch):
+    """Makes small inputs take the LDS radix join (engine.hpp radix_join_args) that big sparse-key inner joins use."""
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE", "0")
+    monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_BUILD", "0")
+    monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_PROBE", "0")
+
+
+def _kernels_of(fn):
+    from cudf_amd import _lib
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    try:
+        out = fn()
+    finally:
+        _lib.profile_enable(False)
+    return out, {k: v[0] for k, v in _lib.profile_report().items()}  # {kernel: launches}
+
+
+@pytest.mark.parametrize("shape", ["unique", "duplicates", "nulls", "marker_key", "four_pairs_per_row"])
+def test_radix_join_matches_oracle(G, oracle, force_radix_join, shape):
+    """Both sides through the two scatter levels into 2048 LDS-sized partitions, then the per-partition LDS table: unique build
+    keys; duplicates on both sides (several pairs per probe row); 5 % NULLs with null_equality::UNEQUAL; rows whose key is the
+    table's empty-slot marker (they take the side list); every probe row matching four build rows (more pairs than the
+    partitions' stages hold: the retrieve pass joins those partitions again)."""
+    rng = np.random.default_rng({"unique": 1, "duplicates": 2, "nulls": 3, "marker_key": 4, "four_pairs_per_row": 5}[shape])
+    nl, nr = 700_000, 90_000
+    if shape == "four_pairs_per_row":
+        nr = 80_000
+        rk = np.repeat(np.arange(20_000, dtype=np.int64), 4) * 1_000_003
+        lk = rng.integers(0, 20_000, nl, dtype=np.int64) * 1_000_003
+    elif shape == "unique":
+        rk = rng.permutation(400_000)[:nr].astype(np.int64) * 1_000_003
+        lk = rng.integers(0, 800_000, nl, dtype=np.int64) * 1_000_003
+    else:
+        rk = rng.integers(0, 60_000, nr, dtype=np.int64) * 1_000_003 - 7
+        lk = np.where(rng.random(nl) < 0.3, rng.integers(0, 60_000, nl), rng.integers(60_000, 200_000, nl)).astype(np.int64) * 1_000_003 - 7
+    left, right = [lk], [rk]
+    nulls_equal = True
+    if shape == "nulls":
+        left, right, nulls_equal = [(lk, rng.random(nl) > 0.05)], [(rk, rng.random(nr) > 0.05)], False
+    if shape == "marker_key":
+        rk[[5, 77, 4000]] = _RJ_EMPTY
+        lk[rng.integers(0, nl, 50)] = _RJ_EMPTY
+    (li, ri), kernels = _kernels_of(lambda: G.join(left, right, nulls_equal=nulls_equal, kind="inner"))
+    assert "join_partition_level2" in kernels, kernels
+    el, er = oracle.join(left, right, nulls_equal=nulls_equal, kind="inner")
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+
+
+def test_radix_join_object_other_kinds_and_sizes(G, oracle, force_radix_join):
+    """A hash_join object whose build side took the radix partitions: inner joins go through them; left / full joins, the size
+    API and the match context build the open-addressing table on first need and agree with the oracle."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(202)
+    rk = rng.integers(0, 30_000, 40_000, dtype=np.int64) * 1_000_003
+    hj = HashJoin(cudf_amd.Table([G.to_device(rk)]), NullEquality.EQUAL)
+    for nl in (5, 70_000, 300_000):
+        lk = rng.integers(0, 60_000, nl, dtype=np.int64) * 1_000_003
+        t = cudf_amd.Table([G.to_device(lk)])
+        (li, ri), kernels = _kernels_of(lambda: hj.inner_join(t))
+        assert "join_partition_level2" in kernels
+        el, er = oracle.join([lk], [rk], nulls_equal=True, kind="inner")
+        assert kat.sorted_pairs(li.to_numpy()[0], ri.to_numpy()[0]) == kat.sorted_pairs(el, er)
+        assert hj.inner_join_size(t) == len(el)
+        for kind in ("left", "full"):
+            gl, gr = getattr(hj, kind + "_join")(t)
+            xl, xr = oracle.join([lk], [rk], nulls_equal=True, kind=kind)
+            assert kat.sorted_pairs(gl.to_numpy()[0], gr.to_numpy()[0]) == kat.sorted_pairs(xl, xr)
+
+
+def test_radix_join_hot_key_falls_back(G, oracle, force_radix_join):
+    """A build key with 20,000 rows: its partition does not fit the LDS table, the constructor keeps the open-addressing table.
+    A probe side whose rows mostly carry ONE key overflows that partition's regions: that call probes the table instead."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(203)
+    nl, nr = 300_000, 80_000
+    rk = rng.permutation(200_000)[:nr].astype(np.int64) * 1_000_003
+    lk = rng.integers(0, 200_000, nl, dtype=np.int64) * 1_000_003
+    hot = rk.copy()
+    hot[:20_000] = rk[7]
+    (li, ri), kernels = _kernels_of(lambda: G.join([lk], [hot], nulls_equal=True, kind="inner"))
+    assert kernels.get("join_partition_level2") == 1 and "join_build" in kernels, kernels  # (the build side tried, the probe side did not)
+    el, er = oracle.join([lk], [hot], nulls_equal=True, kind="inner")
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+    hj = HashJoin(cudf_amd.Table([G.to_device(rk)]), NullEquality.EQUAL)
+    lhot = lk.copy()
+    lhot[::2] = rk[11]
+    li, ri = hj.inner_join(cudf_amd.Table([G.to_device(lhot)]))
+    el, er = oracle.join([lhot], [rk], nulls_equal=True, kind="inner")
+    assert kat.sorted_pairs(li.to_numpy()[0], ri.to_numpy()[0]) == kat.sorted_pairs(el, er)
