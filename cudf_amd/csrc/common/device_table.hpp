@@ -72,6 +72,7 @@ device_table make_device_table(table_view const& t);
 // one 16-byte record: moves as global_load/store_dwordx4 and ds_read/write_b128
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <typename T>
 __device__ __forceinline__ T gload(T const* p)
 {

@@ -1,0 +1,153 @@
+// SPDX-License-Identifier: Apache-2.0
+// gfx950 kernels of the partitioned dense join (engine.hpp dense_part_args): the direct-address table of a dense build side
+// (join_args::dense_head) is hundreds of megabytes, and a random 4-byte access to it costs one trip over the fabric (45-60 G
+// requests/s on the whole chip; 3.2 ms for C3's 142M in-range probe rows, 2.1 ms for its 50M atomic exchanges). Partitioned by
+// key RANGE first (k_radix_scatter's dense mode: 8-byte records {offset, row}), the accesses of one partition fall into ONE
+// contiguous slice of the table (<= 1 MB) that stays in the L2 of the XCD whose workgroups walk that partition (blocks b and
+// b + 8 share an XCD: observed placement, used for speed only - bench_micro/l2_slice_micro.hip: 266 G random loads/s inside an
+// L2-sized window against 57 G/s over 200 MB).
+//   build : plain stores head[offset] = row, then one streaming count of the filled entries: as many as records <=> no key
+//           repeats (the caller runs the atomic-exchange build when they differ);
+//   probe : head[offset] per record; the pairs of a region are staged like the radix join's (k_radix_emit_staged copies them).
+// Replaces, for big inner joins on a dense unique build key, k_dense_build / k_dense_count / k_dense_retrieve (kernels.hip); the
+// reference structure is cuco::static_multiset insert + count + retrieve (cpp/src/join/hash_join/hash_join.cu:62-149).
+#include "engine.hpp"
+#include "../common/profiler.hpp"
+
+#include <cudf/utilities/error.hpp>
+
+namespace cudf::detail::join {
+namespace {
+
+__global__ void k_store_dense_part_args(dense_part_args v, dense_part_args* dst) { *dst = v; }
+
+// workgroup b serves the partitions p = b % 8, b % 8 + 8, ... (one XCD's share); within a partition the regions s = b / 8,
+// b / 8 + gridDim.x / 8, ...
+template <typename F>
+__device__ __forceinline__ void for_each_region(dense_part_args const& a, F&& f)
+{
+  int const cls = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+  for (int p = cls; p < a.P; p += 8)
+    for (int s = w; s < a.S; s += W) f(static_cast<int64_t>(p) * a.S + s);
+}
+
+__global__ void __launch_bounds__(256) k_dense_part_store(dense_part_args const* __restrict__ ap)
+{
+  dense_part_args const& a = *ap;
+  if (*a.overflow != 0) return;
+  for_each_region(a, [&](int64_t reg) {
+    int32_t const cnt   = min(max(a.region_count[reg], 0), static_cast<int32_t>(a.region_cap));
+    uint64_t const* rec = a.recs + reg * a.region_cap;
+    for (int32_t i0 = 0; i0 < cnt; i0 += 256 * 4) {
+      uint64_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int32_t const i = i0 + j * 256 + static_cast<int32_t>(threadIdx.x);
+        v[j]            = i < cnt ? gload(rec + i) : ~uint64_t{0};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + j * 256 + static_cast<int32_t>(threadIdx.x) < cnt) gstore(a.head + static_cast<uint32_t>(v[j]), static_cast<int32_t>(v[j] >> 32));
+    }
+  });
+}
+
+// entries of head[0, n) that hold a row (>= 0) -> *out (preset to 0)
+__global__ void __launch_bounds__(256) k_dense_count_filled(int32_t const* __restrict__ head, uint64_t n, unsigned long long* out)
+{
+  unsigned long long c = 0;
+  uint64_t const n4 = n / 4, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < n4; i += stride) {
+    i32x4 const v = gload(reinterpret_cast<i32x4 const*>(head) + i);
+    c += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) c += head[n4 * 4 + threadIdx.x] >= 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+__global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const* __restrict__ ap)
+{
+  dense_part_args const& a = *ap;
+  __shared__ unsigned long long s_cursor;
+  bool const ok            = *a.overflow == 0;
+  int const lane           = threadIdx.x & 63;
+  uint64_t const below     = (1ull << lane) - 1ull;
+  for_each_region(a, [&](int64_t reg) {
+    __syncthreads();  // (the previous region's cursor has been read)
+    if (threadIdx.x == 0) s_cursor = 0;
+    __syncthreads();
+    int32_t const cnt   = ok ? min(max(a.region_count[reg], 0), static_cast<int32_t>(a.region_cap)) : 0;
+    uint64_t const* rec = a.recs + reg * a.region_cap;
+    uint64_t* stage     = a.stage + reg * a.region_cap;
+    for (int32_t i0 = 0; i0 < cnt; i0 += 256 * 4) {  // (uniform trip count: the ballots below are wave-wide)
+      uint64_t v[4];
+      int32_t h[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int32_t const i = i0 + j * 256 + static_cast<int32_t>(threadIdx.x);
+        v[j]            = i < cnt ? gload(rec + i) : ~uint64_t{0};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = -1;
+        if (i0 + j * 256 + static_cast<int32_t>(threadIdx.x) < cnt) h[j] = gload(a.head + static_cast<uint32_t>(v[j]));
+      }
+      unsigned long long m[4];
+      int tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        m[j] = __ballot(h[j] >= 0);
+        tot += __popcll(m[j]);
+      }
+      if (tot != 0) {
+        unsigned long long pos = 0;
+        if (lane == 0) pos = atomicAdd(&s_cursor, static_cast<unsigned long long>(tot));
+        pos = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(pos >> 32))) << 32) |
+              __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(pos));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (h[j] >= 0) {
+            uint32_t const prow = static_cast<uint32_t>(static_cast<int64_t>(v[j] >> 32) + a.probe_row_base);
+            gstore(stage + pos + __popcll(m[j] & below), static_cast<uint64_t>(prow) | (static_cast<uint64_t>(static_cast<uint32_t>(h[j])) << 32));
+          }
+          pos += __popcll(m[j]);
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.pair_counts[reg] = s_cursor;
+  });
+}
+
+}  // namespace
+
+int32_t dense_part_grid() { return 1024; }  // 4 workgroups of 256 threads per CU, all resident: 128 per XCD
+
+void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.P >= 1 && a.S >= 1 && a.recs != nullptr && a.head != nullptr && a.overflow != nullptr, "partitioned dense join: arguments");
+  hipLaunchKernelGGL(k_store_dense_part_args, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_build", stream};
+  hipLaunchKernelGGL(k_dense_part_store, dim3(dense_part_grid()), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long long* out, hipStream_t stream)
+{
+  cudf::detail::prof::scope prof_{"join_build", stream};
+  hipLaunchKernelGGL(k_dense_count_filled, dim3(2048), dim3(256), 0, stream, head, n, out);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_dense_part_lookup(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.P >= 1 && a.S >= 1 && a.recs != nullptr && a.head != nullptr && a.overflow != nullptr && a.stage != nullptr && a.pair_counts != nullptr,
+               "partitioned dense join: arguments");
+  hipLaunchKernelGGL(k_store_dense_part_args, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_count", stream};
+  hipLaunchKernelGGL(k_dense_part_lookup, dim3(dense_part_grid()), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cudf::detail::join

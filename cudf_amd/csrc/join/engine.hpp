@@ -125,6 +125,11 @@ struct radix_scatter_args {
   int64_t region_cap; // a multiple of 32 records
   int32_t* region_count;
   int32_t* overflow;  // bit 0: a region overflowed
+  // Dense mode (level 1; dense_part_args below): rows become ONE stream of 8-byte records {key - dense_lo | row id << 32} in
+  // out_key, partitioned by the top bits of the offset (digit = offset >> shift); keys outside the range are dropped.
+  int32_t dense;
+  uint64_t dense_lo, dense_range;
+  int32_t pending_budget;  // dense: a workgroup whose rings made it wait more often than this (net of tiles) reports overflow
 };
 struct radix_join_args {
   uint64_t const* b_key;   // build partitions: regions (q, s), s < b_slices
@@ -158,6 +163,25 @@ void launch_radix_partition_max(int32_t const* region_count, int32_t nparts, int
 void launch_radix_join(radix_join_args const& a, radix_join_args* d_args, bool retrieve, hipStream_t stream);
 // copies the staged pairs of every partition that fit its stage to out_probe / out_build (pair_counts holds the exclusive prefix)
 void launch_radix_emit_staged(radix_join_args const& a, radix_join_args* d_args, hipStream_t stream);
+
+// ---- Partitioned dense join (dense_part_kernels.hip; round 3): big inner joins on a dense UNIQUE build key. Both sides go through
+// launch_radix_scatter's dense mode - 8-byte records {key - dense_lo | row << 32} in regions (p, s), p = offset >> shift: one
+// contiguous slice of the direct-address table per partition - so that the random accesses of a partition stay inside one XCD's L2.
+struct dense_part_args {
+  uint64_t const* recs;         // regions (p, s) at (p * S + s) * region_cap
+  int32_t const* region_count;  // [P * S]
+  int64_t region_cap;
+  int32_t P, S;
+  int32_t* head;                // the direct-address table (join_args::dense_head, unique keys: head[offset] = build row or -1)
+  int32_t const* overflow;      // the scatter's flag: nothing is done when it is set
+  // lookup only: the pairs of region r are staged at stage[r * region_cap ...), pair_counts[r] = their number
+  unsigned long long* pair_counts;
+  uint64_t* stage;
+  int64_t probe_row_base;
+};
+void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);
+void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long long* out, hipStream_t stream);
+void launch_dense_part_lookup(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);
 
 void launch_build(join_args const& a, join_args* d_args, hipStream_t stream);
 // minimum and maximum of the valid keys of the (single 8-byte integer) build column: out[0] = min, out[1] = max (bit patterns);

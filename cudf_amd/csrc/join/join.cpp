@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <vector>
 #include <optional>
 #include <cmath>
 #include <cstdlib>
@@ -127,6 +128,8 @@ class hash_join_impl {
         rmm::device_buffer dups{sizeof(int32_t), s, tmp};
         CUDF_HIP_TRY(hipMemsetAsync(dups.data(), 0, sizeof(int32_t), s));
         _dense       = true;
+        // big tables: rows partitioned by key range, plain stores that stay in L2, uniqueness from a count (dense_part_kernels.hip)
+        if (try_dense_part_build(right, stream)) return;
         join_args b  = base_args(right, 0);
         b.dense_dups = static_cast<int32_t*>(dups.data());
         join::launch_dense_build(b, static_cast<join_args*>(d_args.data()), s);
@@ -358,6 +361,151 @@ class hash_join_impl {
     return join_index_pair{std::move(out_l), std::move(out_r)};
   }
 
+  // ---- partitioned dense join (engine.hpp dense_part_args)
+  struct dense_side {
+    rmm::device_buffer recs, counts, ovf;
+    int64_t cap{0};
+    int32_t P{0}, S{0};
+  };
+  // rows -> records {key - lo | row << 32} in regions (partition, slice); `expected` = the rows a slice may have to take
+  void dense_partition(uint64_t const* keys, bitmask_type const* mask, int64_t mask_offset, int64_t nrows, dense_side& out, stream_ref stream) const
+  {
+    hipStream_t const s = stream.value();
+    auto tmp            = cudf::get_current_device_resource_ref();
+    auto log2c = [](uint64_t v) { int l = 0; while ((uint64_t{1} << l) < v) ++l; return l; };
+    // slices of >= 1 MB (CUDF_AMD_JOIN_DENSE_PART_SLICE_LOG2: keys per slice, the tests shrink it), at most 256 of them
+    int const shift     = std::max(static_cast<int>(env_flag("CUDF_AMD_JOIN_DENSE_PART_SLICE_LOG2", 18)), log2c(_dense_range) - 8);
+    int64_t const P     = static_cast<int64_t>((_dense_range - 1) >> shift) + 1;
+    int64_t Pring = 16;
+    while (Pring < P) Pring <<= 1;
+    int64_t const tiles = (nrows + 4095) / 4096, S = std::clamp<int64_t>(tiles, 1, 256);
+    double const mean   = static_cast<double>(std::min<int64_t>(nrows, (tiles + S - 1) / S * 4096)) / static_cast<double>(P);
+    int64_t const cap   = (static_cast<int64_t>(mean * 1.02 + 6.0 * std::sqrt(std::max(mean, 1.0)) + 64.0) + 31) / 32 * 32;
+    out.recs   = rmm::device_buffer{static_cast<std::size_t>(Pring * S * cap) * sizeof(uint64_t), s, tmp};
+    out.counts = rmm::device_buffer{static_cast<std::size_t>(Pring * S) * sizeof(int32_t), s, tmp};
+    out.ovf    = rmm::device_buffer{sizeof(int32_t), s, tmp};
+    out.cap    = cap;
+    out.P      = static_cast<int32_t>(Pring);
+    out.S      = static_cast<int32_t>(S);
+    CUDF_HIP_TRY(hipMemsetAsync(out.counts.data(), 0, out.counts.size(), s));
+    CUDF_HIP_TRY(hipMemsetAsync(out.ovf.data(), 0, sizeof(int32_t), s));
+    join::radix_scatter_args a{};
+    a.level          = 1;
+    a.keys           = keys;
+    a.mask           = mask;
+    a.mask_offset    = mask_offset;
+    a.nrows          = nrows;
+    a.P              = static_cast<int32_t>(Pring);
+    a.capl           = 14 - log2c(static_cast<uint64_t>(Pring));  // 16384 ring slots of 8 bytes
+    a.shift          = shift;
+    a.slices         = static_cast<int32_t>(S);
+    a.out_key        = static_cast<uint64_t*>(out.recs.data());
+    a.region_cap     = cap;
+    a.region_count   = static_cast<int32_t*>(out.counts.data());
+    a.overflow       = static_cast<int32_t*>(out.ovf.data());
+    a.dense          = 1;
+    a.dense_lo       = _dense_lo;
+    a.dense_range    = _dense_range;
+    a.pending_budget = 64;
+    rmm::device_buffer d_args{sizeof(join::radix_scatter_args), s, tmp};
+    join::launch_radix_scatter(a, static_cast<join::radix_scatter_args*>(d_args.data()), s);
+  }
+  join::dense_part_args dense_part_args_of(dense_side const& side) const
+  {
+    join::dense_part_args a{};
+    a.recs         = static_cast<uint64_t const*>(side.recs.data());
+    a.region_count = static_cast<int32_t const*>(side.counts.data());
+    a.region_cap   = side.cap;
+    a.P            = side.P;
+    a.S            = side.S;
+    a.head         = const_cast<int32_t*>(static_cast<int32_t const*>(_dense_head.data()));
+    a.overflow     = static_cast<int32_t const*>(side.ovf.data());
+    return a;
+  }
+  // the dense table of a big build side without atomics; false: a key repeats (or the rows cluster): the caller builds it the
+  // other way (head is all -1 again)
+  bool try_dense_part_build(table_view const& right, stream_ref stream)
+  {
+    auto const& col    = right.column(0);
+    int64_t const rows = right.num_rows();
+    if (env_flag("CUDF_AMD_JOIN_DENSE_PART", 1) == 0 || rows < env_flag("CUDF_AMD_JOIN_DENSE_PART_MIN_BUILD", 4 << 20) ||
+        static_cast<int64_t>(_dense_range) < env_flag("CUDF_AMD_JOIN_DENSE_PART_MIN_RANGE", 8 << 20) || rows > (int64_t{1} << 31) - 1)
+      return false;
+    hipStream_t const s = stream.value();
+    auto tmp            = cudf::get_current_device_resource_ref();
+    dense_side side;
+    dense_partition(col.data<uint64_t>(), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
+    auto a = dense_part_args_of(side);
+    rmm::device_buffer d_args{sizeof(join::dense_part_args), s, tmp}, filled{sizeof(unsigned long long), s, tmp};
+    CUDF_HIP_TRY(hipMemsetAsync(filled.data(), 0, sizeof(unsigned long long), s));
+    join::launch_dense_part_store(a, static_cast<join::dense_part_args*>(d_args.data()), s);
+    join::launch_dense_count_filled(a.head, _dense_range, static_cast<unsigned long long*>(filled.data()), s);
+    std::vector<int32_t> h_counts(static_cast<std::size_t>(side.P) * static_cast<std::size_t>(side.S));
+    unsigned long long h_filled = 0;
+    int32_t h_ovf               = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(h_counts.data(), side.counts.data(), side.counts.size(), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_filled, filled.data(), sizeof(h_filled), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, side.ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long records = 0;
+    for (int32_t c : h_counts) records += static_cast<unsigned long long>(std::max(c, 0));
+    if (h_ovf != 0 || records != h_filled) {
+      CUDF_HIP_TRY(hipMemsetAsync(_dense_head.data(), 0xff, _dense_head.size(), s));
+      return false;
+    }
+    _dense_has_dups = false;
+    _dense_part     = true;
+    return true;
+  }
+  // inner join of a big probe side against the dense unique table; nullopt: this probe side does not take it
+  std::optional<join_index_pair> dense_part_probe(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr, int64_t row_base) const
+  {
+    auto const& col        = left.column(0);
+    bool const probe_nulls = _has_nulls && col.has_nulls();
+    int64_t const rows     = left.num_rows();
+    if (!is_single64(left) || (probe_nulls && _nulls_equal == null_equality::EQUAL) ||
+        rows < env_flag("CUDF_AMD_JOIN_DENSE_PART_MIN_PROBE", 8 << 20) || rows > (int64_t{1} << 31) - 1)
+      return std::nullopt;
+    hipStream_t const s = stream.value();
+    auto tmp            = cudf::get_current_device_resource_ref();
+    dense_side side;
+    dense_partition(col.data<uint64_t>(), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
+    auto a                     = dense_part_args_of(side);
+    std::size_t const nregions = static_cast<std::size_t>(side.P) * static_cast<std::size_t>(side.S);
+    rmm::device_buffer counts{(nregions + 1) * sizeof(unsigned long long), s, tmp}, stage{nregions * static_cast<std::size_t>(side.cap) * sizeof(uint64_t), s, tmp},
+      d_args{sizeof(join::dense_part_args), s, tmp};
+    a.pair_counts    = static_cast<unsigned long long*>(counts.data());
+    a.stage          = static_cast<uint64_t*>(stage.data());
+    a.probe_row_base = row_base;
+    join::launch_dense_part_lookup(a, static_cast<join::dense_part_args*>(d_args.data()), s);
+    join_args sc{};
+    sc.block_counts = a.pair_counts;
+    sc.nblocks      = static_cast<int32_t>(nregions);
+    join::launch_scan(sc, s);
+    unsigned long long total = 0;
+    int32_t h_ovf            = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(&total, a.pair_counts + nregions, sizeof(total), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, side.ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    if (h_ovf != 0) return std::nullopt;
+    CUDF_EXPECTS(total <= static_cast<unsigned long long>(std::numeric_limits<size_type>::max()),
+                 "Join result exceeds the maximum column size; use the *_join_size API and chunk the probe side.", std::overflow_error);
+    auto out_l = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(total), s, mr);
+    auto out_r = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(total), s, mr);
+    join::radix_join_args e{};  // (the copy of the staged pairs is the radix join's)
+    e.nparts       = static_cast<int32_t>(nregions);
+    e.pair_counts  = a.pair_counts;
+    e.stage        = a.stage;
+    e.stage_cap    = side.cap;
+    e.out_probe    = out_l->data();
+    e.out_build    = out_r->data();
+    e.out_capacity = total;
+    rmm::device_buffer d_args2{sizeof(join::radix_join_args), s, tmp};
+    join::launch_radix_emit_staged(e, static_cast<join::radix_join_args*>(d_args2.data()), s);
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    return join_index_pair{std::move(out_l), std::move(out_r)};
+  }
+
   void ensure_classic(stream_ref stream) const
   {
     std::lock_guard<std::mutex> g{_classic_mu};
@@ -472,6 +620,14 @@ class hash_join_impl {
     hipStream_t const s = stream.value();
     if (_radix && k == 0) {  // big inner joins on one 8-byte key: both sides in LDS-sized partitions (engine.hpp)
       auto r = radix_probe(left, stream, mr, row_base);
+      if (r.has_value()) {
+        if (output_size.has_value())
+          CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
+        return std::move(*r);
+      }
+    }
+    if (_dense_part && k == 0) {  // big inner joins on a dense unique key: probe rows partitioned by key range (engine.hpp)
+      auto r = dense_part_probe(left, stream, mr, row_base);
       if (r.has_value()) {
         if (output_size.has_value())
           CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
@@ -674,7 +830,7 @@ class hash_join_impl {
   bool _radix{false};
   int32_t _rx_nparts{0};
   radix_side _rx_build{};
-  bool _dense{false}, _dense_has_dups{false};
+  bool _dense{false}, _dense_has_dups{false}, _dense_part{false};
   uint64_t _dense_lo{0}, _dense_range{0};
   rmm::device_buffer _dense_head{}, _dense_next{};
 };

@@ -30,20 +30,24 @@ __device__ __forceinline__ uint64_t radix_hash(uint64_t key) { return mix64(0x9e
 
 constexpr int RADIX_MAX_REGION_LIST = 256;
 
-template <int LEVEL, int RPT, int D>
+// DENSE (level 1 only; the dense direct-address join's partition pass, dense_part_kernels.hip): a row is the ONE 8-byte record
+// {key - dense_lo (32 bits) | row id << 32}, its partition the top bits of that offset (a contiguous slice of the direct-address
+// table); rows whose key lies outside [dense_lo, dense_lo + dense_range) are dropped like NULL rows. No row-id stream.
+template <int LEVEL, int RPT, int D, bool DENSE>
 __global__ void __launch_bounds__(1024) k_radix_scatter(radix_scatter_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  __shared__ int s_pending, s_abort;
+  __shared__ int s_pending, s_abort, s_rounds;
   __shared__ int32_t s_pre[RADIX_MAX_REGION_LIST + 1];
   radix_scatter_args const& a = *ap;
   constexpr int B = 1024;
   constexpr uint32_t G = 16, GT = 32, TPL = 4;  // keys / row ids per 128-byte granule; row ids per lane of a flush (16 bytes)
   int const P = a.P, capl = a.capl;
   uint32_t const CAP = 1u << capl, cmask = CAP - 1u, tcmask = (CAP << 1) - 1u;
+  uint32_t const nslots = static_cast<uint32_t>(P) << capl;
   uint64_t* rkey  = reinterpret_cast<uint64_t*>(lds_raw);                        // [P << capl]
-  uint32_t* rrow  = reinterpret_cast<uint32_t*>(rkey + RADIX_RING_SLOTS);         // [P << (capl + 1)]
-  uint32_t* tail  = rrow + 2 * RADIX_RING_SLOTS;                                  // [P] next virtual position
+  uint32_t* rrow  = reinterpret_cast<uint32_t*>(rkey + nslots);                   // [P << (capl + 1)] (not DENSE)
+  uint32_t* tail  = rrow + (DENSE ? 0u : 2u * nslots);                            // [P] next virtual position
   uint32_t* limit = tail + P;                                                     // [P] head + CAP as of the last flush
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
   int const PW = P / nwaves;  // partitions owned by a wave (1 ... 16)
@@ -55,6 +59,7 @@ __global__ void __launch_bounds__(1024) k_radix_scatter(radix_scatter_args const
   if (threadIdx.x == 0) {
     s_pending = 0;
     s_abort   = 0;
+    s_rounds  = 0;
   }
   constexpr int64_t T = static_cast<int64_t>(B) * RPT;
   int item = blockIdx.x, seg = 0;
@@ -150,7 +155,7 @@ __global__ void __launch_bounds__(1024) k_radix_scatter(radix_scatter_args const
         }
       }
     }
-    for (int b = 0; b * 8 < PW; ++b) {  // row ids: 8 lanes per granule (four ids per lane)
+    for (int b = 0; !DENSE && b * 8 < PW; ++b) {  // row ids: 8 lanes per granule (four ids per lane)
       int const pl = b * 8 + (lane >> 3), sub = lane & 7;
       uint32_t const mr = __shfl(nrect, pl), mh = __shfl(headt, pl);
       int const mab     = __shfl(ab, pl);
@@ -178,8 +183,8 @@ __global__ void __launch_bounds__(1024) k_radix_scatter(radix_scatter_args const
     }
   };
   auto put = [&](uint32_t d, uint32_t pos, uint64_t key, uint32_t rowid) {
-    rkey[(d << capl) + (pos & cmask)]        = key;
-    rrow[(d << (capl + 1)) + (pos & tcmask)] = rowid;
+    rkey[(d << capl) + (pos & cmask)] = key;
+    if constexpr (!DENSE) rrow[(d << (capl + 1)) + (pos & tcmask)] = rowid;
   };
 
   tile_regs pre[D];
@@ -203,7 +208,14 @@ __global__ void __launch_bounds__(1024) k_radix_scatter(radix_scatter_args const
         } else {
           rowid[k] = pre[j].r[k];
         }
-        d[k] = keep[k] ? static_cast<uint32_t>(radix_hash(key[k]) >> shift) & pmask : 0u;
+        if constexpr (DENSE) {
+          uint64_t const off = key[k] - a.dense_lo;
+          keep[k]            = keep[k] && off < a.dense_range;
+          d[k]               = keep[k] ? static_cast<uint32_t>(off >> shift) : 0u;
+          key[k]             = off | (static_cast<uint64_t>(rowid[k]) << 32);
+        } else {
+          d[k] = keep[k] ? static_cast<uint32_t>(radix_hash(key[k]) >> shift) & pmask : 0u;
+        }
       }
       issue(t0 + D * step, pre[j]);
       if (t0 >= end) break;  // (uniform)
@@ -229,9 +241,15 @@ __global__ void __launch_bounds__(1024) k_radix_scatter(radix_scatter_args const
       lds_barrier();
       flush(false);
       lds_barrier();
+      if (DENSE && threadIdx.x == 0 && s_rounds > 0) --s_rounds;  // (a tile without a wait pays one back)
       while (s_pending) {  // a ring was full: its granules are flushed by now, the waiting rows go in
         lds_barrier();
-        if (threadIdx.x == 0) s_pending = 0;
+        if (threadIdx.x == 0) {
+          s_pending = 0;
+          // (DENSE: rows that arrive sorted or clustered by key fill one ring tile after tile; the caller's direct path is the
+          // better one for them - give up once the waiting rounds outnumber the tiles)
+          if (DENSE && ++s_rounds > a.pending_budget) s_abort = 1;
+        }
         lds_barrier();
         any_pend = false;
 #pragma unroll
@@ -559,14 +577,19 @@ __global__ void __launch_bounds__(256) k_radix_emit_staged(radix_join_args const
 
 void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_args, hipStream_t stream)
 {
-  CUDF_EXPECTS(a.P >= 16 && a.P <= 256 && (a.P & (a.P - 1)) == 0 && (a.P << a.capl) == RADIX_RING_SLOTS && a.capl >= 5 && a.shift >= 32 && a.shift < 64 &&
-                 a.region_cap % 32 == 0 && a.slices >= 1,
+  bool const dense = a.dense != 0;
+  CUDF_EXPECTS(a.P >= 16 && a.P <= 256 && (a.P & (a.P - 1)) == 0 && a.capl >= 5 && a.shift < 64 && a.region_cap % 32 == 0 && a.slices >= 1,
+               "radix join scatter: geometry");
+  CUDF_EXPECTS(dense ? (a.level == 1 && (a.P << a.capl) <= 2 * RADIX_RING_SLOTS && a.dense_range <= (uint64_t{1} << 32) &&
+                        ((a.dense_range - 1) >> a.shift) < static_cast<uint64_t>(a.P))
+                     : ((a.P << a.capl) == RADIX_RING_SLOTS && a.shift >= 32),
                "radix join scatter: geometry");
   CUDF_EXPECTS(a.level == 1 || (a.in_slices + a.slices - 1) / a.slices <= RADIX_MAX_REGION_LIST, "radix join scatter: region list too long");
-  std::size_t const lds = static_cast<std::size_t>(RADIX_RING_SLOTS) * 16 + 2048;
+  std::size_t const lds = static_cast<std::size_t>(a.P << a.capl) * (dense ? 8 : 16) + 2048;
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
-    for (void const* fn : {reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2>), reinterpret_cast<void const*>(&k_radix_scatter<2, 4, 2>)}) {
+    for (void const* fn : {reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false>), reinterpret_cast<void const*>(&k_radix_scatter<2, 4, 2, false>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true>)}) {
       hipFuncAttributes attr{};
       CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
       CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
@@ -574,8 +597,9 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
   });
   hipLaunchKernelGGL(k_store_radix_args<radix_scatter_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{a.level == 1 ? "join_partition" : "join_partition_level2", stream};
-  if (a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2>), dim3(a.slices), dim3(1024), lds, stream, d_args);
-  else hipLaunchKernelGGL((k_radix_scatter<2, 4, 2>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
+  if (dense) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else hipLaunchKernelGGL((k_radix_scatter<2, 4, 2, false>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 

@@ -550,3 +550,65 @@ def test_radix_join_hot_key_falls_back(G, oracle, force_radix_join):
     li, ri = hj.inner_join(cudf_amd.Table([G.to_device(lhot)]))
     el, er = oracle.join([lhot], [rk], nulls_equal=True, kind="inner")
     assert kat.sorted_pairs(li.to_numpy()[0], ri.to_numpy()[0]) == kat.sorted_pairs(el, er)
+
+
+# ---------------------------------------------------------------- partitioned dense join (big inner joins on a dense unique key)
+@pytest.fixture
+def force_dense_part(monkeypatch):
+    """Makes small inputs take the partitioned dense join (engine.hpp dense_part_args) that big dense-key inner joins use."""
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_MIN_BUILD", "0")
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_MIN_RANGE", "0")
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_MIN_PROBE", "0")
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_SLICE_LOG2", "10")
+
+
+@pytest.mark.parametrize("shape", ["unique", "nulls", "negative", "one_partition"])
+def test_dense_part_join_matches_oracle(G, oracle, force_dense_part, monkeypatch, shape):
+    """Unique dense build keys, probe keys inside and outside the build range (the latter are dropped by the partition pass),
+    5 % NULLs on both sides (UNEQUAL), negative keys, a range that is a single slice."""
+    rng = np.random.default_rng({"unique": 11, "nulls": 12, "negative": 13, "one_partition": 14}[shape])
+    nl, nr = 600_000, 150_000
+    span = 200_000
+    if shape == "one_partition":
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_SLICE_LOG2", "18")
+    base = -123_456_789 if shape == "negative" else 1_000
+    rk = rng.permutation(span)[:nr].astype(np.int64) + base
+    lk = rng.integers(-50_000, span + 50_000, nl, dtype=np.int64) + base
+    left, right, nulls_equal = [lk], [rk], True
+    if shape == "nulls":
+        left, right, nulls_equal = [(lk, rng.random(nl) > 0.05)], [(rk, rng.random(nr) > 0.05)], False
+    (li, ri), kernels = _kernels_of(lambda: G.join(left, right, nulls_equal=nulls_equal, kind="inner"))
+    assert kernels.get("join_partition") == 2, kernels  # (the build side and the probe side)
+    el, er = oracle.join(left, right, nulls_equal=nulls_equal, kind="inner")
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+
+
+def test_dense_part_join_fallbacks(G, oracle, force_dense_part):
+    """A repeated build key: the count of filled table entries differs from the number of rows and the atomic-exchange build (then
+    the row lists) takes over. Probe rows sorted by key fill one ring tile after tile: that call takes the direct pass."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(15)
+    nl, nr = 500_000, 120_000
+    rk = rng.permutation(160_000)[:nr].astype(np.int64)
+    lk = rng.integers(0, 200_000, nl, dtype=np.int64)
+    dup = rk.copy()
+    dup[1000] = dup[5]
+    (li, ri), kernels = _kernels_of(lambda: G.join([lk], [dup], nulls_equal=True, kind="inner"))
+    assert kernels.get("join_partition") == 1, kernels
+    el, er = oracle.join([lk], [dup], nulls_equal=True, kind="inner")
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+    hj = HashJoin(cudf_amd.Table([G.to_device(rk)]), NullEquality.EQUAL)
+    for probe in (np.sort(lk), lk):
+        t = cudf_amd.Table([G.to_device(probe)])
+        gl, gr = hj.inner_join(t)
+        el, er = oracle.join([probe], [rk], nulls_equal=True, kind="inner")
+        assert kat.sorted_pairs(gl.to_numpy()[0], gr.to_numpy()[0]) == kat.sorted_pairs(el, er)
+        assert hj.inner_join_size(t) == len(el)
+    for kind in ("left", "full"):
+        gl, gr = getattr(hj, kind + "_join")(cudf_amd.Table([G.to_device(lk)]))
+        xl, xr = oracle.join([lk], [rk], nulls_equal=True, kind=kind)
+        assert kat.sorted_pairs(gl.to_numpy()[0], gr.to_numpy()[0]) == kat.sorted_pairs(xl, xr)
