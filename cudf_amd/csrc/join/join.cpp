@@ -378,8 +378,11 @@ class hash_join_impl {
     int64_t const P     = static_cast<int64_t>((_dense_range - 1) >> shift) + 1;
     int64_t Pring = 16;
     while (Pring < P) Pring <<= 1;
-    int64_t const tiles = (nrows + 4095) / 4096, S = std::clamp<int64_t>(tiles, 1, 256);
-    double const mean   = static_cast<double>(std::min<int64_t>(nrows, (tiles + S - 1) / S * 4096)) / static_cast<double>(P);
+    // CUDF_AMD_JOIN_DENSE_PART_BLOCK=512: two workgroups of 512 threads per CU (8192 ring slots each) instead of one of 1024 - measured
+    // 8 % slower on C3 (1.73 against 1.60 ms for both scatters), kept for the record (profiles/r3_c3_dense_part.txt)
+    int64_t const block = env_flag("CUDF_AMD_JOIN_DENSE_PART_BLOCK", 1024) == 512 ? 512 : 1024, tile_rows = block * 4;
+    int64_t const tiles = (nrows + tile_rows - 1) / tile_rows, S = std::clamp<int64_t>(tiles, 1, block == 512 ? 512 : 256);
+    double const mean   = static_cast<double>(std::min<int64_t>(nrows, (tiles + S - 1) / S * tile_rows)) / static_cast<double>(P);
     int64_t const cap   = (static_cast<int64_t>(mean * 1.02 + 6.0 * std::sqrt(std::max(mean, 1.0)) + 64.0) + 31) / 32 * 32;
     out.recs   = rmm::device_buffer{static_cast<std::size_t>(Pring * S * cap) * sizeof(uint64_t), s, tmp};
     out.counts = rmm::device_buffer{static_cast<std::size_t>(Pring * S) * sizeof(int32_t), s, tmp};
@@ -396,7 +399,8 @@ class hash_join_impl {
     a.mask_offset    = mask_offset;
     a.nrows          = nrows;
     a.P              = static_cast<int32_t>(Pring);
-    a.capl           = 14 - log2c(static_cast<uint64_t>(Pring));  // 16384 ring slots of 8 bytes
+    a.capl           = (block == 512 ? 13 : 14) - log2c(static_cast<uint64_t>(Pring));  // 16384 (8192) ring slots of 8 bytes
+    a.block          = static_cast<int32_t>(block);
     a.shift          = shift;
     a.slices         = static_cast<int32_t>(S);
     a.out_key        = static_cast<uint64_t*>(out.recs.data());

@@ -33,14 +33,13 @@ constexpr int RADIX_MAX_REGION_LIST = 256;
 // DENSE (level 1 only; the dense direct-address join's partition pass, dense_part_kernels.hip): a row is the ONE 8-byte record
 // {key - dense_lo (32 bits) | row id << 32}, its partition the top bits of that offset (a contiguous slice of the direct-address
 // table); rows whose key lies outside [dense_lo, dense_lo + dense_range) are dropped like NULL rows. No row-id stream.
-template <int LEVEL, int RPT, int D, bool DENSE>
-__global__ void __launch_bounds__(1024) k_radix_scatter(radix_scatter_args const* __restrict__ ap)
+template <int LEVEL, int RPT, int D, bool DENSE, int B = 1024>
+__global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int s_pending, s_abort, s_rounds;
   __shared__ int32_t s_pre[RADIX_MAX_REGION_LIST + 1];
   radix_scatter_args const& a = *ap;
-  constexpr int B = 1024;
   constexpr uint32_t G = 16, GT = 32, TPL = 4;  // keys / row ids per 128-byte granule; row ids per lane of a flush (16 bytes)
   int const P = a.P, capl = a.capl;
   uint32_t const CAP = 1u << capl, cmask = CAP - 1u, tcmask = (CAP << 1) - 1u;
@@ -589,7 +588,7 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     for (void const* fn : {reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false>), reinterpret_cast<void const*>(&k_radix_scatter<2, 4, 2, false>),
-                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true>)}) {
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true>), reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true, 512>)}) {
       hipFuncAttributes attr{};
       CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
       CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
@@ -597,7 +596,8 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
   });
   hipLaunchKernelGGL(k_store_radix_args<radix_scatter_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{a.level == 1 ? "join_partition" : "join_partition_level2", stream};
-  if (dense) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  if (dense && a.block == 512) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true, 512>), dim3(a.slices), dim3(512), lds, stream, d_args);
+  else if (dense) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else if (a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else hipLaunchKernelGGL((k_radix_scatter<2, 4, 2, false>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
