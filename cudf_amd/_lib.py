@@ -79,6 +79,9 @@ SYMBOLS = {
 _lib = None
 
 
+ABI_VERSION = 3  # include/cudf_amd_c.h CUDF_AMD_ABI_VERSION
+
+
 def load():
     global _lib
     if _lib is None:
@@ -91,6 +94,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
+        if lib.cudf_amd_abi_version() != ABI_VERSION:  # struct layouts and signatures below were written for this version
+            raise ImportError(f"{LIB_PATH} has ABI version {lib.cudf_amd_abi_version()}, cudf_amd/_lib.py expects {ABI_VERSION}: rebuild the library")
         _lib = lib
     return _lib
 

@@ -49,7 +49,7 @@ struct planner_env {
   int64_t lds_kb, agg_block, big_min_rows, estimate_min_rows, forced_p, s_items, preagg_min_pct, dense_log2p, scatter_block, rpt;
   int64_t dense_nsplit, wc_g, chunk_rows, slices, plan_load_pct;  // -1: not set (the default depends on the plan)
   bool dense, dense_composite, dense_one_table, dense_ring, dense_multi, chunked, hot, preagg, optimistic, optimistic2, exact, wc, cyclic,
-    stamps, debug, no_simple, vec16, trace, hash_ring;
+    stamps, debug, no_simple, vec16, trace, hash_ring, collapse_runs;
   int64_t static_shapes;  // composite dense keys: 0 = run-time loader, 1 / 2 = compiled column shapes with one / two tiles of loads in flight
   static planner_env load();
 };

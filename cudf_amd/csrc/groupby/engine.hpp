@@ -468,6 +468,22 @@ struct finalize_args {
 void launch_finalize(finalize_args const& a, finalize_args* d_args, uint64_t const* records, int64_t cap,
                      int64_t const* prefix, int32_t nitems, int64_t total, hipStream_t stream);
 // prefix[i] = counts[0] + ... + counts[i - 1] for i <= nitems (the items' group counts -> where each item's groups go in the output)
+// ---- path A front end for plain shapes (collapse_runs.hip): runs of equal keys -> one partial record each, no hash table.
+// Chunk `item` = rows [item * chunk, + chunk); its records [key | accumulators] go to out_records[item * out_stride * PU ...),
+// their number to out_count[item]; a chunk with more than out_stride records raises bit 1 of *overflow.
+struct collapse_args {
+  plan_dev plan;  // simple, one key unit, <= 2 payload units, no NULLs (collapse_runs_applies)
+  int64_t nrows;
+  int64_t chunk;
+  int32_t nitems;
+  int64_t out_stride;
+  uint64_t* out_records;
+  int32_t* out_count;
+  int32_t* overflow;
+};
+bool collapse_runs_applies(plan_dev const& p);
+void launch_collapse_runs(collapse_args const& a, collapse_args* d_args, hipStream_t stream);
+
 void launch_count_prefix(int32_t const* counts, int32_t nitems, int64_t* prefix, hipStream_t stream);
 // item i's records [i * cap, i * cap + prefix[i + 1] - prefix[i]) of `units` 8-byte units each -> out[prefix[i] ...] (contiguous)
 void launch_compact_records(uint64_t const* records, int64_t cap, int64_t const* prefix, int32_t nitems, int units, uint64_t* out, hipStream_t stream);

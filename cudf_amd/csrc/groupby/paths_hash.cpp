@@ -165,22 +165,42 @@ outcome aggregate_call::try_preaggregate(attempt_plan& ap)
         double const run_starts = std::max(1.0 - adjacent_equal, 1e-6);  // distinct keys of a chunk <= its run starts
         // (and at least ~2048 chunks: long runs would otherwise leave most CUs without a chunk - 200M sorted rows on 100K groups
         // ran on 48 workgroups, 5.1 ms)
-        int64_t const chunk_rows = std::clamp<int64_t>(static_cast<int64_t>(static_cast<double>(ag.fill_limit) / 1.5 / run_starts), int64_t{1} << 14,
-                                                       std::max<int64_t>(int64_t{1} << 14, n / 2048));
-        int64_t const items      = (n + chunk_rows - 1) / chunk_rows;
-        if (static_cast<double>(items) * ag.cap * PU * 8.0 <= 16.0 * 1024 * 1024 * 1024) {
+        // plain shapes: the run-collapsing front end (collapse_runs.hip: no table, one record per run and row set); the rest: row
+        // chunks small enough for one LDS table each
+        bool const collapse = env.collapse_runs && collapse_runs_applies(p);
+        int64_t const chunk_rows =
+          collapse ? std::clamp<int64_t>(n / 4096 / 1024 * 1024, int64_t{1} << 16, int64_t{1} << 19)
+                   : std::clamp<int64_t>(static_cast<int64_t>(static_cast<double>(ag.fill_limit) / 1.5 / run_starts), int64_t{1} << 14,
+                                         std::max<int64_t>(int64_t{1} << 14, n / 2048));
+        int64_t const items = (n + chunk_rows - 1) / chunk_rows;
+        // (records per chunk: a table's worth, or - collapsing - every run start plus one per row set, doubled)
+        int64_t const stride1 = collapse ? static_cast<int64_t>(static_cast<double>(chunk_rows) * std::min(1.0, 2.0 * (run_starts + 1.0 / 64.0))) + 256 : ag.cap;
+        if (static_cast<double>(items) * static_cast<double>(stride1) * PU * 8.0 <= 16.0 * 1024 * 1024 * 1024) {
           path         = hash_path::PARTITIONED_LDS;
-          uint64_t* partial1 = sc.alloc<uint64_t>(static_cast<size_t>(items) * ag.cap * PU);
+          uint64_t* partial1 = sc.alloc<uint64_t>(static_cast<size_t>(items) * static_cast<size_t>(stride1) * PU);
           int32_t* d_count1  = sc.alloc<int32_t>(static_cast<size_t>(items));
-          agg_args a1        = aa;
-          a1.input           = IN_COLUMNS;
-          a1.seg             = SEG_ROW_CHUNKS;
-          a1.nrows           = n;
-          a1.chunk           = chunk_rows;
-          a1.out_records     = partial1;
-          a1.out_count       = d_count1;
-          a1.nitems          = static_cast<int32_t>(items);
-          launch_aggregate(a1, sc.alloc<agg_args>(1), s);
+          if (collapse) {
+            collapse_args c1{};
+            c1.plan        = p;
+            c1.nrows       = n;
+            c1.chunk       = chunk_rows;
+            c1.nitems      = static_cast<int32_t>(items);
+            c1.out_stride  = stride1;
+            c1.out_records = partial1;
+            c1.out_count   = d_count1;
+            c1.overflow    = aa.overflow;
+            launch_collapse_runs(c1, sc.alloc<collapse_args>(1), s);
+          } else {
+            agg_args a1    = aa;
+            a1.input       = IN_COLUMNS;
+            a1.seg         = SEG_ROW_CHUNKS;
+            a1.nrows       = n;
+            a1.chunk       = chunk_rows;
+            a1.out_records = partial1;
+            a1.out_count   = d_count1;
+            a1.nitems      = static_cast<int32_t>(items);
+            launch_aggregate(a1, sc.alloc<agg_args>(1), s);
+          }
           nitems  = static_cast<int32_t>(items);
           d_count = d_count1;
           int32_t const ov1 = overflow_and_counts();
@@ -198,7 +218,7 @@ outcome aggregate_call::try_preaggregate(attempt_plan& ap)
           int64_t* d_prefix1 = sc.alloc<int64_t>(static_cast<size_t>(items) + 1);
           launch_count_prefix(d_count1, static_cast<int32_t>(items), d_prefix1, s);
           uint64_t* compact = sc.alloc<uint64_t>(static_cast<size_t>(std::max<int64_t>(n2, 1)) * PU);
-          launch_compact_records(partial1, ag.cap, d_prefix1, static_cast<int32_t>(items), PU, compact, s);
+          launch_compact_records(partial1, stride1, d_prefix1, static_cast<int32_t>(items), PU, compact, s);
           int64_t* d_seg = sc.alloc<int64_t>(2);
           launch_store_i64x2(0, n2, d_seg, s);
           // tables for the merged groups

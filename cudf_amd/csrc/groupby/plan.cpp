@@ -60,6 +60,7 @@ planner_env planner_env::load()
   e.stamps            = env_i64("CUDF_AMD_GB_STAMPS", 0) != 0;
   e.debug             = env_i64("CUDF_AMD_DEBUG", 0) != 0;
   e.no_simple         = env_i64("CUDF_AMD_GB_NO_SIMPLE", 0) != 0;
+  e.collapse_runs     = env_i64("CUDF_AMD_GB_COLLAPSE_RUNS", 1) != 0;
   e.vec16             = env_i64("CUDF_AMD_GB_VEC16", 0) != 0;
   e.trace             = env_i64("CUDF_AMD_GB_TRACE", 0) != 0;
   // (off by default: measured SLOWER than the write-combining scatter + tagged tables - profiles/r3_sparse_ring.txt)

@@ -57,29 +57,32 @@ __global__ void __launch_bounds__(256) k_dense_count_filled(int32_t const* __res
 {
   unsigned long long c = 0;
   uint64_t const n4 = n / 4, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
-  for (uint64_t i = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i < n4; i += stride) {
-    i32x4 const v = gload(reinterpret_cast<i32x4 const*>(head) + i);
-    c += (v.x >= 0) + (v.y >= 0) + (v.z >= 0) + (v.w >= 0);
+  for (uint64_t i0 = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    i32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = i0 + j * stride < n4 ? gload(reinterpret_cast<i32x4 const*>(head) + i0 + j * stride) : i32x4{-1, -1, -1, -1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += (v[j].x >= 0) + (v[j].y >= 0) + (v[j].z >= 0) + (v[j].w >= 0);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) c += head[n4 * 4 + threadIdx.x] >= 0;
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
+// the pairs of ALL regions a workgroup serves go to its own stage, one after the other: one cursor, one count per workgroup
 __global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const* __restrict__ ap)
 {
   dense_part_args const& a = *ap;
   __shared__ unsigned long long s_cursor;
-  bool const ok            = *a.overflow == 0;
-  int const lane           = threadIdx.x & 63;
-  uint64_t const below     = (1ull << lane) - 1ull;
+  bool const ok        = *a.overflow == 0;
+  int const lane       = threadIdx.x & 63;
+  uint64_t const below = (1ull << lane) - 1ull;
+  uint64_t* stage      = a.stage + static_cast<int64_t>(blockIdx.x) * a.stage_cap;
+  if (threadIdx.x == 0) s_cursor = 0;
+  __syncthreads();
   for_each_region(a, [&](int64_t reg) {
-    __syncthreads();  // (the previous region's cursor has been read)
-    if (threadIdx.x == 0) s_cursor = 0;
-    __syncthreads();
     int32_t const cnt   = ok ? min(max(a.region_count[reg], 0), static_cast<int32_t>(a.region_cap)) : 0;
     uint64_t const* rec = a.recs + reg * a.region_cap;
-    uint64_t* stage     = a.stage + reg * a.region_cap;
     for (int32_t i0 = 0; i0 < cnt; i0 += 256 * 4) {  // (uniform trip count: the ballots below are wave-wide)
       uint64_t v[4];
       int32_t h[4];
@@ -115,14 +118,19 @@ __global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const
         }
       }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) a.pair_counts[reg] = s_cursor;
   });
+  __syncthreads();
+  if (threadIdx.x == 0) a.pair_counts[blockIdx.x] = s_cursor;
 }
 
 }  // namespace
 
 int32_t dense_part_grid() { return 1024; }  // 4 workgroups of 256 threads per CU, all resident: 128 per XCD
+int64_t dense_part_regions_per_workgroup(int32_t P, int32_t S)
+{
+  int64_t const W = dense_part_grid() / 8;
+  return static_cast<int64_t>((P + 7) / 8) * ((S + W - 1) / W);
+}
 
 void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream)
 {
@@ -142,7 +150,8 @@ void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long lo
 
 void launch_dense_part_lookup(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream)
 {
-  CUDF_EXPECTS(a.P >= 1 && a.S >= 1 && a.recs != nullptr && a.head != nullptr && a.overflow != nullptr && a.stage != nullptr && a.pair_counts != nullptr,
+  CUDF_EXPECTS(a.P >= 1 && a.S >= 1 && a.recs != nullptr && a.head != nullptr && a.overflow != nullptr && a.stage != nullptr && a.pair_counts != nullptr &&
+                 a.stage_cap >= dense_part_regions_per_workgroup(a.P, a.S) * a.region_cap,
                "partitioned dense join: arguments");
   hipLaunchKernelGGL(k_store_dense_part_args, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_count", stream};

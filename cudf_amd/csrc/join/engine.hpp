@@ -175,11 +175,14 @@ struct dense_part_args {
   int32_t P, S;
   int32_t* head;                // the direct-address table (join_args::dense_head, unique keys: head[offset] = build row or -1)
   int32_t const* overflow;      // the scatter's flag: nothing is done when it is set
-  // lookup only: the pairs of region r are staged at stage[r * region_cap ...), pair_counts[r] = their number
-  unsigned long long* pair_counts;
+  // lookup only: workgroup b stages the pairs of all its regions at stage[b * stage_cap ...), pair_counts[b] = their number
+  unsigned long long* pair_counts;  // [dense_part_grid() + 1]
   uint64_t* stage;
+  int64_t stage_cap;                // >= dense_part_regions_per_workgroup(P, S) * region_cap
   int64_t probe_row_base;
 };
+int32_t dense_part_grid();
+int64_t dense_part_regions_per_workgroup(int32_t P, int32_t S);
 void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);
 void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long long* out, hipStream_t stream);
 void launch_dense_part_lookup(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);

@@ -475,9 +475,10 @@ class hash_join_impl {
     dense_side side;
     dense_partition(col.data<uint64_t>(), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
     auto a                     = dense_part_args_of(side);
-    std::size_t const nregions = static_cast<std::size_t>(side.P) * static_cast<std::size_t>(side.S);
-    rmm::device_buffer counts{(nregions + 1) * sizeof(unsigned long long), s, tmp}, stage{nregions * static_cast<std::size_t>(side.cap) * sizeof(uint64_t), s, tmp},
-      d_args{sizeof(join::dense_part_args), s, tmp};
+    std::size_t const nregions = static_cast<std::size_t>(join::dense_part_grid());  // (one stage and one pair count per workgroup)
+    a.stage_cap                = join::dense_part_regions_per_workgroup(side.P, side.S) * side.cap;
+    rmm::device_buffer counts{(nregions + 1) * sizeof(unsigned long long), s, tmp},
+      stage{nregions * static_cast<std::size_t>(a.stage_cap) * sizeof(uint64_t), s, tmp}, d_args{sizeof(join::dense_part_args), s, tmp};
     a.pair_counts    = static_cast<unsigned long long*>(counts.data());
     a.stage          = static_cast<uint64_t*>(stage.data());
     a.probe_row_base = row_base;
@@ -500,7 +501,7 @@ class hash_join_impl {
     e.nparts       = static_cast<int32_t>(nregions);
     e.pair_counts  = a.pair_counts;
     e.stage        = a.stage;
-    e.stage_cap    = side.cap;
+    e.stage_cap    = a.stage_cap;
     e.out_probe    = out_l->data();
     e.out_build    = out_r->data();
     e.out_capacity = total;

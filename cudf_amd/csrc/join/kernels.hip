@@ -492,11 +492,22 @@ __global__ void __launch_bounds__(256) k_key_minmax(join_args const* __restrict_
   uint64_t const* keys = static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset;
   bool const masked    = a.check_nulls && a.build.col[0].mask != nullptr;
   T lo = SIGNED ? static_cast<T>(INT64_MAX) : static_cast<T>(UINT64_MAX), hi = SIGNED ? static_cast<T>(INT64_MIN) : T{0};
-  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) {
-    if (masked && !col_is_valid(a.build.col[0], i)) continue;
-    T const k = static_cast<T>(gload(keys + i));
-    lo = k < lo ? k : lo;
-    hi = k > hi ? k : hi;
+  constexpr int R = 4;  // loads in flight per thread
+  for (int64_t i0 = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i0 < n; i0 += R * stride) {
+    T k[R];
+    bool ok[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      int64_t const i = i0 + j * stride;
+      ok[j]           = i < n;
+      k[j]            = ok[j] ? static_cast<T>(gload(keys + i)) : T{0};
+      ok[j]           = ok[j] && !(masked && !col_is_valid(a.build.col[0], i));
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      lo = ok[j] && k[j] < lo ? k[j] : lo;
+      hi = ok[j] && k[j] > hi ? k[j] : hi;
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {

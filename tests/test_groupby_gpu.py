@@ -785,6 +785,50 @@ def test_sorted_and_clustered_keys_are_preaggregated(G, oracle, monkeypatch, sha
     _check_against_oracle(G, oracle, keys, [(vals, kinds)])
 
 
+@pytest.mark.parametrize("shape", ["runs_of_64", "ragged_runs", "int_values_sum_of_squares", "two_value_columns", "few_long_runs"])
+def test_plain_runs_collapse_without_a_table(G, oracle, monkeypatch, shape):
+    """Plain shapes (one int64 key, 8-byte values, no NULLs) with clustered rows take the run-collapsing front end of path A
+    (collapse_runs.hip): a segmented scan over the lanes, one partial record per run and row set, no LDS table. Runs of exactly 64
+    rows whose keys recur; runs of 1..200 rows (unaligned, a row count that is not a multiple of the batch); int64 values with
+    SUM of squares / MIN / MAX; two value columns; a handful of very long runs. The same call with the front end switched off
+    (CUDF_AMD_GB_COLLAPSE_RUNS=0: one LDS table per row chunk) agrees."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng({"runs_of_64": 1, "ragged_runs": 2, "int_values_sum_of_squares": 3, "two_value_columns": 4, "few_long_runs": 5}[shape])
+    n = 4_700_003
+    i = np.arange(n, dtype=np.int64)
+    requests = None
+    if shape == "runs_of_64":
+        keys = [((i // 64) * 2654435761) % 99_991 - 50_000]
+        requests = [(HostColumn(rng.random(n), None, "float64"), ["sum", "count_valid", "mean"])]
+    elif shape == "ragged_runs":
+        lens = rng.integers(1, 200, n // 50)
+        k = np.repeat(rng.integers(-2**40, 2**40, len(lens)), lens)[:n]
+        k = np.concatenate([k, np.full(n - len(k), 7, dtype=np.int64)]) if len(k) < n else k
+        keys = [k.astype(np.int64)]
+        requests = [(HostColumn(rng.random(n), None, "float64"), ["sum", "min", "max", "count_all"])]
+    elif shape == "int_values_sum_of_squares":
+        keys = [i // 90 * 3]
+        requests = [(HostColumn(rng.integers(-3000, 3000, n).astype(np.int64), None, "int64"), ["sum", "sum_of_squares", "min", "max"])]
+    elif shape == "two_value_columns":
+        keys = [((i // 48) * 40503) % 20_011]
+        requests = [(HostColumn(rng.random(n), None, "float64"), ["sum", "count_valid"]),
+                    (HostColumn(rng.integers(-10**6, 10**6, n).astype(np.int64), None, "int64"), ["sum", "max"])]
+    else:
+        keys = [np.minimum(i // 1_000_000, 3)]
+        requests = [(HostColumn(rng.random(n), None, "float64"), ["sum", "count_valid", "min"])]
+    from cudf_amd import _lib
+    _lib.profile_reset()
+    _lib.profile_enable(True)
+    try:
+        _check_against_oracle(G, oracle, keys, requests, expect_path=None if shape == "few_long_runs" else "PARTITIONED_LDS")
+    finally:
+        _lib.profile_enable(False)
+    if shape != "few_long_runs":  # (four groups fit one table per workgroup: no pre-aggregation)
+        assert "collapse_runs" in _lib.profile_report(), _lib.profile_report()
+    monkeypatch.setenv("CUDF_AMD_GB_COLLAPSE_RUNS", "0")
+    _check_against_oracle(G, oracle, keys, requests)
+
+
 @pytest.mark.parametrize("vt", ["float64", "int64"])
 @pytest.mark.parametrize("hot_fraction", [0.01, 0.3, 0.9])
 def test_heavy_hitters_dense_keys(G, oracle, vt, hot_fraction):
