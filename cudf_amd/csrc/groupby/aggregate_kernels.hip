@@ -276,11 +276,17 @@ __host__ __device__ inline uint32_t hot_threshold(uint32_t min_count, int64_t co
   uint64_t const mean8 = 8ull * static_cast<uint64_t>(counted_rows) / (bits_set > 0 ? bits_set : 1u);
   return static_cast<uint32_t>(mean8 > min_count ? (mean8 > 0xffffffffull ? 0xffffffffull : mean8) : min_count);
 }
+// (also: the sum of the squared bucket counts -> *sumsq. (sumsq - S) / S^2 - 1 / HOT_BUCKETS estimates the sum over the keys of
+// their squared row shares - the chance that two rows carry the same key - from which the planner sizes regions for skewed keys)
 __global__ void __launch_bounds__(256) k_hot_any(uint32_t const* buckets, uint32_t min_count, int64_t counted_rows, uint32_t const* bits_set,
-                                                 uint32_t* crowded)
+                                                 uint32_t* crowded, unsigned long long* sumsq)
 {
-  int const i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < HOT_BUCKETS && buckets[i] >= hot_threshold(min_count, counted_rows, *bits_set)) *crowded = 1;
+  int const i      = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t const c = i < HOT_BUCKETS ? buckets[i] : 0u;
+  if (c >= hot_threshold(min_count, counted_rows, *bits_set) && i < HOT_BUCKETS) *crowded = 1;
+  unsigned long long sq = static_cast<unsigned long long>(c) * c;
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_down(sq, o);
+  if ((threadIdx.x & 63) == 0 && sq) atomicAdd(sumsq, sq);
 }
 __global__ void __launch_bounds__(256) k_hot_collect(plan_dev const* __restrict__ pp, int64_t nrows, int64_t sample,
                                                      uint32_t const* buckets, uint32_t const* crowded, uint32_t min_count_in,
@@ -472,13 +478,15 @@ uint32_t hot_keys_threshold(uint32_t min_count, int64_t sample, uint32_t bits_se
 void launch_hot_keys(plan_dev const* d_plan, int64_t nrows, int64_t sample, uint32_t min_count, uint32_t* buckets, uint32_t const* d_bits_set,
                      uint64_t* table_keys, uint32_t* table_counts, hipStream_t stream)
 {
-  // table_counts holds HOT_TABLE counters followed by the one-word "some bucket is crowded" flag
-  CUDF_HIP_TRY(hipMemsetAsync(table_counts, 0, (HOT_TABLE + 1) * sizeof(uint32_t), stream));
+  // table_counts holds HOT_TABLE counters, the one-word "some bucket is crowded" flag, a pad word and the 8-byte sum of the
+  // squared bucket counts (HOT_TABLE + 4 words)
+  CUDF_HIP_TRY(hipMemsetAsync(table_counts, 0, (HOT_TABLE + 4) * sizeof(uint32_t), stream));
   CUDF_HIP_TRY(hipMemsetAsync(table_keys, 0xff, HOT_TABLE * sizeof(uint64_t), stream));
   uint32_t* crowded   = table_counts + HOT_TABLE;
   unsigned const grid = static_cast<unsigned>(((sample + 3) / 4 + 255) / 256);
   cudf::detail::prof::scope prof_{"estimate", stream};
-  hipLaunchKernelGGL(k_hot_any, dim3(HOT_BUCKETS / 256), dim3(256), 0, stream, buckets, min_count, (sample + 3) / 4, d_bits_set, crowded);
+  hipLaunchKernelGGL(k_hot_any, dim3(HOT_BUCKETS / 256), dim3(256), 0, stream, buckets, min_count, (sample + 3) / 4, d_bits_set, crowded,
+                     reinterpret_cast<unsigned long long*>(table_counts + HOT_TABLE + 2));
   // a bucket holds sample / 4 / 65536 counted keys on average (4 of a 1M-row sample): only crowded ones can hide a
   // heavy hitter, and their keys are counted exactly
   hipLaunchKernelGGL(k_hot_collect, dim3(grid), dim3(256), 0, stream, d_plan, nrows, sample, buckets, crowded, min_count, d_bits_set, table_keys,

@@ -154,6 +154,8 @@ class aggregate_call {
   bool ranges_known{false};
   double adjacent_equal{0.0};            // share of the sampled rows whose successor row carries the same key
   std::vector<uint64_t> hot_keys;        // heavy hitters (aggregated inside the scatter workgroups)
+  double hot_mass{0.0};                  // their share of the sampled rows
+  double skew_m2{0.0};                   // sum of the squared row shares of the other keys (0: not measured)
   // ---- state that attempts change
   scratch sc;
   int32_t* d_overflow{nullptr};

@@ -468,9 +468,10 @@ void launch_dense_ring_scatter(dense_ring_args const& a, dense_ring_args const* 
       return launch_ring_t<RING_SRC_COLS, 4, 1>(a, d_args, stream);
     }
     CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1, "ring scatter: one plain key column and one plain value column");
-    if (a.hot_n > 0) {
-      CUDF_EXPECTS(a.tag16 && a.hot_n <= HOT_MAX_KEYS, "ring scatter: heavy hitters on a single level");
-      return launch_ring_tag<RING_SRC_SIMPLE, 4, 2, uint16_t, true>(a, d_args, stream);
+    if (a.hot_n > 0) {  // (the first level of one or of two levels)
+      CUDF_EXPECTS(a.hot_n <= HOT_MAX_KEYS, "ring scatter: heavy hitters");
+      if (a.tag16) return launch_ring_tag<RING_SRC_SIMPLE, 4, 2, uint16_t, true>(a, d_args, stream);
+      return launch_ring_tag<RING_SRC_SIMPLE, 4, 2, uint32_t, true>(a, d_args, stream);
     }
     return launch_ring_t<RING_SRC_SIMPLE, 4, 2>(a, d_args, stream);
   }

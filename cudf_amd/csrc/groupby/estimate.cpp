@@ -84,7 +84,7 @@ void aggregate_call::estimate()
                     d_blk_adj, d_adj);
     // Dense integer keys ("Dense keys"): minimum and maximum of the key column over the same sample
     // (every read-back of this pass lands in page-locked memory: a copy into pageable memory blocks the host until it is done)
-    unsigned char* const pin = pinned_bytes(64 + 16 + sizeof(h_ranges) + HOT_TABLE * (sizeof(uint64_t) + sizeof(uint32_t)));
+    unsigned char* const pin = pinned_bytes(64 + 16 + sizeof(h_ranges) + HOT_TABLE * (sizeof(uint64_t) + sizeof(uint32_t)) + 16);
     uint32_t* const pin_set    = reinterpret_cast<uint32_t*>(pin);
     uint64_t* const pin_range  = reinterpret_cast<uint64_t*>(pin + 64);
     int64_t* const pin_ranges  = reinterpret_cast<int64_t*>(pin + 64 + 16);
@@ -107,10 +107,10 @@ void aggregate_call::estimate()
     if (hot_eligible) {
       uint32_t* buckets = hot_buckets;
       uint64_t* tkeys   = sc.alloc<uint64_t>(HOT_TABLE);
-      uint32_t* tcounts = sc.alloc<uint32_t>(HOT_TABLE + 1);
+      uint32_t* tcounts = sc.alloc<uint32_t>(HOT_TABLE + 4);
       launch_hot_keys(d_plan, n, sample, hot_min_count, buckets, d_set, tkeys, tcounts, s);
       CUDF_HIP_TRY(hipMemcpyAsync(pin_tkeys, tkeys, HOT_TABLE * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-      CUDF_HIP_TRY(hipMemcpyAsync(pin_tcounts, tcounts, HOT_TABLE * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+      CUDF_HIP_TRY(hipMemcpyAsync(pin_tcounts, tcounts, (HOT_TABLE + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     CUDF_HIP_TRY(hipMemcpyAsync(pin_set, d_set, 4, hipMemcpyDeviceToHost, s));
     if (want_adj) CUDF_HIP_TRY(hipMemcpyAsync(pin_set + 2, d_adj, 8, hipMemcpyDeviceToHost, s));
@@ -131,11 +131,25 @@ void aggregate_call::estimate()
       for (int i = 0; i < HOT_TABLE; ++i)
         if (h_tkeys[i] != ~uint64_t{0} && h_tcounts[i] >= hot_keys_threshold(hot_min_count, sample, h_set)) cand.emplace_back(h_tcounts[i], h_tkeys[i]);
       std::sort(cand.begin(), cand.end(), [](auto const& a, auto const& b) { return a.first > b.first; });
+      // Skew of the keys that stay in the scatter: the sum of their squared row shares (two rows meet in a key with that
+      // probability) from the hashed counters, less the heavy hitters' own; a partition's share of the rows then varies by
+      // sqrt(skew_m2 * partitions) of its mean on top of the sampling noise (region_cap_for in paths_dense.cpp)
+      double const counted = static_cast<double>((sample + 3) / 4);
+      unsigned long long sumsq = 0;
+      std::memcpy(&sumsq, pin_tcounts + HOT_TABLE + 2, sizeof(sumsq));
+      double m2 = std::max(0.0, (static_cast<double>(sumsq) - counted) / (counted * counted) - 1.0 / HOT_BUCKETS);
       if (cand.size() > HOT_MAX_KEYS) cand.resize(HOT_MAX_KEYS);
-      for (auto const& c : cand) hot_keys.push_back(c.second);
+      hot_mass = 0.0;
+      for (auto const& c : cand) {
+        hot_keys.push_back(c.second);
+        double const share = static_cast<double>(c.first) / counted;
+        hot_mass += share;
+        m2 -= share * share;
+      }
+      skew_m2 = std::max(0.0, m2);
       if (env.debug)
-        fprintf(stderr, "[cudf_amd] heavy hitters: %zu keys (most frequent: %u of %ld counted rows)\n", hot_keys.size(),
-                cand.empty() ? 0u : cand[0].first, (long)(sample / 4));
+        fprintf(stderr, "[cudf_amd] heavy hitters: %zu keys (most frequent: %u of %ld counted rows), %.3f of the rows; squared shares of the other keys sum to %.3g\n",
+                hot_keys.size(), cand.empty() ? 0u : cand[0].first, (long)(sample / 4), hot_mass, skew_m2);
     }
     double const m  = std::ldexp(1.0, bits_log2);
     double const ds = h_set >= m ? m * 20 : -m * std::log(1.0 - h_set / m);  // distinct keys in the sample

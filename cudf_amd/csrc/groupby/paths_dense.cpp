@@ -101,10 +101,13 @@ outcome aggregate_call::try_dense_ring()
           int32_t const ntables = static_cast<int32_t>(int64_t{1} << rlog2P);
           int const nsplit      = static_cast<int>(std::clamp<int64_t>((env.dense_nsplit >= 0 ? env.dense_nsplit : 256 / ntables), 1, two_level ? 1 : 16));
           // (heavy hitters: one level, and their merged item - at most HOT_MAX_KEYS groups - must fit the stride of the items)
-          bool const ring_ok = (hot_keys.empty() || (!two_level && slots / nsplit >= HOT_MAX_KEYS)) &&
+          bool const ring_ok = (hot_keys.empty() || slots / nsplit >= HOT_MAX_KEYS) &&
                                dm.range <= (uint64_t{1} << bits) && bits <= 30 && bits - rlog2P >= 6 && rlog2P <= 16 && l1 >= 4 && l1 <= 8 &&
                                (l2 == 0 || (l2 >= 4 && l2 <= 8)) && image <= 150 * 1024 &&
-                               static_cast<double>(dm.range) <= 8.0 * std::max(est_groups, 4096.0);
+                               // (a column with heavy hitters: the sample's distinct count says little about the tail - log-uniform
+                               // keys over 10M values looked like 380K groups - but tables over a range of at most an eighth of the
+                               // rows cost little whatever the number of groups turns out to be)
+                               static_cast<double>(dm.range) <= std::max(8.0 * std::max(est_groups, 4096.0), hot_mass > 0.02 ? static_cast<double>(n) / 8.0 : 0.0);
           if (ring_ok) {
             path  = hash_path::DENSE_DIRECT;
             dm.mult     = 0x9E3779B1u;  // odd: index -> (index * mult) mod 2^bits is a bijection
@@ -117,7 +120,10 @@ outcome aggregate_call::try_dense_ring()
             int64_t const PD = int64_t{1} << l1, P2D = int64_t{1} << l2, S = 256;
             auto region_cap_for = [&](double mean, double parts) {
               double const keys_per_p = std::max(1.0, 0.5 * est_groups / parts);
-              double const rel_sigma  = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, mean));
+              // (skewed keys - Zipf over 10M keys leaves 3 % per partition after the 256 heaviest - widen the spread of a
+              // partition's share: counted only from 10 % on, below that the equal-weights term covers it)
+              double const skew       = skew_m2 * parts / std::max(0.05, (1.0 - hot_mass) * (1.0 - hot_mass));
+              double const rel_sigma  = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, mean) + (skew > 0.01 ? skew : 0.0));
               return (static_cast<int64_t>(mean * (1.0 + 6.0 * std::min(rel_sigma, 1.0)) + 64.0) + 63) / 64 * 64;
             };
             // (workgroup w takes the 4096-row tiles w, w + S, ...: the busiest workgroup has ceil(tiles / S) of them)
@@ -175,6 +181,7 @@ outcome aggregate_call::try_dense_ring()
               size_t const nreg2 = static_cast<size_t>(PD * P2D * slices2);
               rb                 = ra;
               rb.from_columns    = 0;
+              rb.hot_n           = 0;  // (the heavy hitters left the stream on the first level)
               rb.P               = static_cast<int32_t>(P2D);
               rb.capl            = 13 - l2;
               rb.shift           = bits - rlog2P;  // the l2 bits below the level-1 digit

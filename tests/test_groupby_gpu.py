@@ -427,6 +427,21 @@ def test_dense_composite_keys(G, oracle, monkeypatch, shape, two_level, ring):
         assert G.last_path.name != "DENSE_DIRECT"
 
 
+@pytest.mark.parametrize("vt", ["float64", "int64"])
+def test_skewed_dense_keys_on_two_levels(G, oracle, monkeypatch, vt):
+    """Log-uniform ("Zipf") keys over 400K dense values with two ring levels forced: the 256 heaviest keys are aggregated inside
+    the first level's workgroups (the tag32 instantiation of the heavy-hitter table), the regions of both levels are sized from
+    the squared row shares of the remaining keys (estimate.cpp skew_m2), and the call stays on the direct-address tables."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(71)
+    n, groups = 6_000_000, 400_000
+    k = np.clip((float(groups) ** rng.random(n)).astype(np.int64) - 1, 0, groups - 1) - 777
+    v = rng.random(n) if vt == "float64" else rng.integers(-1000, 1000, n).astype(np.int64)
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE_LOG2P", "11")
+    _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), ["sum", "count_valid"])], expect_path="DENSE_DIRECT")
+    assert G.last_path.name == "DENSE_DIRECT"
+
+
 def test_two_level_partition_forced(G, oracle, monkeypatch):
     """Forces the two-level radix partition (C4's regime) at a size the oracle can check."""
     rng = np.random.default_rng(13)
