@@ -275,10 +275,25 @@ def main():
         # torch.distributed - still the literal config-5 form - and the line says so. (A collective that hangs cannot be recovered.)
         if dist_mode == "shuffle_native":
             first_error = None
+            # (a collective that HANGS on its first use cannot be recovered in-process: a watchdog ends this rank with a non-zero
+            # exit code instead of leaving the driver waiting - no re-exec, the GPU has been initialised)
+            import threading
+
+            def give_up():
+                sys.stderr.write(f"[bench] rank {rank}: the first in-library exchange did not finish within {first_timeout_s} s; exiting\n")
+                sys.stderr.flush()
+                os._exit(3)
+            first_timeout_s = int(os.environ.get("BENCH_FIRST_STEP_TIMEOUT_S", "300"))
+            first_watchdog = threading.Timer(first_timeout_s, give_up)
+            first_watchdog.daemon = True
+            first_watchdog.start()
             try:
                 step()
+                torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001
                 first_error = repr(e)
+            finally:
+                first_watchdog.cancel()
             ok = torch.tensor([0 if first_error else 1], device=dev, dtype=torch.int32)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
