@@ -46,6 +46,15 @@ struct ring_tile<RING_SRC_COLS_STATIC, RPT, SHAPE> {
   dense_static_tile<SHAPE, RPT> t;
 };
 
+// home slot of a key in the heavy-hitter table (every row of a call with heavy hitters pays it: two 32-bit multiplies instead
+// of mix64's eight - the scatter with heavy hitters ran at half the plain one's rate)
+static_assert((HOT_SLOTS & (HOT_SLOTS - 1)) == 0 && HOT_SLOTS >= 2, "heavy-hitter table: a power of two");
+__device__ __forceinline__ uint32_t hot_slot_of(uint64_t key)
+{
+  uint32_t const h = static_cast<uint32_t>(key) * 0x9e3779b1u + static_cast<uint32_t>(key >> 32) * 0x85ebca77u;
+  return h >> (32 - __builtin_ctz(HOT_SLOTS));
+}
+
 // TAG: uint16_t for the last level (a table has at most 2^15 slots: slot | validity << 15), uint32_t for the first of two levels
 // (the bits of the scrambled index below its digit | validity << 31).
 // HOT: heavy-hitter keys are aggregated in a small LDS table behind the rings and leave the scatter (a key with percents of the
@@ -101,7 +110,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
     __syncthreads();
     if (static_cast<int>(threadIdx.x) < a.hot_n) {
       uint64_t const key = a.hot_keys[threadIdx.x];
-      uint32_t slot      = static_cast<uint32_t>(mix64(0x9e3779b97f4a7c15ull ^ key) >> 20) & (HOT_SLOTS - 1);
+      uint32_t slot      = hot_slot_of(key);
       while (atomicCAS(reinterpret_cast<unsigned long long*>(hkeys + slot), HOT_EMPTY, key) != HOT_EMPTY) slot = (slot + 1) & (HOT_SLOTS - 1);
     }
   }
@@ -288,7 +297,7 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
           if constexpr (HOT) {  // a heavy hitter is accumulated here and leaves the scatter
             if (keep[k]) {
               uint64_t const key = pre[j].k[k];
-              uint32_t slot      = static_cast<uint32_t>(mix64(0x9e3779b97f4a7c15ull ^ key) >> 20) & (HOT_SLOTS - 1);
+              uint32_t slot      = hot_slot_of(key);
               for (;;) {
                 uint64_t const kk = hkeys[slot];
                 if (kk == key) {
