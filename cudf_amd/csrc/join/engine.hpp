@@ -104,7 +104,9 @@ constexpr int RADIX_RING_SLOTS = 8192;  // key-ring slots of a scatter workgroup
 struct radix_scatter_args {
   int32_t level;      // 1: rows of a key column; 2: the regions of level-1 partition `seg`
   // level 1
-  uint64_t const* keys;        // element i = key of row i
+  uint64_t const* keys;        // element i = key of row i (key_width bytes each)
+  int32_t key_width;           // 8, or 4: a 4-byte integer column, widened to 64 bits by the scatter (key_signed: sign-extended)
+  int32_t key_signed;
   bitmask_type const* mask;    // validity of the key column (bit mask_offset + i), nullptr: no NULLs; NULL rows are dropped
   int64_t mask_offset;
   int64_t nrows;

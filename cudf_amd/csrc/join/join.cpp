@@ -57,6 +57,21 @@ bool is_single64(table_view const& t)
   return size_of_id(id) == 8 && (cls == CLS_SINT || cls == CLS_UINT);
 }
 
+// 8 or 4: the table is ONE integer key column of that width (what the partitioned joins take; 4-byte keys are widened by their
+// first scatter level); 0 otherwise
+int single_int_width(table_view const& t)
+{
+  if (t.num_columns() != 1) return 0;
+  auto const id  = t.column(0).type().id();
+  auto const cls = class_of(id);
+  auto const w   = size_of_id(id);
+  return (cls == CLS_SINT || cls == CLS_UINT) && (w == 8 || w == 4) ? static_cast<int>(w) : 0;
+}
+uint64_t const* key_bytes(column_view const& c, int width)
+{
+  return reinterpret_cast<uint64_t const*>(c.head<uint8_t>() + static_cast<std::size_t>(c.offset()) * static_cast<std::size_t>(width));
+}
+
 int64_t env_flag(char const* name, int64_t dflt)
 {
   char const* v = std::getenv(name);
@@ -104,9 +119,15 @@ class hash_join_impl {
     // sides are radix-partitioned on the same bits. Default: 8-byte slots, direct windowed probe.
     bool const build_check_nulls = _has_nulls && cudf::has_nulls(right);
     bool const key64 = is_single64(right) && (!build_check_nulls || _nulls_equal != null_equality::EQUAL);
+    // (one 4-byte integer key: only the partitioned joins take it - they widen it in their first scatter level; everything else
+    // about such a table goes through the generic row comparator of the open-addressing table)
+    _keyw         = (!build_check_nulls || _nulls_equal != null_equality::EQUAL) ? single_int_width(right) : 0;
+    _key_signed   = _keyw != 0 && class_of(right.column(0).type().id()) == CLS_SINT;
+    _key64        = key64;
+    _classic_load = load_factor;
     // Dense build keys (one 8-byte integer key column, NULLs never match, valid values within a small range): a direct-address
     // table over [min, max] replaces the hash table - see engine.hpp. Decided from the exact minimum / maximum of the build keys.
-    if (key64 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
+    if (_keyw != 0 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
       hipStream_t const s = stream.value();
       auto tmp            = cudf::get_current_device_resource_ref();
       bool const is_signed = class_of(right.column(0).type().id()) == CLS_SINT;
@@ -125,11 +146,17 @@ class hash_join_impl {
         _dense_head  = rmm::device_buffer{_dense_range * sizeof(int32_t), s, mr};
         _dense_next  = rmm::device_buffer{rows * sizeof(int32_t), s, mr};
         CUDF_HIP_TRY(hipMemsetAsync(_dense_head.data(), 0xff, _dense_head.size(), s));
+        // big tables: rows partitioned by key range, plain stores that stay in L2, uniqueness from a count (dense_part_kernels.hip)
+        _dense = key64;  // (the direct passes over a dense table read 8-byte keys)
+        if (try_dense_part_build(right, stream)) return;
+        if (!key64) {  // a 4-byte key whose rows did not take the partitioned build: the hash table
+          _dense_head = rmm::device_buffer{};
+          _dense_next = rmm::device_buffer{};
+        }
+      }
+      if (any_valid && _dense) {
         rmm::device_buffer dups{sizeof(int32_t), s, tmp};
         CUDF_HIP_TRY(hipMemsetAsync(dups.data(), 0, sizeof(int32_t), s));
-        _dense       = true;
-        // big tables: rows partitioned by key range, plain stores that stay in L2, uniqueness from a count (dense_part_kernels.hip)
-        if (try_dense_part_build(right, stream)) return;
         join_args b  = base_args(right, 0);
         b.dense_dups = static_cast<int32_t*>(dups.data());
         join::launch_dense_build(b, static_cast<join_args*>(d_args.data()), s);
@@ -150,11 +177,9 @@ class hash_join_impl {
         return;
       }
     }
-    _key64        = key64;
-    _classic_load = load_factor;
     // LDS radix join (engine.hpp): the build side partitioned into LDS-sized partitions; the open-addressing table in HBM is then
     // only built if a call needs it (left / full joins, match contexts, small probe sides, a probe side that overflows a region)
-    if (key64 && try_radix_build(right, stream)) return;
+    if (_keyw != 0 && try_radix_build(right, stream)) return;
     build_classic(stream);
   }
 
@@ -229,6 +254,8 @@ class hash_join_impl {
     join::radix_scatter_args a1{};
     a1.level        = 1;
     a1.keys         = keys;
+    a1.key_width    = _keyw;
+    a1.key_signed   = _key_signed ? 1 : 0;
     a1.mask         = mask;
     a1.mask_offset  = mask_offset;
     a1.nrows        = nrows;
@@ -281,7 +308,7 @@ class hash_join_impl {
     if (valid < env_flag("CUDF_AMD_JOIN_RADIX_MIN_BUILD", 3 << 20) || valid > nparts * 3500) return false;
     _rx_nparts = static_cast<int32_t>(nparts);
     hipStream_t const s = stream.value();
-    if (!radix_partition(col.data<uint64_t>(), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, valid, _rx_build, stream, _mr))
+    if (!radix_partition(key_bytes(col, _keyw), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, valid, _rx_build, stream, _mr))
       return false;
     // every partition must fit its LDS table
     auto tmp = cudf::get_current_device_resource_ref();
@@ -305,14 +332,14 @@ class hash_join_impl {
   {
     auto const& col = left.column(0);
     bool const probe_nulls = _has_nulls && col.has_nulls();
-    if (!is_single64(left) || (probe_nulls && _nulls_equal == null_equality::EQUAL)) return std::nullopt;
+    if (single_int_width(left) != _keyw || (probe_nulls && _nulls_equal == null_equality::EQUAL)) return std::nullopt;
     int64_t const rows  = left.num_rows();
     int64_t const valid = rows - (col.nullable() ? col.null_count() : 0);
     if (rows < env_flag("CUDF_AMD_JOIN_RADIX_MIN_PROBE", 8 << 20) || rows > (int64_t{1} << 31) - 1) return std::nullopt;
     hipStream_t const s = stream.value();
     auto tmp            = cudf::get_current_device_resource_ref();
     radix_side probe;
-    if (!radix_partition(col.data<uint64_t>(), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, valid, probe, stream, tmp)) return std::nullopt;
+    if (!radix_partition(key_bytes(col, _keyw), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, valid, probe, stream, tmp)) return std::nullopt;
     rmm::device_buffer counts{(static_cast<std::size_t>(_rx_nparts) + 1) * sizeof(unsigned long long), s, tmp}, ovf{sizeof(int32_t), s, tmp},
       d_args{sizeof(join::radix_join_args), s, tmp};
     CUDF_HIP_TRY(hipMemsetAsync(ovf.data(), 0, sizeof(int32_t), s));
@@ -395,6 +422,8 @@ class hash_join_impl {
     join::radix_scatter_args a{};
     a.level          = 1;
     a.keys           = keys;
+    a.key_width      = _keyw;
+    a.key_signed     = _key_signed ? 1 : 0;
     a.mask           = mask;
     a.mask_offset    = mask_offset;
     a.nrows          = nrows;
@@ -438,7 +467,7 @@ class hash_join_impl {
     hipStream_t const s = stream.value();
     auto tmp            = cudf::get_current_device_resource_ref();
     dense_side side;
-    dense_partition(col.data<uint64_t>(), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
+    dense_partition(key_bytes(col, _keyw), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
     auto a = dense_part_args_of(side);
     rmm::device_buffer d_args{sizeof(join::dense_part_args), s, tmp}, filled{sizeof(unsigned long long), s, tmp};
     CUDF_HIP_TRY(hipMemsetAsync(filled.data(), 0, sizeof(unsigned long long), s));
@@ -467,13 +496,13 @@ class hash_join_impl {
     auto const& col        = left.column(0);
     bool const probe_nulls = _has_nulls && col.has_nulls();
     int64_t const rows     = left.num_rows();
-    if (!is_single64(left) || (probe_nulls && _nulls_equal == null_equality::EQUAL) ||
+    if (single_int_width(left) != _keyw || (probe_nulls && _nulls_equal == null_equality::EQUAL) ||
         rows < env_flag("CUDF_AMD_JOIN_DENSE_PART_MIN_PROBE", 8 << 20) || rows > (int64_t{1} << 31) - 1)
       return std::nullopt;
     hipStream_t const s = stream.value();
     auto tmp            = cudf::get_current_device_resource_ref();
     dense_side side;
-    dense_partition(col.data<uint64_t>(), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
+    dense_partition(key_bytes(col, _keyw), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
     auto a                     = dense_part_args_of(side);
     std::size_t const nregions = static_cast<std::size_t>(join::dense_part_grid());  // (one stage and one pair count per workgroup)
     a.stage_cap                = join::dense_part_regions_per_workgroup(side.P, side.S) * side.cap;
@@ -822,6 +851,8 @@ class hash_join_impl {
   device_table _build_dev{};
   rmm::device_async_resource_ref _mr;
   bool _key64{false};
+  int _keyw{0};             // 8 / 4: one integer key column of that width whose NULLs never match (the partitioned joins); 0: none
+  bool _key_signed{false};
   double _classic_load{0.5};
   // the open-addressing table in HBM: built by the constructor, or on first need when the build side took the radix partitions
   mutable std::mutex _classic_mu;

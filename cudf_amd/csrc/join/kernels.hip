@@ -489,7 +489,9 @@ __global__ void __launch_bounds__(256) k_key_minmax(join_args const* __restrict_
   __shared__ T s_lo[4], s_hi[4];
   int64_t const n      = a.build.nrows;
   int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  uint64_t const* keys = static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset;
+  bool const narrow    = a.build.col[0].width == 4;  // a 4-byte integer key column: widened like the join's scatter does
+  uint64_t const* keys = static_cast<uint64_t const*>(a.build.col[0].head) + (narrow ? 0 : a.build.col[0].offset);
+  uint32_t const* keys32 = static_cast<uint32_t const*>(a.build.col[0].head) + a.build.col[0].offset;
   bool const masked    = a.check_nulls && a.build.col[0].mask != nullptr;
   T lo = SIGNED ? static_cast<T>(INT64_MAX) : static_cast<T>(UINT64_MAX), hi = SIGNED ? static_cast<T>(INT64_MIN) : T{0};
   constexpr int R = 4;  // loads in flight per thread
@@ -500,7 +502,12 @@ __global__ void __launch_bounds__(256) k_key_minmax(join_args const* __restrict_
     for (int j = 0; j < R; ++j) {
       int64_t const i = i0 + j * stride;
       ok[j]           = i < n;
-      k[j]            = ok[j] ? static_cast<T>(gload(keys + i)) : T{0};
+      if (narrow) {
+        uint32_t const k32 = ok[j] ? gload(keys32 + i) : 0u;
+        k[j]               = SIGNED ? static_cast<T>(static_cast<int32_t>(k32)) : static_cast<T>(k32);
+      } else {
+        k[j] = ok[j] ? static_cast<T>(gload(keys + i)) : T{0};
+      }
       ok[j]           = ok[j] && !(masked && !col_is_valid(a.build.col[0], i));
     }
 #pragma unroll

@@ -612,3 +612,48 @@ def test_dense_part_join_fallbacks(G, oracle, force_dense_part):
         gl, gr = getattr(hj, kind + "_join")(cudf_amd.Table([G.to_device(lk)]))
         xl, xr = oracle.join([lk], [rk], nulls_equal=True, kind=kind)
         assert kat.sorted_pairs(gl.to_numpy()[0], gr.to_numpy()[0]) == kat.sorted_pairs(xl, xr)
+
+
+@pytest.mark.parametrize("dtype", ["int32", "uint32"])
+@pytest.mark.parametrize("path", ["dense_part", "radix"])
+def test_partitioned_joins_take_four_byte_keys(G, oracle, monkeypatch, dtype, path):
+    """One 4-byte integer key column: the partitioned joins widen it in their first scatter level (sign-extended for signed
+    types), so int32 / uint32 keys take the same paths as int64 keys; negative keys, 5 % NULLs (UNEQUAL); a hash_join object
+    whose build side took the partitions still answers left joins and sizes through the generic hash table."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(21 if dtype == "int32" else 22)
+    nl, nr = 500_000, 120_000
+    npt = np.dtype(dtype)
+    if path == "dense_part":
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
+        for k, v in (("MIN_BUILD", "0"), ("MIN_RANGE", "0"), ("MIN_PROBE", "0"), ("SLICE_LOG2", "10")):
+            monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_" + k, v)
+        base = -70_000 if dtype == "int32" else 3_000_000_000  # (unsigned keys above 2^31: zero-extended, not sign-extended)
+        rk = (rng.permutation(200_000)[:nr].astype(np.int64) + base).astype(npt)
+        lk = (rng.integers(-20_000, 240_000, nl, dtype=np.int64) + base).astype(npt)
+    else:
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_BUILD", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_PROBE", "0")
+        lo, hi = (-2**31, 2**31 - 1) if dtype == "int32" else (0, 2**32 - 1)
+        pool = rng.integers(lo, hi, 150_000, dtype=np.int64)
+        rk = pool[rng.integers(0, 100_000, nr)].astype(npt)           # duplicates on the build side
+        lk = pool[rng.integers(0, 150_000, nl)].astype(npt)           # a third of the probe keys have no partner
+    lv, rv = rng.random(nl) > 0.05, rng.random(nr) > 0.05
+    left, right = [HostColumn(lk, lv, dtype)], [HostColumn(rk, rv, dtype)]
+    (li, ri), kernels = _kernels_of(lambda: G.join(left, right, nulls_equal=False, kind="inner"))
+    assert kernels.get("join_partition", 0) >= 2, kernels
+    el, er = oracle.join(left, right, nulls_equal=False, kind="inner")
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+    hj = HashJoin(cudf_amd.Table([G.to_device(right[0])]), NullEquality.UNEQUAL)
+    t = cudf_amd.Table([G.to_device(left[0])])
+    gl, gr = hj.left_join(t)
+    xl, xr = oracle.join(left, right, nulls_equal=False, kind="left")
+    assert kat.sorted_pairs(gl.to_numpy()[0], gr.to_numpy()[0]) == kat.sorted_pairs(xl, xr)
+    assert hj.inner_join_size(t) == len(el)
+    pl, pr = hj.inner_join(t)
+    assert kat.sorted_pairs(pl.to_numpy()[0], pr.to_numpy()[0]) == kat.sorted_pairs(el, er)
