@@ -21,21 +21,24 @@ namespace {
 
 __global__ void k_store_dense_part_args(dense_part_args v, dense_part_args* dst) { *dst = v; }
 
-// workgroup b serves the partitions p = b % 8, b % 8 + 8, ... (one XCD's share); within a partition the regions s = b / 8,
-// b / 8 + gridDim.x / 8, ...
+// One launch serves EIGHT partitions, p0 ... p0 + 7: workgroup b the partition p0 + b % 8 (one XCD's workgroups share one
+// partition, i.e. one <= 1 MB slice of the table in that XCD's 4 MB L2), within it the regions s = b / 8, b / 8 + gridDim.x / 8, ...
+// The launch boundary is what keeps an XCD on one slice: with one launch for all partitions the workgroups of an XCD drifted over
+// many partitions (a workgroup's share of a partition is ~6 batches) and every lookup fetched its sector from beyond L2
+// (FETCH_SIZE: 5.6 GB for 1.1 GB of records + 142M lookups).
 template <typename F>
-__device__ __forceinline__ void for_each_region(dense_part_args const& a, F&& f)
+__device__ __forceinline__ void for_each_region(dense_part_args const& a, int p0, F&& f)
 {
-  int const cls = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
-  for (int p = cls; p < a.P; p += 8)
-    for (int s = w; s < a.S; s += W) f(static_cast<int64_t>(p) * a.S + s);
+  int const p = p0 + (blockIdx.x & 7), w = blockIdx.x >> 3, W = gridDim.x >> 3;
+  if (p >= a.P) return;
+  for (int s = w; s < a.S; s += W) f(static_cast<int64_t>(p) * a.S + s);
 }
 
-__global__ void __launch_bounds__(256) k_dense_part_store(dense_part_args const* __restrict__ ap)
+__global__ void __launch_bounds__(256) k_dense_part_store(dense_part_args const* __restrict__ ap, int p0)
 {
   dense_part_args const& a = *ap;
   if (*a.overflow != 0) return;
-  for_each_region(a, [&](int64_t reg) {
+  for_each_region(a, p0, [&](int64_t reg) {
     int32_t const cnt   = min(max(a.region_count[reg], 0), static_cast<int32_t>(a.region_cap));
     uint64_t const* rec = a.recs + reg * a.region_cap;
     for (int32_t i0 = 0; i0 < cnt; i0 += 256 * 4) {
@@ -43,7 +46,7 @@ __global__ void __launch_bounds__(256) k_dense_part_store(dense_part_args const*
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int32_t const i = i0 + j * 256 + static_cast<int32_t>(threadIdx.x);
-        v[j]            = i < cnt ? gload(rec + i) : ~uint64_t{0};
+        v[j]            = i < cnt ? gload_stream(rec + i) : ~uint64_t{0};  // (read once: must not displace the table slice in L2)
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -69,8 +72,9 @@ __global__ void __launch_bounds__(256) k_dense_count_filled(int32_t const* __res
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 
-// the pairs of ALL regions a workgroup serves go to its own stage, one after the other: one cursor, one count per workgroup
-__global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const* __restrict__ ap)
+// the pairs of ALL regions a workgroup serves (over all launches) go to its own stage, one after the other: one cursor, one
+// count per workgroup (pair_counts[b], zero before the first launch)
+__global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const* __restrict__ ap, int p0)
 {
   dense_part_args const& a = *ap;
   __shared__ unsigned long long s_cursor;
@@ -78,28 +82,29 @@ __global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const
   int const lane       = threadIdx.x & 63;
   uint64_t const below = (1ull << lane) - 1ull;
   uint64_t* stage      = a.stage + static_cast<int64_t>(blockIdx.x) * a.stage_cap;
-  if (threadIdx.x == 0) s_cursor = 0;
+  if (threadIdx.x == 0) s_cursor = a.pair_counts[blockIdx.x];
   __syncthreads();
-  for_each_region(a, [&](int64_t reg) {
+  for_each_region(a, p0, [&](int64_t reg) {
     int32_t const cnt   = ok ? min(max(a.region_count[reg], 0), static_cast<int32_t>(a.region_cap)) : 0;
     uint64_t const* rec = a.recs + reg * a.region_cap;
-    for (int32_t i0 = 0; i0 < cnt; i0 += 256 * 4) {  // (uniform trip count: the ballots below are wave-wide)
-      uint64_t v[4];
-      int32_t h[4];
+    constexpr int R = 8;  // records in flight per thread: a region is ~12 records per thread, latency is what a launch pays for
+    for (int32_t i0 = 0; i0 < cnt; i0 += 256 * R) {  // (uniform trip count: the ballots below are wave-wide)
+      uint64_t v[R];
+      int32_t h[R];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < R; ++j) {
         int32_t const i = i0 + j * 256 + static_cast<int32_t>(threadIdx.x);
-        v[j]            = i < cnt ? gload(rec + i) : ~uint64_t{0};
+        v[j]            = i < cnt ? gload_stream(rec + i) : ~uint64_t{0};  // (read once: must not displace the table slice in L2)
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < R; ++j) {
         h[j] = -1;
         if (i0 + j * 256 + static_cast<int32_t>(threadIdx.x) < cnt) h[j] = gload(a.head + static_cast<uint32_t>(v[j]));
       }
-      unsigned long long m[4];
+      unsigned long long m[R];
       int tot = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < R; ++j) {
         m[j] = __ballot(h[j] >= 0);
         tot += __popcll(m[j]);
       }
@@ -109,10 +114,10 @@ __global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const
         pos = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(pos >> 32))) << 32) |
               __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(pos));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < R; ++j) {
           if (h[j] >= 0) {
             uint32_t const prow = static_cast<uint32_t>(static_cast<int64_t>(v[j] >> 32) + a.probe_row_base);
-            gstore(stage + pos + __popcll(m[j] & below), static_cast<uint64_t>(prow) | (static_cast<uint64_t>(static_cast<uint32_t>(h[j])) << 32));
+            gstore_stream(stage + pos + __popcll(m[j] & below), static_cast<uint64_t>(prow) | (static_cast<uint64_t>(static_cast<uint32_t>(h[j])) << 32));
           }
           pos += __popcll(m[j]);
         }
@@ -125,19 +130,20 @@ __global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const
 
 }  // namespace
 
-int32_t dense_part_grid() { return 1024; }  // 4 workgroups of 256 threads per CU, all resident: 128 per XCD
+int32_t dense_part_grid() { return 2048; }  // 8 workgroups of 256 threads per CU: 256 per XCD, one region of a partition each
 int64_t dense_part_regions_per_workgroup(int32_t P, int32_t S)
 {
   int64_t const W = dense_part_grid() / 8;
-  return static_cast<int64_t>((P + 7) / 8) * ((S + W - 1) / W);
+  return static_cast<int64_t>((P + 7) / 8) * ((S + W - 1) / W);  // (P: the partitions that can hold rows, dense_part_args::P_used)
 }
 
 void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream)
 {
-  CUDF_EXPECTS(a.P >= 1 && a.S >= 1 && a.recs != nullptr && a.head != nullptr && a.overflow != nullptr, "partitioned dense join: arguments");
+  CUDF_EXPECTS(a.P >= 1 && a.S >= 1 && a.P_used >= 1 && a.P_used <= a.P && a.recs != nullptr && a.head != nullptr && a.overflow != nullptr,
+               "partitioned dense join: arguments");
   hipLaunchKernelGGL(k_store_dense_part_args, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_build", stream};
-  hipLaunchKernelGGL(k_dense_part_store, dim3(dense_part_grid()), dim3(256), 0, stream, d_args);
+  for (int p0 = 0; p0 < a.P_used; p0 += 8) hipLaunchKernelGGL(k_dense_part_store, dim3(dense_part_grid()), dim3(256), 0, stream, d_args, p0);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
@@ -151,11 +157,12 @@ void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long lo
 void launch_dense_part_lookup(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream)
 {
   CUDF_EXPECTS(a.P >= 1 && a.S >= 1 && a.recs != nullptr && a.head != nullptr && a.overflow != nullptr && a.stage != nullptr && a.pair_counts != nullptr &&
-                 a.stage_cap >= dense_part_regions_per_workgroup(a.P, a.S) * a.region_cap,
+                 a.stage_cap >= dense_part_regions_per_workgroup(a.P_used, a.S) * a.region_cap && a.P_used >= 1 && a.P_used <= a.P,
                "partitioned dense join: arguments");
   hipLaunchKernelGGL(k_store_dense_part_args, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_count", stream};
-  hipLaunchKernelGGL(k_dense_part_lookup, dim3(dense_part_grid()), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipMemsetAsync(a.pair_counts, 0, (static_cast<std::size_t>(dense_part_grid()) + 1) * sizeof(unsigned long long), stream));
+  for (int p0 = 0; p0 < a.P_used; p0 += 8) hipLaunchKernelGGL(k_dense_part_lookup, dim3(dense_part_grid()), dim3(256), 0, stream, d_args, p0);
   CUDF_HIP_TRY(hipGetLastError());
 }
 

@@ -174,7 +174,8 @@ struct dense_part_args {
   uint64_t const* recs;         // regions (p, s) at (p * S + s) * region_cap
   int32_t const* region_count;  // [P * S]
   int64_t region_cap;
-  int32_t P, S;
+  int32_t P, S;                 // partitions of the region layout (the scatter's ring count: a power of two), slices
+  int32_t P_used;               // partitions that can hold rows: (range - 1 >> shift) + 1 <= P; eight per launch
   int32_t* head;                // the direct-address table (join_args::dense_head, unique keys: head[offset] = build row or -1)
   int32_t const* overflow;      // the scatter's flag: nothing is done when it is set
   // lookup only: workgroup b stages the pairs of all its regions at stage[b * stage_cap ...), pair_counts[b] = their number

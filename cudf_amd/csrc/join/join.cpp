@@ -392,7 +392,7 @@ class hash_join_impl {
   struct dense_side {
     rmm::device_buffer recs, counts, ovf;
     int64_t cap{0};
-    int32_t P{0}, S{0};
+    int32_t P{0}, S{0}, P_used{0};
   };
   // rows -> records {key - lo | row << 32} in regions (partition, slice); `expected` = the rows a slice may have to take
   void dense_partition(uint64_t const* keys, bitmask_type const* mask, int64_t mask_offset, int64_t nrows, dense_side& out, stream_ref stream) const
@@ -416,6 +416,7 @@ class hash_join_impl {
     out.ovf    = rmm::device_buffer{sizeof(int32_t), s, tmp};
     out.cap    = cap;
     out.P      = static_cast<int32_t>(Pring);
+    out.P_used = static_cast<int32_t>(P);
     out.S      = static_cast<int32_t>(S);
     CUDF_HIP_TRY(hipMemsetAsync(out.counts.data(), 0, out.counts.size(), s));
     CUDF_HIP_TRY(hipMemsetAsync(out.ovf.data(), 0, sizeof(int32_t), s));
@@ -450,6 +451,7 @@ class hash_join_impl {
     a.region_count = static_cast<int32_t const*>(side.counts.data());
     a.region_cap   = side.cap;
     a.P            = side.P;
+    a.P_used       = side.P_used;
     a.S            = side.S;
     a.head         = const_cast<int32_t*>(static_cast<int32_t const*>(_dense_head.data()));
     a.overflow     = static_cast<int32_t const*>(side.ovf.data());
@@ -505,7 +507,7 @@ class hash_join_impl {
     dense_partition(key_bytes(col, _keyw), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
     auto a                     = dense_part_args_of(side);
     std::size_t const nregions = static_cast<std::size_t>(join::dense_part_grid());  // (one stage and one pair count per workgroup)
-    a.stage_cap                = join::dense_part_regions_per_workgroup(side.P, side.S) * side.cap;
+    a.stage_cap                = join::dense_part_regions_per_workgroup(side.P_used, side.S) * side.cap;
     rmm::device_buffer counts{(nregions + 1) * sizeof(unsigned long long), s, tmp},
       stage{nregions * static_cast<std::size_t>(a.stage_cap) * sizeof(uint64_t), s, tmp}, d_args{sizeof(join::dense_part_args), s, tmp};
     a.pair_counts    = static_cast<unsigned long long*>(counts.data());
