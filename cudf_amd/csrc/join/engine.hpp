@@ -132,6 +132,7 @@ struct radix_scatter_args {
   int32_t dense;
   uint64_t dense_lo, dense_range;
   int32_t pending_budget;  // dense: a workgroup whose rings made it wait more often than this (net of tiles) reports overflow
+  int32_t rpt;             // dense, block 1024: rows per thread and tile, 4 (tiles of 4096 rows) or 8
   int32_t block;           // dense: threads per workgroup, 1024 (tiles of 4096 rows) or 512 (2048 rows; two workgroups per CU when the rings take <= 64 KB)
 };
 struct radix_join_args {

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <new>
 #include <vector>
 #include <optional>
 #include <cmath>
@@ -148,7 +149,13 @@ class hash_join_impl {
         CUDF_HIP_TRY(hipMemsetAsync(_dense_head.data(), 0xff, _dense_head.size(), s));
         // big tables: rows partitioned by key range, plain stores that stay in L2, uniqueness from a count (dense_part_kernels.hip)
         _dense = key64;  // (the direct passes over a dense table read 8-byte keys)
-        if (try_dense_part_build(right, stream)) return;
+        bool part_built = false;
+        try {
+          part_built = try_dense_part_build(right, stream);
+        } catch (std::bad_alloc const&) {  // (no room for the partition scratch: the atomic-exchange build needs none)
+          CUDF_HIP_TRY(hipMemsetAsync(_dense_head.data(), 0xff, _dense_head.size(), s));
+        }
+        if (part_built) return;
         if (!key64) {  // a 4-byte key whose rows did not take the partitioned build: the hash table
           _dense_head = rmm::device_buffer{};
           _dense_next = rmm::device_buffer{};
@@ -179,7 +186,15 @@ class hash_join_impl {
     }
     // LDS radix join (engine.hpp): the build side partitioned into LDS-sized partitions; the open-addressing table in HBM is then
     // only built if a call needs it (left / full joins, match contexts, small probe sides, a probe side that overflows a region)
-    if (_keyw != 0 && try_radix_build(right, stream)) return;
+    if (_keyw != 0) {
+      bool radix_built = false;
+      try {
+        radix_built = try_radix_build(right, stream);
+      } catch (std::bad_alloc const&) {
+        _rx_build = radix_side{};
+      }
+      if (radix_built) return;
+    }
     build_classic(stream);
   }
 
@@ -407,7 +422,8 @@ class hash_join_impl {
     while (Pring < P) Pring <<= 1;
     // CUDF_AMD_JOIN_DENSE_PART_BLOCK=512: two workgroups of 512 threads per CU (8192 ring slots each) instead of one of 1024 - measured
     // 8 % slower on C3 (1.73 against 1.60 ms for both scatters), kept for the record (profiles/r3_c3_dense_part.txt)
-    int64_t const block = env_flag("CUDF_AMD_JOIN_DENSE_PART_BLOCK", 1024) == 512 ? 512 : 1024, tile_rows = block * 4;
+    int64_t const rpt   = env_flag("CUDF_AMD_JOIN_DENSE_PART_RPT", 4) == 8 ? 8 : 4;
+    int64_t const block = env_flag("CUDF_AMD_JOIN_DENSE_PART_BLOCK", 1024) == 512 ? 512 : 1024, tile_rows = block * (block == 1024 ? rpt : 4);
     int64_t const tiles = (nrows + tile_rows - 1) / tile_rows, S = std::clamp<int64_t>(tiles, 1, block == 512 ? 512 : 256);
     double const mean   = static_cast<double>(std::min<int64_t>(nrows, (tiles + S - 1) / S * tile_rows)) / static_cast<double>(P);
     int64_t const cap   = (static_cast<int64_t>(mean * 1.02 + 6.0 * std::sqrt(std::max(mean, 1.0)) + 64.0) + 31) / 32 * 32;
@@ -431,6 +447,7 @@ class hash_join_impl {
     a.P              = static_cast<int32_t>(Pring);
     a.capl           = (block == 512 ? 13 : 14) - log2c(static_cast<uint64_t>(Pring));  // 16384 (8192) ring slots of 8 bytes
     a.block          = static_cast<int32_t>(block);
+    a.rpt            = static_cast<int32_t>(rpt);
     a.shift          = shift;
     a.slices         = static_cast<int32_t>(S);
     a.out_key        = static_cast<uint64_t*>(out.recs.data());
@@ -654,8 +671,17 @@ class hash_join_impl {
     }
     int const k = kind == join_kind::INNER_JOIN ? 0 : kind == join_kind::LEFT_JOIN ? 1 : 2;
     hipStream_t const s = stream.value();
+    // (the partitioned joins take scratch of ~3x the probe column - regions sized for the worst case, the pair stage: when the pool
+    // cannot give it, the direct passes below still can run)
+    auto or_nothing = [](auto&& f) -> std::optional<join_index_pair> {
+      try {
+        return f();
+      } catch (std::bad_alloc const&) {
+        return std::nullopt;
+      }
+    };
     if (_radix && k == 0) {  // big inner joins on one 8-byte key: both sides in LDS-sized partitions (engine.hpp)
-      auto r = radix_probe(left, stream, mr, row_base);
+      auto r = or_nothing([&] { return radix_probe(left, stream, mr, row_base); });
       if (r.has_value()) {
         if (output_size.has_value())
           CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
@@ -663,7 +689,7 @@ class hash_join_impl {
       }
     }
     if (_dense_part && k == 0) {  // big inner joins on a dense unique key: probe rows partitioned by key range (engine.hpp)
-      auto r = dense_part_probe(left, stream, mr, row_base);
+      auto r = or_nothing([&] { return dense_part_probe(left, stream, mr, row_base); });
       if (r.has_value()) {
         if (output_size.has_value())
           CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);

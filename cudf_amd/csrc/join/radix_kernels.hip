@@ -594,7 +594,8 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     for (void const* fn : {reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false>), reinterpret_cast<void const*>(&k_radix_scatter<2, 4, 2, false>),
-                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true>), reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true, 512>)}) {
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true>), reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true, 512>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 8, 2, true>)}) {
       hipFuncAttributes attr{};
       CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
       CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
@@ -603,6 +604,7 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
   hipLaunchKernelGGL(k_store_radix_args<radix_scatter_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{a.level == 1 ? "join_partition" : "join_partition_level2", stream};
   if (dense && a.block == 512) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true, 512>), dim3(a.slices), dim3(512), lds, stream, d_args);
+  else if (dense && a.rpt == 8) hipLaunchKernelGGL((k_radix_scatter<1, 8, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else if (dense) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else if (a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else hipLaunchKernelGGL((k_radix_scatter<2, 4, 2, false>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
