@@ -183,27 +183,30 @@ def run_secondary_children():
     import subprocess
     out = {}
     budget_s = float(os.environ.get("BENCH_SECONDARY_TIMEOUT_S", "100"))
-    for cfg in ("c3", "c3sparse", "c4"):
+    # (c3_partitioned_probe: C3 with the probe rows partitioned by key range instead of the ordered direct probe that is the default
+    # - less time in the join, pairs partition-major instead of in probe-row order: DESIGN.md section 4)
+    for name, cfg, env_extra in (("c3", "c3", {}), ("c3_partitioned_probe", "c3", {"CUDF_AMD_JOIN_DENSE_PROBE": "2"}), ("c3sparse", "c3sparse", {}),
+                                 ("c4", "c4", {})):
         t0 = time.perf_counter()
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s, cwd=ROOT)
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s, cwd=ROOT, env={**os.environ, **env_extra})
             lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not lines:
-                out[cfg] = {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr.decode(errors="replace")[-400:]}
+                out[name] = {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr.decode(errors="replace")[-400:]}
                 continue
             doc = json.loads(lines[-1])
             checks = doc["config"]["checks"]
-            out[cfg] = {"ms_per_step": doc["ms_per_step"], "value": doc["value"], "unit": doc["unit"], "steps": doc["steps"],
+            out[name] = {"ms_per_step": doc["ms_per_step"], "value": doc["value"], "unit": doc["unit"], "steps": doc["steps"],
                         "frac": doc["roofline"]["frac"], "whole_call_frac": doc["roofline"]["whole_call_frac"],
                         "dominant_kernel": doc["roofline"]["kernel"], "kernels_ms_per_step": doc["roofline"]["kernels_ms_per_step"],
                         "checks": checks, "checks_ok": all(v for k, v in checks.items()
                                          if isinstance(v, bool) and (k.endswith("_ok") or k in ("keys_equal", "no_null_rows", "pairs_distinct"))),
                         "wall_s": time.perf_counter() - t0}
         except subprocess.TimeoutExpired:
-            out[cfg] = {"error": f"not finished after {budget_s:.0f} s"}
+            out[name] = {"error": f"not finished after {budget_s:.0f} s"}
         except Exception as e:  # noqa: BLE001
-            out[cfg] = {"error": repr(e)}
+            out[name] = {"error": repr(e)}
     return out
 
 

@@ -128,7 +128,70 @@ __global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const
   if (threadIdx.x == 0) a.pair_counts[blockIdx.x] = s_cursor;
 }
 
+__global__ void k_store_dense_stage_args(dense_stage_args v, dense_stage_args* dst) { *dst = v; }
+
+// (engine.hpp dense_stage_args) one wave = one contiguous range of probe rows, walked in order, 8 row sets of 64 in flight
+__global__ void __launch_bounds__(256) k_dense_probe_staged(dense_stage_args const* __restrict__ ap)
+{
+  dense_stage_args const& a = *ap;
+  constexpr int R = 8;
+  int const lane = threadIdx.x & 63;
+  int64_t const w = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= a.nwaves) return;
+  uint64_t const below = (1ull << lane) - 1ull;
+  int64_t const begin = w * a.wave_rows, end = min(a.nrows, begin + a.wave_rows);
+  uint64_t* stage      = a.stage + w * a.wave_rows;
+  uint64_t const lo = a.dense_lo, range = a.dense_range;
+  bool const narrow = a.key_width == 4;
+  uint32_t const* keys32 = reinterpret_cast<uint32_t const*>(a.keys);
+  unsigned long long npairs = 0;
+  for (int64_t base = begin; base < end; base += 64 * R) {
+    uint64_t idx[R];
+    bool in[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      int64_t const r = base + j * 64 + lane;
+      in[j]           = r < end;
+      idx[j]          = 0;
+      if (in[j]) {
+        if (narrow) {
+          uint32_t const k32 = gload_stream(keys32 + r);
+          idx[j] = (a.key_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32)) - lo;
+        } else {
+          idx[j] = gload_stream(a.keys + r) - lo;
+        }
+        if (a.mask != nullptr) in[j] = (gload(a.mask + ((a.mask_offset + r) >> 5)) >> ((a.mask_offset + r) & 31)) & 1u;
+        in[j] = in[j] && idx[j] < range;  // a key outside the build side's range matches nothing and reads nothing
+      }
+    }
+    int32_t h[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) h[j] = in[j] ? gload(a.head + idx[j]) : -1;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      unsigned long long const m = __ballot(h[j] >= 0);
+      if (h[j] >= 0) {
+        uint32_t const prow = static_cast<uint32_t>(base + j * 64 + lane + a.probe_row_base);
+        gstore_stream(stage + npairs + __popcll(m & below), static_cast<uint64_t>(prow) | (static_cast<uint64_t>(static_cast<uint32_t>(h[j])) << 32));
+      }
+      npairs += __popcll(m);
+    }
+  }
+  if (lane == 0) a.pair_counts[w] = npairs;
+}
+
 }  // namespace
+
+void launch_dense_probe_staged(dense_stage_args const& a, dense_stage_args* d_args, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.keys != nullptr && a.head != nullptr && a.stage != nullptr && a.pair_counts != nullptr && a.wave_rows >= 64 && a.wave_rows % 64 == 0 &&
+                 a.nwaves >= 1 && static_cast<int64_t>(a.nwaves) * a.wave_rows >= a.nrows && (a.key_width == 4 || a.key_width == 8),
+               "dense join, ordered probe: arguments");
+  hipLaunchKernelGGL(k_store_dense_stage_args, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_count", stream};
+  hipLaunchKernelGGL(k_dense_probe_staged, dim3((a.nwaves + 3) / 4), dim3(256), 0, stream, d_args);
+  CUDF_HIP_TRY(hipGetLastError());
+}
 
 int32_t dense_part_grid() { return 2048; }  // 8 workgroups of 256 threads per CU: 256 per XCD, one region of a partition each
 int64_t dense_part_regions_per_workgroup(int32_t P, int32_t S)

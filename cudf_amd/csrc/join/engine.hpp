@@ -187,6 +187,26 @@ struct dense_part_args {
 };
 int32_t dense_part_grid();
 int64_t dense_part_regions_per_workgroup(int32_t P, int32_t S);
+// ---- Ordered direct probe of a dense UNIQUE table (dense_part_kernels.hip k_dense_probe_staged): every WAVE walks its own
+// contiguous range of probe rows in order, looks the keys up directly (no partition pass) and appends its pairs to its own stage
+// (no atomics): pair_counts[w] pairs at stage[w * wave_rows ...). The copy (launch_radix_emit_staged, nparts = waves) then yields
+// the pairs in PROBE-ROW ORDER - which is what makes the caller's payload gather by them fast.
+struct dense_stage_args {
+  uint64_t const* keys;         // key_width bytes per row
+  int32_t key_width, key_signed;
+  bitmask_type const* mask;     // nullptr: no NULLs
+  int64_t mask_offset;
+  int64_t nrows;
+  int64_t wave_rows;            // rows per wave (a multiple of 64)
+  int32_t nwaves;               // ceil(nrows / wave_rows): 4 per workgroup
+  uint64_t dense_lo, dense_range;
+  int32_t const* head;
+  uint64_t* stage;              // [nwaves * wave_rows]
+  unsigned long long* pair_counts;  // [nwaves + 1]
+  int64_t probe_row_base;
+};
+void launch_dense_probe_staged(dense_stage_args const& a, dense_stage_args* d_args, hipStream_t stream);
+
 void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);
 void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long long* out, hipStream_t stream);
 void launch_dense_part_lookup(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);

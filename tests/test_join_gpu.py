@@ -561,6 +561,7 @@ def force_dense_part(monkeypatch):
     monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_MIN_RANGE", "0")
     monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_MIN_PROBE", "0")
     monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_SLICE_LOG2", "10")
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PROBE", "2")  # (the default, 1, is the ordered direct probe: test_dense_ordered_probe_*)
 
 
 @pytest.mark.parametrize("shape", ["unique", "nulls", "negative", "one_partition"])
@@ -631,6 +632,7 @@ def test_partitioned_joins_take_four_byte_keys(G, oracle, monkeypatch, dtype, pa
         monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
         for k, v in (("MIN_BUILD", "0"), ("MIN_RANGE", "0"), ("MIN_PROBE", "0"), ("SLICE_LOG2", "10")):
             monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_" + k, v)
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PROBE", "2")
         base = -70_000 if dtype == "int32" else 3_000_000_000  # (unsigned keys above 2^31: zero-extended, not sign-extended)
         rk = (rng.permutation(200_000)[:nr].astype(np.int64) + base).astype(npt)
         lk = (rng.integers(-20_000, 240_000, nl, dtype=np.int64) + base).astype(npt)
@@ -657,3 +659,41 @@ def test_partitioned_joins_take_four_byte_keys(G, oracle, monkeypatch, dtype, pa
     assert hj.inner_join_size(t) == len(el)
     pl, pr = hj.inner_join(t)
     assert kat.sorted_pairs(pl.to_numpy()[0], pr.to_numpy()[0]) == kat.sorted_pairs(el, er)
+
+
+@pytest.mark.parametrize("shape", ["int64", "int64_nulls", "int32_negative", "uint32_high", "atomic_build"])
+def test_dense_ordered_probe_yields_pairs_in_probe_row_order(G, oracle, monkeypatch, shape):
+    """Inner joins on a dense unique build key take the ordered direct probe (engine.hpp dense_stage_args): every wave walks its own
+    contiguous range of probe rows and appends its pairs to its own stage, so the pairs come out sorted by probe row - what a
+    payload gather by them wants. 8-byte and 4-byte keys, NULLs (UNEQUAL), probe keys outside the build range; a table built by the
+    partitioned stores and one built by the atomic exchanges (`atomic_build`); a probe of rows [a, b) of a bigger table through the
+    match context keeps the row base."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng({"int64": 31, "int64_nulls": 32, "int32_negative": 33, "uint32_high": 34, "atomic_build": 35}[shape])
+    nl, nr = 900_001, 150_000
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
+    monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_ORDERED_MIN_PROBE", "0")
+    if shape != "atomic_build":
+        for k, v in (("MIN_BUILD", "0"), ("MIN_RANGE", "0"), ("SLICE_LOG2", "10")):
+            monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_" + k, v)
+    dtype = {"int32_negative": "int32", "uint32_high": "uint32"}.get(shape, "int64")
+    base = {"int32_negative": -90_000, "uint32_high": 4_000_000_000}.get(shape, 10**12)
+    npt = np.dtype(dtype)
+    rk = (rng.permutation(220_000)[:nr].astype(np.int64) + base).astype(npt)
+    lk = (rng.integers(-30_000, 260_000, nl, dtype=np.int64) + base).astype(npt)
+    lv = rng.random(nl) > 0.05 if shape == "int64_nulls" else None
+    rv = rng.random(nr) > 0.05 if shape == "int64_nulls" else None
+    left, right = [HostColumn(lk, lv, dtype)], [HostColumn(rk, rv, dtype)]
+    hj = HashJoin(cudf_amd.Table([G.to_device(right[0])]), NullEquality.UNEQUAL)
+    t = cudf_amd.Table([G.to_device(left[0])])
+    (pl, pr), kernels = _kernels_of(lambda: hj.inner_join(t))
+    assert "join_retrieve" in kernels and kernels.get("join_partition", 0) == 0, kernels  # (count + copy, no probe-side partition pass)
+    li, ri = pl.to_numpy()[0], pr.to_numpy()[0]
+    assert np.all(np.diff(li.astype(np.int64)) >= 0), "pairs are not in probe-row order"
+    el, er = oracle.join(left, right, nulls_equal=False, kind="inner")
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+    assert hj.inner_join_size(t) == len(el)
