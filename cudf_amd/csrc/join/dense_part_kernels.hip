@@ -14,7 +14,10 @@
 #include "engine.hpp"
 #include "../common/profiler.hpp"
 
+#include <cudf/join/join.hpp>
 #include <cudf/utilities/error.hpp>
+
+#include <algorithm>
 
 namespace cudf::detail::join {
 namespace {
@@ -180,7 +183,61 @@ __global__ void __launch_bounds__(256) k_dense_probe_staged(dense_stage_args con
   if (lane == 0) a.pair_counts[w] = npairs;
 }
 
+// (engine.hpp launch_dense_left_direct)
+__global__ void __launch_bounds__(256) k_dense_left_direct(dense_stage_args const* __restrict__ ap, size_type* __restrict__ out_probe,
+                                                           size_type* __restrict__ out_build)
+{
+  dense_stage_args const& a = *ap;
+  constexpr int R = 8;
+  uint64_t const lo = a.dense_lo, range = a.dense_range;
+  bool const narrow = a.key_width == 4;
+  uint32_t const* keys32 = reinterpret_cast<uint32_t const*>(a.keys);
+  int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x * R;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * blockDim.x * R; base < a.nrows; base += stride) {
+    uint64_t idx[R];
+    bool in[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      int64_t const r = base + j * 256 + threadIdx.x;
+      in[j]           = r < a.nrows;
+      idx[j]          = 0;
+      if (in[j]) {
+        if (narrow) {
+          uint32_t const k32 = gload_stream(keys32 + r);
+          idx[j] = (a.key_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32)) - lo;
+        } else {
+          idx[j] = gload_stream(a.keys + r) - lo;
+        }
+        if (a.mask != nullptr) in[j] = (gload(a.mask + ((a.mask_offset + r) >> 5)) >> ((a.mask_offset + r) & 31)) & 1u;
+        in[j] = in[j] && idx[j] < range;
+      }
+    }
+    int32_t h[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) h[j] = in[j] ? gload(a.head + idx[j]) : -1;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      int64_t const r = base + j * 256 + threadIdx.x;
+      if (r < a.nrows) {
+        gstore_stream(out_probe + r, static_cast<size_type>(r + a.probe_row_base));
+        gstore_stream(out_build + r, h[j] >= 0 ? static_cast<size_type>(h[j]) : JoinNoMatch);
+      }
+    }
+  }
+}
+
 }  // namespace
+
+void launch_dense_left_direct(dense_stage_args const& a, dense_stage_args* d_args, size_type* out_probe, size_type* out_build, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.keys != nullptr && a.head != nullptr && out_probe != nullptr && out_build != nullptr && a.nrows >= 1 && (a.key_width == 4 || a.key_width == 8),
+               "dense join, direct left join: arguments");
+  hipLaunchKernelGGL(k_store_dense_stage_args, dim3(1), dim3(1), 0, stream, a, d_args);
+  cudf::detail::prof::scope prof_{"join_retrieve", stream};
+  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((a.nrows + 2047) / 2048, 1, 8192));
+  hipLaunchKernelGGL(k_dense_left_direct, dim3(grid), dim3(256), 0, stream, d_args, out_probe, out_build);
+  CUDF_HIP_TRY(hipGetLastError());
+}
 
 void launch_dense_probe_staged(dense_stage_args const& a, dense_stage_args* d_args, hipStream_t stream)
 {

@@ -206,6 +206,11 @@ struct dense_stage_args {
   int64_t probe_row_base;
 };
 void launch_dense_probe_staged(dense_stage_args const& a, dense_stage_args* d_args, hipStream_t stream);
+// LEFT join against a dense unique table: every probe row yields exactly one pair - its build row or JoinNoMatch - so the output
+// is the probe rows in order and needs no count pass, no stage and no compaction: out_probe[i] = i + probe_row_base,
+// out_build[i] = head[key_i - lo] (or JoinNoMatch for a NULL key, a key outside the range, an empty entry). Uses dense_stage_args'
+// keys / mask / nrows / dense_* / head / probe_row_base.
+void launch_dense_left_direct(dense_stage_args const& a, dense_stage_args* d_args, size_type* out_probe, size_type* out_build, hipStream_t stream);
 
 void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);
 void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long long* out, hipStream_t stream);

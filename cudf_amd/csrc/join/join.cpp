@@ -755,6 +755,32 @@ class hash_join_impl {
         return std::move(*r);
       }
     }
+    // LEFT join against a dense unique table: one pair per probe row, in order - a single pass (engine.hpp launch_dense_left_direct)
+    if (unique_table && k == 1 && dense_probe != 0 && single_int_width(left) == _keyw && _keyw != 0 &&
+        !((_has_nulls && left.column(0).has_nulls()) && _nulls_equal == null_equality::EQUAL) &&
+        left.num_rows() >= env_flag("CUDF_AMD_JOIN_DENSE_ORDERED_MIN_PROBE", 1 << 20) && left.num_rows() + row_base <= (int64_t{1} << 31) - 1) {
+      auto const& col  = left.column(0);
+      std::size_t const n = static_cast<std::size_t>(left.num_rows());
+      if (output_size.has_value())
+        CUDF_EXPECTS(*output_size == n, "hash join: output_size does not match the number of matches", std::invalid_argument);
+      auto out_l = std::make_unique<rmm::device_uvector<size_type>>(n, s, mr);
+      auto out_r = std::make_unique<rmm::device_uvector<size_type>>(n, s, mr);
+      join::dense_stage_args a{};
+      a.keys           = key_bytes(col, _keyw);
+      a.key_width      = _keyw;
+      a.key_signed     = _key_signed ? 1 : 0;
+      a.mask           = (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr;
+      a.mask_offset    = col.offset();
+      a.nrows          = left.num_rows();
+      a.dense_lo       = _dense_lo;
+      a.dense_range    = _dense_range;
+      a.head           = static_cast<int32_t const*>(_dense_head.data());
+      a.probe_row_base = row_base;
+      rmm::device_buffer d_args_l{sizeof(join::dense_stage_args), s, cudf::get_current_device_resource_ref()};
+      join::launch_dense_left_direct(a, static_cast<join::dense_stage_args*>(d_args_l.data()), out_l->data(), out_r->data(), s);
+      CUDF_HIP_TRY(hipStreamSynchronize(s));
+      return {std::move(out_l), std::move(out_r)};
+    }
     if (_dense_part && k == 0 && dense_probe != 0) {  // probe rows partitioned by key range (engine.hpp)
       auto r = or_nothing([&] { return dense_part_probe(left, stream, mr, row_base); });
       if (r.has_value()) {

@@ -697,3 +697,10 @@ def test_dense_ordered_probe_yields_pairs_in_probe_row_order(G, oracle, monkeypa
     assert len(li) == len(el)
     assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
     assert hj.inner_join_size(t) == len(el)
+    # LEFT join against the same table: one pair per probe row, in order, from a single pass (launch_dense_left_direct)
+    (gl, gr), kernels = _kernels_of(lambda: hj.left_join(t))
+    assert "join_count" not in kernels, kernels
+    gl, gr = gl.to_numpy()[0], gr.to_numpy()[0]
+    assert np.array_equal(gl, np.arange(nl, dtype=gl.dtype))
+    xl, xr = oracle.join(left, right, nulls_equal=False, kind="left")
+    assert kat.sorted_pairs(gl, gr) == kat.sorted_pairs(xl, xr)
