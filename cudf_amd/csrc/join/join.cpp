@@ -318,8 +318,9 @@ class hash_join_impl {
     int64_t const rows  = right.num_rows();
     int64_t const valid = rows - (col.nullable() ? col.null_count() : 0);
     // partitions: a power of two with at most ~3500 build rows each (LDS tables of 8192 slots: load <= 0.43), 128 x (16 ... 256)
+    int64_t const part_rows = std::clamp<int64_t>(env_flag("CUDF_AMD_JOIN_RADIX_PART_ROWS", 3500), 256, 3500);
     int64_t nparts = 2048;
-    while (nparts < 32768 && valid > nparts * 3500) nparts <<= 1;
+    while (nparts < 32768 && valid > nparts * part_rows) nparts <<= 1;
     if (valid < env_flag("CUDF_AMD_JOIN_RADIX_MIN_BUILD", 3 << 20) || valid > nparts * 3500) return false;
     _rx_nparts = static_cast<int32_t>(nparts);
     hipStream_t const s = stream.value();
