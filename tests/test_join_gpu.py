@@ -704,3 +704,46 @@ def test_dense_ordered_probe_yields_pairs_in_probe_row_order(G, oracle, monkeypa
     assert np.array_equal(gl, np.arange(nl, dtype=gl.dtype))
     xl, xr = oracle.join(left, right, nulls_equal=False, kind="left")
     assert kat.sorted_pairs(gl, gr) == kat.sorted_pairs(xl, xr)
+
+
+@pytest.mark.parametrize("path", ["dense_ordered", "dense_partitioned", "radix"])
+@pytest.mark.parametrize("kind", ["inner", "left"])
+def test_partitioned_join_ranges_through_the_round3_paths(G, oracle, monkeypatch, path, kind):
+    """Chunked probing (partitioned_{inner,left}_join over row ranges of the left table, reference hash_join.hpp:276-441) with the
+    range probes going through the ordered direct probe / the one-pass left join, the partitioned dense probe and the LDS radix
+    join: the emitted left indices carry the range's first row, the union over the ranges is the whole join."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin, JoinPartitionContext
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(88)
+    nl, nr = 700_000, 90_000
+    if path == "radix":
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_BUILD", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_PROBE", "0")
+        rk = rng.permutation(300_000)[:nr].astype(np.int64) * 1_000_003
+        lk = rng.integers(0, 400_000, nl, dtype=np.int64) * 1_000_003
+    else:
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_ORDERED_MIN_PROBE", "0")
+        for k, v in (("MIN_BUILD", "0"), ("MIN_RANGE", "0"), ("MIN_PROBE", "0"), ("SLICE_LOG2", "10")):
+            monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PART_" + k, v)
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PROBE", "1" if path == "dense_ordered" else "2")
+        rk = rng.permutation(200_000)[:nr].astype(np.int64) - 5_000
+        lk = rng.integers(-30_000, 230_000, nl, dtype=np.int64)
+    lv, rv = rng.random(nl) > 0.05, rng.random(nr) > 0.05
+    hj = HashJoin(cudf_amd.Table([G.to_device((rk, rv))]), NullEquality.UNEQUAL)
+    left = cudf_amd.Table([G.to_device((lk, lv))])
+    ctx = getattr(hj, f"{kind}_join_match_context")(left)
+    counts = ctx._match_counts.to_numpy()[0]
+    bounds = [0, 3, 250_000, 250_000, 699_999, nl]
+    ls, rs = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        li, ri = getattr(hj, f"partitioned_{kind}_join")(JoinPartitionContext(ctx, a, b))
+        l, r = li.to_numpy()[0], ri.to_numpy()[0]
+        assert len(l) == int(counts[a:b].sum())
+        assert len(l) == 0 or (l.min() >= a and l.max() < b)
+        ls.append(l)
+        rs.append(r)
+    el, er = oracle.join([(lk, lv)], [(rk, rv)], nulls_equal=False, kind=kind)
+    assert kat.sorted_pairs(np.concatenate(ls), np.concatenate(rs)) == kat.sorted_pairs(el, er)
