@@ -160,7 +160,12 @@ struct radix_join_args {
   uint64_t out_capacity;
   int64_t probe_row_base;
   int32_t* overflow;       // bit 1: a build partition does not fit its table; bit 2: a partition's pairs did not fit its stage
+  int32_t left;            // left join: a probe record without a partner yields {probe row, JoinNoMatch}
 };
+// left join: the pairs {row, JoinNoMatch} of the probe rows with a NULL key (bit clear in mask), appended at *cursor (device word
+// holding the number of pairs written so far)
+void launch_radix_null_rows(bitmask_type const* mask, int64_t mask_offset, int64_t nrows, int64_t row_base, size_type* out_probe, size_type* out_build,
+                            unsigned long long out_capacity, unsigned long long* cursor, hipStream_t stream);
 void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_args, hipStream_t stream);
 // the largest number of rows of one partition (regions summed over its slices) -> *out_max (preset to 0)
 void launch_radix_partition_max(int32_t const* region_count, int32_t nparts, int32_t slices, int32_t* out_max, hipStream_t stream);

@@ -344,7 +344,8 @@ class hash_join_impl {
   static constexpr int32_t RADIX_TABLE_SLOTS = 8192, RADIX_FILL_LIMIT = 5200;
 
   // inner join of a big probe side against the radix-partitioned build side; nullopt: this probe side does not take it
-  std::optional<join_index_pair> radix_probe(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr, int64_t row_base) const
+  std::optional<join_index_pair> radix_probe(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr, int64_t row_base,
+                                             bool left_join = false) const
   {
     auto const& col = left.column(0);
     bool const probe_nulls = _has_nulls && col.has_nulls();
@@ -376,6 +377,7 @@ class hash_join_impl {
     a.pair_counts = static_cast<unsigned long long*>(counts.data());
     a.probe_row_base = row_base;
     a.overflow = static_cast<int32_t*>(ovf.data());
+    a.left = left_join ? 1 : 0;
     a.stage_cap = probe.cap2 * probe.slices2;  // (as many pairs as the partition has room for probe rows: enough unless keys repeat a lot)
     rmm::device_buffer stage{static_cast<std::size_t>(_rx_nparts) * static_cast<std::size_t>(a.stage_cap) * sizeof(uint64_t), s, tmp};
     a.stage = static_cast<uint64_t*>(stage.data());
@@ -390,16 +392,21 @@ class hash_join_impl {
     CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipStreamSynchronize(s));
     if ((h_ovf & 3) != 0) return std::nullopt;
-    CUDF_EXPECTS(total <= static_cast<unsigned long long>(std::numeric_limits<size_type>::max()),
+    // (left join: the probe rows with a NULL key never entered a partition; their {row, JoinNoMatch} pairs follow the partitions')
+    unsigned long long const null_rows = (left_join && probe_nulls) ? static_cast<unsigned long long>(col.null_count()) : 0ull;
+    unsigned long long const pairs_all = total + null_rows;
+    CUDF_EXPECTS(pairs_all <= static_cast<unsigned long long>(std::numeric_limits<size_type>::max()),
                  "Join result exceeds the maximum column size; use the *_join_size API and chunk the probe side.", std::overflow_error);
-    auto out_l = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(total), s, mr);
-    auto out_r = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(total), s, mr);
+    auto out_l = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(pairs_all), s, mr);
+    auto out_r = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(pairs_all), s, mr);
     a.out_probe    = out_l->data();
     a.out_build    = out_r->data();
-    a.out_capacity = total;
+    a.out_capacity = pairs_all;
     rmm::device_buffer d_args2{sizeof(join::radix_join_args), s, tmp};
     join::launch_radix_emit_staged(a, static_cast<join::radix_join_args*>(d_args2.data()), s);
     if ((h_ovf & 4) != 0) join::launch_radix_join(a, static_cast<join::radix_join_args*>(d_args2.data()), true, s);
+    if (null_rows != 0)  // (pair_counts[nparts] = the number of pairs of the partitions: the cursor the NULL rows append at)
+      join::launch_radix_null_rows(col.null_mask(), col.offset(), rows, row_base, a.out_probe, a.out_build, pairs_all, a.pair_counts + _rx_nparts, s);
     CUDF_HIP_TRY(hipStreamSynchronize(s));
     return join_index_pair{std::move(out_l), std::move(out_r)};
   }
@@ -736,8 +743,8 @@ class hash_join_impl {
         return std::nullopt;
       }
     };
-    if (_radix && k == 0) {  // big inner joins on one 8-byte key: both sides in LDS-sized partitions (engine.hpp)
-      auto r = or_nothing([&] { return radix_probe(left, stream, mr, row_base); });
+    if (_radix && (k == 0 || k == 1)) {  // big inner and left joins on one integer key: both sides in LDS-sized partitions (engine.hpp)
+      auto r = or_nothing([&] { return radix_probe(left, stream, mr, row_base, k == 1); });
       if (r.has_value()) {
         if (output_size.has_value())
           CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);

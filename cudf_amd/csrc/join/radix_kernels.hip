@@ -310,7 +310,9 @@ __device__ __forceinline__ uint32_t table_hash(uint64_t key)
 }
 constexpr int RJ_RPT = 4;  // probe records a thread loads before it walks the table for them (HBM latency: ~48 KB in flight per CU)
 
-template <bool RETRIEVE>
+// LEFT: a probe record without a partner yields the pair {probe row, JoinNoMatch} (left join; the probe rows the scatter dropped
+// - NULL keys - get theirs from k_radix_null_rows)
+template <bool RETRIEVE, bool LEFT>
 __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -433,17 +435,20 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
   auto walk_and_emit = [&](bool live, uint64_t key, size_type prow) {
     bool const special = live && key == RJ_EMPTY;
     bool walking       = live && !special;
+    bool found         = special && nspec != 0;
     uint32_t bkt       = table_hash(key) >> bshift;
     while (__any(walking)) {
       u64x2 pr{RJ_EMPTY, RJ_EMPTY};
       if (walking) pr = *reinterpret_cast<u64x2 const*>(keys + 2u * bkt);
       bool const w0 = walking && pr.x == key, w1 = walking && pr.x != RJ_EMPTY && pr.y == key;
+      found         = found || w0 || w1;
       emit2(prow, w0, w0 ? static_cast<size_type>(rows[2u * bkt]) : 0, w1, w1 ? static_cast<size_type>(rows[2u * bkt + 1]) : 0);
       walking = walking && pr.x != RJ_EMPTY && pr.y != RJ_EMPTY;  // an entry takes the first empty slot of its sequence
       bkt     = (bkt + 1) & bmask;
     }
     if (nspec != 0 && __any(special))
       for (uint32_t t = 0; t < nspec; ++t) emit2(prow, special, s_spec_rows[t], false, 0);
+    if constexpr (LEFT) emit2(prow, live && !found, JoinNoMatch, false, 0);
   };
   struct batch {
     uint64_t k[RJ_RPT];
@@ -518,7 +523,7 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
         int tot = 0;
 #pragma unroll
         for (int j = 0; j < RJ_RPT; ++j) {
-          m[j] = __ballot(nmatch[j] == 1);
+          m[j] = __ballot(nmatch[j] == 1 || (LEFT && live[j] && nmatch[j] == 0));
           tot += __popcll(m[j]);
         }
         if (tot != 0) {
@@ -529,6 +534,7 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
 #pragma unroll
           for (int j = 0; j < RJ_RPT; ++j) {
             if (nmatch[j] == 1) put(pos + __popcll(m[j] & below), static_cast<size_type>(cur.w[j] + a.probe_row_base), static_cast<size_type>(brow[j]));
+            else if (LEFT && live[j] && nmatch[j] == 0) put(pos + __popcll(m[j] & below), static_cast<size_type>(cur.w[j] + a.probe_row_base), JoinNoMatch);
             pos += __popcll(m[j]);
           }
         }
@@ -547,6 +553,45 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
     if (threadIdx.x == 0) {
       a.pair_counts[q] = s_cursor;
       if (s_cursor > static_cast<unsigned long long>(a.stage_cap)) atomicOr(a.overflow, 4);
+    }
+  }
+}
+
+// left join: the probe rows whose key is NULL (the scatter dropped them) -> {row, JoinNoMatch} pairs appended at *cursor
+__global__ void __launch_bounds__(256) k_radix_null_rows(bitmask_type const* __restrict__ mask, int64_t mask_offset, int64_t nrows, int64_t chunk,
+                                                         int64_t row_base, size_type* out_probe, size_type* out_build, unsigned long long out_capacity,
+                                                         unsigned long long* cursor)
+{
+  __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_n;
+  int64_t const begin = static_cast<int64_t>(blockIdx.x) * chunk, end = min(nrows, begin + chunk);
+  int const lane = threadIdx.x & 63;
+  // pass 1: how many; pass 2: where (one global atomic per workgroup)
+  uint32_t mine = 0;
+  for (int64_t r = begin + threadIdx.x; r < end; r += blockDim.x) mine += !((gload(mask + ((mask_offset + r) >> 5)) >> ((mask_offset + r) & 31)) & 1u);
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if (lane == 0 && mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_base = s_n ? atomicAdd(cursor, static_cast<unsigned long long>(s_n)) : 0ull;
+    s_n    = 0;
+  }
+  __syncthreads();
+  for (int64_t r0 = begin; r0 < end; r0 += blockDim.x) {
+    int64_t const r  = r0 + threadIdx.x;
+    bool const null_ = r < end && !((gload(mask + ((mask_offset + r) >> 5)) >> ((mask_offset + r) & 31)) & 1u);
+    unsigned long long const m = __ballot(null_);
+    uint32_t at = 0;
+    if (lane == 0 && m) at = atomicAdd(&s_n, static_cast<uint32_t>(__popcll(m)));
+    at = __builtin_amdgcn_readfirstlane(at);
+    if (null_) {
+      unsigned long long const o = s_base + at + __popcll(m & ((1ull << lane) - 1ull));
+      if (o < out_capacity) {
+        gstore(out_probe + o, static_cast<size_type>(r + row_base));
+        gstore(out_build + o, JoinNoMatch);
+      }
     }
   }
 }
@@ -625,7 +670,8 @@ void launch_radix_join(radix_join_args const& a, radix_join_args* d_args, bool r
   std::size_t const lds = static_cast<std::size_t>(a.cap) * 12 + 16;
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
-    for (void const* fn : {reinterpret_cast<void const*>(&k_radix_join<false>), reinterpret_cast<void const*>(&k_radix_join<true>)}) {
+    for (void const* fn : {reinterpret_cast<void const*>(&k_radix_join<false, false>), reinterpret_cast<void const*>(&k_radix_join<true, false>),
+                           reinterpret_cast<void const*>(&k_radix_join<false, true>), reinterpret_cast<void const*>(&k_radix_join<true, true>)}) {
       hipFuncAttributes attr{};
       CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
       CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
@@ -633,8 +679,23 @@ void launch_radix_join(radix_join_args const& a, radix_join_args* d_args, bool r
   });
   hipLaunchKernelGGL(k_store_radix_args<radix_join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{retrieve ? "join_retrieve" : "join_count", stream};
-  if (retrieve) hipLaunchKernelGGL(k_radix_join<true>, dim3(a.nparts), dim3(1024), lds, stream, d_args);
-  else hipLaunchKernelGGL(k_radix_join<false>, dim3(a.nparts), dim3(1024), lds, stream, d_args);
+  if (a.left != 0) {
+    if (retrieve) hipLaunchKernelGGL((k_radix_join<true, true>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
+    else hipLaunchKernelGGL((k_radix_join<false, true>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
+  } else {
+    if (retrieve) hipLaunchKernelGGL((k_radix_join<true, false>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
+    else hipLaunchKernelGGL((k_radix_join<false, false>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
+  }
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_radix_null_rows(bitmask_type const* mask, int64_t mask_offset, int64_t nrows, int64_t row_base, size_type* out_probe, size_type* out_build,
+                            unsigned long long out_capacity, unsigned long long* cursor, hipStream_t stream)
+{
+  cudf::detail::prof::scope prof_{"join_retrieve", stream};
+  int64_t const chunk = 65536;
+  hipLaunchKernelGGL(k_radix_null_rows, dim3(static_cast<unsigned>((nrows + chunk - 1) / chunk)), dim3(256), 0, stream, mask, mask_offset, nrows, chunk, row_base,
+                     out_probe, out_build, out_capacity, cursor);
   CUDF_HIP_TRY(hipGetLastError());
 }
 

@@ -473,8 +473,9 @@ def _kernels_of(fn):
     return out, {k: v[0] for k, v in _lib.profile_report().items()}  # {kernel: launches}
 
 
+@pytest.mark.parametrize("kind", ["inner", "left"])
 @pytest.mark.parametrize("shape", ["unique", "duplicates", "nulls", "marker_key", "four_pairs_per_row"])
-def test_radix_join_matches_oracle(G, oracle, force_radix_join, shape):
+def test_radix_join_matches_oracle(G, oracle, force_radix_join, shape, kind):
     """Both sides through the two scatter levels into 2048 LDS-sized partitions, then the per-partition LDS table: unique build
     keys; duplicates on both sides (several pairs per probe row); 5 % NULLs with null_equality::UNEQUAL; rows whose key is the
     table's empty-slot marker (they take the side list); every probe row matching four build rows (more pairs than the
@@ -498,9 +499,11 @@ def test_radix_join_matches_oracle(G, oracle, force_radix_join, shape):
     if shape == "marker_key":
         rk[[5, 77, 4000]] = _RJ_EMPTY
         lk[rng.integers(0, nl, 50)] = _RJ_EMPTY
-    (li, ri), kernels = _kernels_of(lambda: G.join(left, right, nulls_equal=nulls_equal, kind="inner"))
-    assert "join_partition_level2" in kernels, kernels
-    el, er = oracle.join(left, right, nulls_equal=nulls_equal, kind="inner")
+    # (left joins: a probe record without a partner yields {row, JoinNoMatch} inside its partition, the probe rows with a NULL key
+    # get theirs from k_radix_null_rows)
+    (li, ri), kernels = _kernels_of(lambda: G.join(left, right, nulls_equal=nulls_equal, kind=kind))
+    assert kernels.get("join_partition_level2") == 2, kernels
+    el, er = oracle.join(left, right, nulls_equal=nulls_equal, kind=kind)
     assert len(li) == len(el)
     assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
 
