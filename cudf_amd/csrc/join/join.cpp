@@ -733,9 +733,22 @@ class hash_join_impl {
       }
     }
     int const k = kind == join_kind::INNER_JOIN ? 0 : kind == join_kind::LEFT_JOIN ? 1 : 2;
-    hipStream_t const s = stream.value();
+    if (auto r = probe_partitioned_paths(left, k, stream, mr, row_base); r.has_value()) {
+      if (output_size.has_value())
+        CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
+      return std::move(*r);
+    }
+    return probe_tables(left, kind, k, output_size, stream, mr, row_base);
+  }
+
+ private:
+  // ---- round 3: the paths in front of the tables' count / retrieve passes (engine.hpp), in the order they are tried. nullopt: none
+  // of them takes this call (kind, key shape, size, a region that overflowed, no room for the scratch).
+  std::optional<join_index_pair> probe_partitioned_paths(table_view const& left, int k, stream_ref stream, rmm::device_async_resource_ref mr,
+                                                         int64_t row_base) const
+  {
     // (the partitioned joins take scratch of ~3x the probe column - regions sized for the worst case, the pair stage: when the pool
-    // cannot give it, the direct passes below still can run)
+    // cannot give it, the direct passes still can run)
     auto or_nothing = [](auto&& f) -> std::optional<join_index_pair> {
       try {
         return f();
@@ -743,60 +756,61 @@ class hash_join_impl {
         return std::nullopt;
       }
     };
-    if (_radix && (k == 0 || k == 1)) {  // big inner and left joins on one integer key: both sides in LDS-sized partitions (engine.hpp)
-      auto r = or_nothing([&] { return radix_probe(left, stream, mr, row_base, k == 1); });
-      if (r.has_value()) {
-        if (output_size.has_value())
-          CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
-        return std::move(*r);
-      }
+    // big inner and left joins on one sparse integer key: both sides in LDS-sized partitions
+    if (_radix && (k == 0 || k == 1)) {
+      if (auto r = or_nothing([&] { return radix_probe(left, stream, mr, row_base, k == 1); }); r.has_value()) return r;
     }
-    // inner joins on a dense unique key: the ordered direct probe (pairs in probe-row order: CUDF_AMD_JOIN_DENSE_PROBE=1, the
-    // default) or probe rows partitioned by key range (=2: ~0.2 ms less at C3, pairs partition-major); 0: neither
+    // a dense unique table. CUDF_AMD_JOIN_DENSE_PROBE: 1 (default) inner joins by the ordered direct probe (pairs in probe-row
+    // order), 2 by probe rows partitioned by key range (~0.6 ms less at C3, pairs partition-major), 0 neither; left joins in one pass
     int64_t const dense_probe = env_flag("CUDF_AMD_JOIN_DENSE_PROBE", 1);
     bool const unique_table   = (_dense && !_dense_has_dups) || _dense_part;
     if (unique_table && k == 0 && dense_probe == 1) {
-      auto r = or_nothing([&] { return dense_ordered_probe(left, stream, mr, row_base); });
-      if (r.has_value()) {
-        if (output_size.has_value())
-          CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
-        return std::move(*r);
-      }
+      if (auto r = or_nothing([&] { return dense_ordered_probe(left, stream, mr, row_base); }); r.has_value()) return r;
     }
-    // LEFT join against a dense unique table: one pair per probe row, in order - a single pass (engine.hpp launch_dense_left_direct)
-    if (unique_table && k == 1 && dense_probe != 0 && single_int_width(left) == _keyw && _keyw != 0 &&
-        !((_has_nulls && left.column(0).has_nulls()) && _nulls_equal == null_equality::EQUAL) &&
-        left.num_rows() >= env_flag("CUDF_AMD_JOIN_DENSE_ORDERED_MIN_PROBE", 1 << 20) && left.num_rows() + row_base <= (int64_t{1} << 31) - 1) {
-      auto const& col  = left.column(0);
-      std::size_t const n = static_cast<std::size_t>(left.num_rows());
-      if (output_size.has_value())
-        CUDF_EXPECTS(*output_size == n, "hash join: output_size does not match the number of matches", std::invalid_argument);
-      auto out_l = std::make_unique<rmm::device_uvector<size_type>>(n, s, mr);
-      auto out_r = std::make_unique<rmm::device_uvector<size_type>>(n, s, mr);
-      join::dense_stage_args a{};
-      a.keys           = key_bytes(col, _keyw);
-      a.key_width      = _keyw;
-      a.key_signed     = _key_signed ? 1 : 0;
-      a.mask           = (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr;
-      a.mask_offset    = col.offset();
-      a.nrows          = left.num_rows();
-      a.dense_lo       = _dense_lo;
-      a.dense_range    = _dense_range;
-      a.head           = static_cast<int32_t const*>(_dense_head.data());
-      a.probe_row_base = row_base;
-      rmm::device_buffer d_args_l{sizeof(join::dense_stage_args), s, cudf::get_current_device_resource_ref()};
-      join::launch_dense_left_direct(a, static_cast<join::dense_stage_args*>(d_args_l.data()), out_l->data(), out_r->data(), s);
-      CUDF_HIP_TRY(hipStreamSynchronize(s));
-      return {std::move(out_l), std::move(out_r)};
+    if (unique_table && k == 1 && dense_probe != 0) {
+      if (auto r = or_nothing([&] { return dense_left_direct(left, stream, mr, row_base); }); r.has_value()) return r;
     }
-    if (_dense_part && k == 0 && dense_probe != 0) {  // probe rows partitioned by key range (engine.hpp)
-      auto r = or_nothing([&] { return dense_part_probe(left, stream, mr, row_base); });
-      if (r.has_value()) {
-        if (output_size.has_value())
-          CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
-        return std::move(*r);
-      }
+    if (_dense_part && k == 0 && dense_probe != 0) {
+      if (auto r = or_nothing([&] { return dense_part_probe(left, stream, mr, row_base); }); r.has_value()) return r;
     }
+    return std::nullopt;
+  }
+
+  // LEFT join against a dense unique table: one pair per probe row, in order - a single pass (engine.hpp launch_dense_left_direct)
+  std::optional<join_index_pair> dense_left_direct(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr, int64_t row_base) const
+  {
+    auto const& col        = left.column(0);
+    bool const probe_nulls = _has_nulls && col.has_nulls();
+    if (single_int_width(left) != _keyw || _keyw == 0 || (probe_nulls && _nulls_equal == null_equality::EQUAL) ||
+        left.num_rows() < env_flag("CUDF_AMD_JOIN_DENSE_ORDERED_MIN_PROBE", 1 << 20) || left.num_rows() + row_base > (int64_t{1} << 31) - 1)
+      return std::nullopt;
+    hipStream_t const s = stream.value();
+    std::size_t const n = static_cast<std::size_t>(left.num_rows());
+    auto out_l          = std::make_unique<rmm::device_uvector<size_type>>(n, s, mr);
+    auto out_r          = std::make_unique<rmm::device_uvector<size_type>>(n, s, mr);
+    join::dense_stage_args a{};
+    a.keys           = key_bytes(col, _keyw);
+    a.key_width      = _keyw;
+    a.key_signed     = _key_signed ? 1 : 0;
+    a.mask           = probe_nulls ? col.null_mask() : nullptr;
+    a.mask_offset    = col.offset();
+    a.nrows          = left.num_rows();
+    a.dense_lo       = _dense_lo;
+    a.dense_range    = _dense_range;
+    a.head           = static_cast<int32_t const*>(_dense_head.data());
+    a.probe_row_base = row_base;
+    rmm::device_buffer d_args{sizeof(join::dense_stage_args), s, cudf::get_current_device_resource_ref()};
+    join::launch_dense_left_direct(a, static_cast<join::dense_stage_args*>(d_args.data()), out_l->data(), out_r->data(), s);
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    return join_index_pair{std::move(out_l), std::move(out_r)};
+  }
+
+  // ---- the tables' own passes: count (match cache, per-workgroup pair counts) -> scan -> retrieve, over the open-addressing table
+  // in HBM or the dense direct-address table (rounds 1 and 2)
+  [[nodiscard]] join_index_pair probe_tables(table_view const& left, join_kind kind, int k, std::optional<std::size_t> output_size, stream_ref stream,
+                                             rmm::device_async_resource_ref mr, int64_t row_base) const
+  {
+    hipStream_t const s = stream.value();
     ensure_classic(stream);
     rmm::device_buffer d_args{sizeof(join_args), s, cudf::get_current_device_resource_ref()};
     // ---- size: given, or counted with one probe pass (reference: compute_join_output_size, size_impl.cuh:26-61)
