@@ -40,7 +40,10 @@ __global__ void __launch_bounds__(256) k_collapse_runs(collapse_args const* __re
   plan_dev const& p      = a.plan;
   __shared__ uint32_t s_cursor;
   __shared__ int s_overflow;
-  constexpr int R = 4;  // row sets in flight per wave
+  constexpr int R = NACCT >= 3 ? 2 : 4;  // row sets in flight per wave (four with three or four accumulators took 172 VGPRs)
+  // (tried: the scan's steps inside a row of 16 lanes as DPP row_shr moves + three readlane carries across rows instead of six
+  // ds_bpermute steps - one scanned accumulator 3.5 -> 4.1 ms per 1B rows, three 7.2 -> 7.2 ms: the kernel is bound by instruction
+  // issue - ~280 wave instructions per 64 rows with three scans - not by the LDS permutes)
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   int const item = blockIdx.x;
   if (threadIdx.x == 0) {
