@@ -324,6 +324,17 @@ def test_fuzz_joins_against_oracle(G, oracle, seed, monkeypatch):
         monkeypatch.setenv("CUDF_AMD_JOIN_PARTITIONED", "1")
         monkeypatch.setenv("CUDF_AMD_JOIN_SLICE_MIN_MB", "0")
         monkeypatch.setenv("CUDF_AMD_JOIN_PARTITION_MIN_ROWS", "1")
+    if seed % 4 in (1, 2):
+        # the round-3 paths at fuzz sizes: whenever a case is ONE integer key column of 4 or 8 bytes whose NULLs never match, it goes
+        # through the LDS radix join (seed % 4 == 1: dense tables off) or the dense table's ordered / partitioned / one-pass-left
+        # probes (seed % 4 == 2), sliced columns and validity offsets included
+        for k, v in (("RADIX_MIN_BUILD", "0"), ("RADIX_MIN_PROBE", "0"), ("DENSE_MIN_ROWS", "1"), ("DENSE_ORDERED_MIN_PROBE", "0"),
+                     ("DENSE_PART_MIN_BUILD", "0"), ("DENSE_PART_MIN_RANGE", "0"), ("DENSE_PART_MIN_PROBE", "0"), ("DENSE_PART_SLICE_LOG2", "8")):
+            monkeypatch.setenv("CUDF_AMD_JOIN_" + k, v)
+        if seed % 4 == 1:
+            monkeypatch.setenv("CUDF_AMD_JOIN_DENSE", "0")
+        else:
+            monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PROBE", str(1 + (seed // 4) % 2))
     nl = int(rng.choice([0, 1, 50, 3_000, 120_000]))
     nr = int(rng.choice([0, 1, 40, 2_000, 30_000]))
     ncols = int(rng.integers(1, 4))
