@@ -68,6 +68,17 @@ int single_int_width(table_view const& t)
   auto const w   = size_of_id(id);
   return (cls == CLS_SINT || cls == CLS_UINT) && (w == 8 || w == 4) ? static_cast<int>(w) : 0;
 }
+// the table is TWO 4-byte integer key columns: the radix join packs them into its 8-byte key
+bool is_two_int32(table_view const& t)
+{
+  if (t.num_columns() != 2) return false;
+  for (int c = 0; c < 2; ++c) {
+    auto const id  = t.column(c).type().id();
+    auto const cls = class_of(id);
+    if (!(cls == CLS_SINT || cls == CLS_UINT) || size_of_id(id) != 4) return false;
+  }
+  return true;
+}
 uint64_t const* key_bytes(column_view const& c, int width)
 {
   return reinterpret_cast<uint64_t const*>(c.head<uint8_t>() + static_cast<std::size_t>(c.offset()) * static_cast<std::size_t>(width));
@@ -101,6 +112,12 @@ struct dev_scalar {  // one T in device memory, stream ordered
 };
 }  // namespace
 
+struct second_key {  // the second of two packed 4-byte key columns (radix_scatter_args::keys2)
+  uint32_t const* keys{nullptr};
+  bitmask_type const* mask{nullptr};
+  int64_t mask_offset{0};
+};
+
 class hash_join_impl {
  public:
   hash_join_impl(table_view const& right, bool has_nulls, null_equality compare_nulls, double load_factor,
@@ -123,12 +140,15 @@ class hash_join_impl {
     // (one 4-byte integer key: only the partitioned joins take it - they widen it in their first scatter level; everything else
     // about such a table goes through the generic row comparator of the open-addressing table)
     _keyw         = (!build_check_nulls || _nulls_equal != null_equality::EQUAL) ? single_int_width(right) : 0;
+    // (two 4-byte integer key columns: the radix join packs them into its 8-byte key; no dense table for those)
+    _pack2        = (!build_check_nulls || _nulls_equal != null_equality::EQUAL) && is_two_int32(right);
+    if (_pack2) _keyw = 4;
     _key_signed   = _keyw != 0 && class_of(right.column(0).type().id()) == CLS_SINT;
     _key64        = key64;
     _classic_load = load_factor;
     // Dense build keys (one 8-byte integer key column, NULLs never match, valid values within a small range): a direct-address
     // table over [min, max] replaces the hash table - see engine.hpp. Decided from the exact minimum / maximum of the build keys.
-    if (_keyw != 0 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
+    if (_keyw != 0 && !_pack2 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
       hipStream_t const s = stream.value();
       auto tmp            = cudf::get_current_device_resource_ref();
       bool const is_signed = class_of(right.column(0).type().id()) == CLS_SINT;
@@ -241,8 +261,19 @@ class hash_join_impl {
     int64_t cap2{0};
     int32_t slices2{0};
   };
+  second_key second_of(table_view const& t) const
+  {
+    second_key k2{};
+    if (_pack2) {
+      auto const& c = t.column(1);
+      k2.keys       = reinterpret_cast<uint32_t const*>(key_bytes(c, 4));
+      k2.mask       = (_has_nulls && c.has_nulls()) ? c.null_mask() : nullptr;
+      k2.mask_offset = c.offset();
+    }
+    return k2;
+  }
   bool radix_partition(uint64_t const* keys, bitmask_type const* mask, int64_t mask_offset, int64_t nrows, int64_t valid_rows, radix_side& out,
-                       stream_ref stream, rmm::device_async_resource_ref mr2) const
+                       stream_ref stream, rmm::device_async_resource_ref mr2, second_key k2) const
   {
     hipStream_t const s = stream.value();
     auto tmp            = cudf::get_current_device_resource_ref();
@@ -271,6 +302,9 @@ class hash_join_impl {
     a1.keys         = keys;
     a1.key_width    = _keyw;
     a1.key_signed   = _key_signed ? 1 : 0;
+    a1.keys2        = k2.keys;
+    a1.mask2        = k2.mask;
+    a1.mask2_offset = k2.mask_offset;
     a1.mask         = mask;
     a1.mask_offset  = mask_offset;
     a1.nrows        = nrows;
@@ -316,7 +350,8 @@ class hash_join_impl {
     if (env_flag("CUDF_AMD_JOIN_RADIX", 1) == 0) return false;
     auto const& col     = right.column(0);
     int64_t const rows  = right.num_rows();
-    int64_t const valid = rows - (col.nullable() ? col.null_count() : 0);
+    // (two packed columns: the rows with a NULL in either are dropped; their number is at least the larger of the two null counts)
+    int64_t const valid = rows - std::max<int64_t>(col.nullable() ? col.null_count() : 0, (_pack2 && right.column(1).nullable()) ? right.column(1).null_count() : 0);
     // partitions: a power of two with at most ~3500 build rows each (LDS tables of 8192 slots: load <= 0.43), 128 x (16 ... 256)
     int64_t const part_rows = std::clamp<int64_t>(env_flag("CUDF_AMD_JOIN_RADIX_PART_ROWS", 3500), 256, 3500);
     int64_t nparts = 2048;
@@ -324,7 +359,8 @@ class hash_join_impl {
     if (valid < env_flag("CUDF_AMD_JOIN_RADIX_MIN_BUILD", 3 << 20) || valid > nparts * 3500) return false;
     _rx_nparts = static_cast<int32_t>(nparts);
     hipStream_t const s = stream.value();
-    if (!radix_partition(key_bytes(col, _keyw), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, valid, _rx_build, stream, _mr))
+    if (!radix_partition(key_bytes(col, _keyw), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, valid, _rx_build, stream, _mr,
+                         second_of(right)))
       return false;
     // every partition must fit its LDS table
     auto tmp = cudf::get_current_device_resource_ref();
@@ -349,14 +385,19 @@ class hash_join_impl {
   {
     auto const& col = left.column(0);
     bool const probe_nulls = _has_nulls && col.has_nulls();
-    if (single_int_width(left) != _keyw || (probe_nulls && _nulls_equal == null_equality::EQUAL)) return std::nullopt;
+    bool const second_nulls = _pack2 && _has_nulls && left.num_columns() == 2 && left.column(1).has_nulls();
+    if ((_pack2 ? !is_two_int32(left) : single_int_width(left) != _keyw) || ((probe_nulls || second_nulls) && _nulls_equal == null_equality::EQUAL))
+      return std::nullopt;
+    // (left join of two packed columns with NULLs: the rows dropped for a NULL in either column are not one column's null count)
+    if (left_join && _pack2 && (probe_nulls || second_nulls)) return std::nullopt;
     int64_t const rows  = left.num_rows();
-    int64_t const valid = rows - (col.nullable() ? col.null_count() : 0);
+    int64_t const valid = rows - std::max<int64_t>(col.nullable() ? col.null_count() : 0, second_nulls ? left.column(1).null_count() : 0);
     if (rows < env_flag("CUDF_AMD_JOIN_RADIX_MIN_PROBE", 8 << 20) || rows > (int64_t{1} << 31) - 1) return std::nullopt;
     hipStream_t const s = stream.value();
     auto tmp            = cudf::get_current_device_resource_ref();
     radix_side probe;
-    if (!radix_partition(key_bytes(col, _keyw), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, valid, probe, stream, tmp)) return std::nullopt;
+    if (!radix_partition(key_bytes(col, _keyw), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, valid, probe, stream, tmp, second_of(left)))
+      return std::nullopt;
     rmm::device_buffer counts{(static_cast<std::size_t>(_rx_nparts) + 1) * sizeof(unsigned long long), s, tmp}, ovf{sizeof(int32_t), s, tmp},
       d_args{sizeof(join::radix_join_args), s, tmp};
     CUDF_HIP_TRY(hipMemsetAsync(ovf.data(), 0, sizeof(int32_t), s));
@@ -996,6 +1037,7 @@ class hash_join_impl {
   bool _key64{false};
   int _keyw{0};             // 8 / 4: one integer key column of that width whose NULLs never match (the partitioned joins); 0: none
   bool _key_signed{false};
+  bool _pack2{false};       // two 4-byte integer key columns, packed into the radix join's 8-byte key (_keyw == 4)
   double _classic_load{0.5};
   // the open-addressing table in HBM: built by the constructor, or on first need when the build side took the radix partitions
   mutable std::mutex _classic_mu;

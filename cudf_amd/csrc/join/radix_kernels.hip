@@ -111,13 +111,18 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
       int64_t const row = tile + static_cast<int64_t>(k) * B + threadIdx.x;
       if (row < end) {
         if constexpr (LEVEL == 1) {
-          if (a.key_width == 4) {  // a 4-byte integer key column: widened here (sign-extended when the type is signed)
+          if (a.keys2 != nullptr) {  // TWO 4-byte integer key columns, packed into the 8-byte key (a bijection: rows are equal iff both are)
+            uint32_t const c0 = gload(reinterpret_cast<uint32_t const*>(a.keys) + row), c1 = gload(a.keys2 + row);
+            t.k[k]            = static_cast<uint64_t>(c0) | (static_cast<uint64_t>(c1) << 32);
+          } else if (a.key_width == 4) {  // a 4-byte integer key column: widened here (sign-extended when the type is signed)
             uint32_t const k32 = gload(reinterpret_cast<uint32_t const*>(a.keys) + row);
             t.k[k]             = a.key_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32);
           } else {
             t.k[k] = gload(a.keys + row);
           }
           t.r[k] = a.mask != nullptr ? gload(a.mask + ((a.mask_offset + row) >> 5)) : 0xffffffffu;
+          // (a NULL in the second column drops the row as well: the word the later test reads becomes all zeros)
+          if (a.mask2 != nullptr && !((gload(a.mask2 + ((a.mask2_offset + row) >> 5)) >> ((a.mask2_offset + row) & 31)) & 1u)) t.r[k] = 0;
         } else {
           int64_t const ri = record_of(row, reg_hint[k]);
           t.k[k]           = gload(a.in_key + ri);
@@ -628,6 +633,7 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
 {
   bool const dense = a.dense != 0;
   CUDF_EXPECTS(a.level != 1 || a.key_width == 4 || a.key_width == 8, "radix join scatter: key width");
+  CUDF_EXPECTS(a.keys2 == nullptr || (a.level == 1 && a.key_width == 4 && a.dense == 0), "radix join scatter: two packed key columns are 4 bytes each");
   CUDF_EXPECTS(a.P >= 16 && a.P <= 256 && (a.P & (a.P - 1)) == 0 && a.capl >= 5 && a.shift < 64 && a.region_cap % 32 == 0 && a.slices >= 1,
                "radix join scatter: geometry");
   CUDF_EXPECTS(dense ? (a.level == 1 && (a.P << a.capl) <= 2 * RADIX_RING_SLOTS && a.dense_range <= (uint64_t{1} << 32) &&

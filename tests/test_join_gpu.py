@@ -761,3 +761,27 @@ def test_partitioned_join_ranges_through_the_round3_paths(G, oracle, monkeypatch
         rs.append(r)
     el, er = oracle.join([(lk, lv)], [(rk, rv)], nulls_equal=False, kind=kind)
     assert kat.sorted_pairs(np.concatenate(ls), np.concatenate(rs)) == kat.sorted_pairs(el, er)
+
+
+@pytest.mark.parametrize("kind", ["inner", "left"])
+@pytest.mark.parametrize("nulls", [False, True])
+def test_radix_join_packs_two_four_byte_key_columns(G, oracle, force_radix_join, kind, nulls):
+    """TWO 4-byte integer key columns (int32, uint32) are packed into the radix join's 8-byte key by its first scatter level -
+    rows are equal iff both columns are; a NULL in either column drops the row (UNEQUAL). Duplicates on both sides, negative
+    values. Left joins take the path when no probe column has NULLs; with NULLs they fall back to the hash table (still right)."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng(55 + int(nulls))
+    nl, nr = 600_000, 100_000
+    a_pool = rng.integers(-2**31, 2**31 - 1, 3000, dtype=np.int64).astype(np.int32)
+    b_pool = rng.integers(0, 2**32 - 1, 80, dtype=np.int64).astype(np.uint32)
+    ra, rb = a_pool[rng.integers(0, 2500, nr)], b_pool[rng.integers(0, 60, nr)]
+    la, lb = a_pool[rng.integers(0, 3000, nl)], b_pool[rng.integers(0, 80, nl)]
+    def col(x, t):
+        return HostColumn(x, (rng.random(len(x)) > 0.05) if nulls else None, t)
+    left, right = [col(la, "int32"), col(lb, "uint32")], [col(ra, "int32"), col(rb, "uint32")]
+    (li, ri), kernels = _kernels_of(lambda: G.join(left, right, nulls_equal=False, kind=kind))
+    expect_radix_probe = not (kind == "left" and nulls)
+    assert kernels.get("join_partition_level2") == (2 if expect_radix_probe else 1), kernels
+    el, er = oracle.join(left, right, nulls_equal=False, kind=kind)
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
