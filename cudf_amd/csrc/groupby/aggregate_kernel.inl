@@ -245,11 +245,19 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
     }
   };
   auto hash_of = [&](uint64_t const (&key)[KUT]) {
-    uint64_t h = 0x9e3779b97f4a7c15ull;
+    if constexpr (KUT == 1) {
+      // one key unit: ONE 64-bit multiply, halves swapped (the table's bucket comes from the low 32 bits of the result = the high
+      // half of the product, which every key bit reaches; the tag from its middle). The partition a row is in was chosen from
+      // mix64's top bits, a different function, so the buckets of a partition's keys stay spread.
+      uint64_t const x = (key[0] & kmask[0]) * 0x9e3779b97f4a7c15ull;
+      return ((x >> 32) | (x << 32)) ^ (x >> 15);
+    } else {
+      uint64_t h = 0x9e3779b97f4a7c15ull;
 #pragma unroll
-    for (int u = 0; u < KUT; ++u)
-      if (u < KU) h = mix64(h ^ (key[u] & kmask[u]));
-    return h;
+      for (int u = 0; u < KUT; ++u)
+        if (u < KU) h = mix64(h ^ (key[u] & kmask[u]));
+      return h;
+    }
   };
   // one row, unbatched (tail rows)
   auto process = [&](int64_t r, uint64_t const (&key)[KUT], uint64_t const (&pay)[PAYT > 0 ? PAYT : 1], uint32_t valvalid) {
