@@ -29,19 +29,23 @@ __global__ void k_store_dense_part_args(dense_part_args v, dense_part_args* dst)
 // The launch boundary is what keeps an XCD on one slice: with one launch for all partitions the workgroups of an XCD drifted over
 // many partitions (a workgroup's share of a partition is ~6 batches) and every lookup fetched its sector from beyond L2
 // (FETCH_SIZE: 5.6 GB for 1.1 GB of records + 142M lookups).
+// (G: partitions per XCD and launch, one after the other - the store pass takes two: its launches are short and it only writes)
 template <typename F>
-__device__ __forceinline__ void for_each_region(dense_part_args const& a, int p0, F&& f)
+__device__ __forceinline__ void for_each_region(dense_part_args const& a, int p0, int G, F&& f)
 {
-  int const p = p0 + (blockIdx.x & 7), w = blockIdx.x >> 3, W = gridDim.x >> 3;
-  if (p >= a.P) return;
-  for (int s = w; s < a.S; s += W) f(static_cast<int64_t>(p) * a.S + s);
+  int const w = blockIdx.x >> 3, W = gridDim.x >> 3;
+  for (int g = 0; g < G; ++g) {
+    int const p = p0 + 8 * g + (blockIdx.x & 7);
+    if (p >= a.P) return;
+    for (int s = w; s < a.S; s += W) f(static_cast<int64_t>(p) * a.S + s);
+  }
 }
 
-__global__ void __launch_bounds__(256) k_dense_part_store(dense_part_args const* __restrict__ ap, int p0)
+__global__ void __launch_bounds__(256) k_dense_part_store(dense_part_args const* __restrict__ ap, int p0, int G)
 {
   dense_part_args const& a = *ap;
   if (*a.overflow != 0) return;
-  for_each_region(a, p0, [&](int64_t reg) {
+  for_each_region(a, p0, G, [&](int64_t reg) {
     int32_t const cnt   = min(max(a.region_count[reg], 0), static_cast<int32_t>(a.region_cap));
     uint64_t const* rec = a.recs + reg * a.region_cap;
     for (int32_t i0 = 0; i0 < cnt; i0 += 256 * 4) {
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const
   uint64_t* stage      = a.stage + static_cast<int64_t>(blockIdx.x) * a.stage_cap;
   if (threadIdx.x == 0) s_cursor = a.pair_counts[blockIdx.x];
   __syncthreads();
-  for_each_region(a, p0, [&](int64_t reg) {
+  for_each_region(a, p0, 1, [&](int64_t reg) {
     int32_t const cnt   = ok ? min(max(a.region_count[reg], 0), static_cast<int32_t>(a.region_cap)) : 0;
     uint64_t const* rec = a.recs + reg * a.region_cap;
     constexpr int R = 8;  // records in flight per thread: a region is ~12 records per thread, latency is what a launch pays for
@@ -263,7 +267,7 @@ void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, 
                "partitioned dense join: arguments");
   hipLaunchKernelGGL(k_store_dense_part_args, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_build", stream};
-  for (int p0 = 0; p0 < a.P_used; p0 += 8) hipLaunchKernelGGL(k_dense_part_store, dim3(dense_part_grid()), dim3(256), 0, stream, d_args, p0);
+  for (int p0 = 0; p0 < a.P_used; p0 += 16) hipLaunchKernelGGL(k_dense_part_store, dim3(dense_part_grid()), dim3(256), 0, stream, d_args, p0, 2);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
