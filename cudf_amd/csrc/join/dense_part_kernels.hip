@@ -62,6 +62,16 @@ __global__ void __launch_bounds__(256) k_dense_part_store(dense_part_args const*
   });
 }
 
+// sum of the (non-negative) region counts -> *out (preset to 0): the number of records a scatter produced
+__global__ void __launch_bounds__(256) k_sum_region_counts(int32_t const* __restrict__ counts, int64_t n, unsigned long long* out)
+{
+  unsigned long long c = 0;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+    c += static_cast<unsigned long long>(max(counts[i], 0));
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 // entries of head[0, n) that hold a row (>= 0) -> *out (preset to 0)
 __global__ void __launch_bounds__(256) k_dense_count_filled(int32_t const* __restrict__ head, uint64_t n, unsigned long long* out)
 {
@@ -268,6 +278,12 @@ void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, 
   hipLaunchKernelGGL(k_store_dense_part_args, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_build", stream};
   for (int p0 = 0; p0 < a.P_used; p0 += 16) hipLaunchKernelGGL(k_dense_part_store, dim3(dense_part_grid()), dim3(256), 0, stream, d_args, p0, 2);
+  CUDF_HIP_TRY(hipGetLastError());
+}
+
+void launch_sum_region_counts(int32_t const* counts, int64_t n, unsigned long long* out, hipStream_t stream)
+{
+  hipLaunchKernelGGL(k_sum_region_counts, dim3(static_cast<unsigned>(std::clamp<int64_t>((n + 255) / 256, 1, 256))), dim3(256), 0, stream, counts, n, out);
   CUDF_HIP_TRY(hipGetLastError());
 }
 

@@ -223,6 +223,7 @@ void launch_dense_left_direct(dense_stage_args const& a, dense_stage_args* d_arg
 
 void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);
 void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long long* out, hipStream_t stream);
+void launch_sum_region_counts(int32_t const* counts, int64_t n, unsigned long long* out, hipStream_t stream);  // *out preset to 0
 void launch_dense_part_lookup(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);
 
 void launch_build(join_args const& a, join_args* d_args, hipStream_t stream);

@@ -537,20 +537,19 @@ class hash_join_impl {
     dense_side side;
     dense_partition(key_bytes(col, _keyw), (_has_nulls && col.has_nulls()) ? col.null_mask() : nullptr, col.offset(), rows, side, stream);
     auto a = dense_part_args_of(side);
-    rmm::device_buffer d_args{sizeof(join::dense_part_args), s, tmp}, filled{sizeof(unsigned long long), s, tmp};
-    CUDF_HIP_TRY(hipMemsetAsync(filled.data(), 0, sizeof(unsigned long long), s));
+    // {filled table entries, records the scatter produced}: equal <=> no build key repeats
+    rmm::device_buffer d_args{sizeof(join::dense_part_args), s, tmp}, tally{2 * sizeof(unsigned long long), s, tmp};
+    CUDF_HIP_TRY(hipMemsetAsync(tally.data(), 0, 2 * sizeof(unsigned long long), s));
+    auto* d_tally = static_cast<unsigned long long*>(tally.data());
     join::launch_dense_part_store(a, static_cast<join::dense_part_args*>(d_args.data()), s);
-    join::launch_dense_count_filled(a.head, _dense_range, static_cast<unsigned long long*>(filled.data()), s);
-    std::vector<int32_t> h_counts(static_cast<std::size_t>(side.P) * static_cast<std::size_t>(side.S));
-    unsigned long long h_filled = 0;
-    int32_t h_ovf               = 0;
-    CUDF_HIP_TRY(hipMemcpyAsync(h_counts.data(), side.counts.data(), side.counts.size(), hipMemcpyDeviceToHost, s));
-    CUDF_HIP_TRY(hipMemcpyAsync(&h_filled, filled.data(), sizeof(h_filled), hipMemcpyDeviceToHost, s));
+    join::launch_dense_count_filled(a.head, _dense_range, d_tally, s);
+    join::launch_sum_region_counts(a.region_count, static_cast<int64_t>(side.P) * side.S, d_tally + 1, s);
+    unsigned long long h_tally[2] = {0, 0};
+    int32_t h_ovf                 = 0;
+    CUDF_HIP_TRY(hipMemcpyAsync(h_tally, d_tally, sizeof(h_tally), hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, side.ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipStreamSynchronize(s));
-    unsigned long long records = 0;
-    for (int32_t c : h_counts) records += static_cast<unsigned long long>(std::max(c, 0));
-    if (h_ovf != 0 || records != h_filled) {
+    if (h_ovf != 0 || h_tally[0] != h_tally[1]) {
       CUDF_HIP_TRY(hipMemsetAsync(_dense_head.data(), 0xff, _dense_head.size(), s));
       return false;
     }
