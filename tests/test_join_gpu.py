@@ -785,3 +785,34 @@ def test_radix_join_packs_two_four_byte_key_columns(G, oracle, force_radix_join,
     el, er = oracle.join(left, right, nulls_equal=False, kind=kind)
     assert len(li) == len(el)
     assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+
+
+@pytest.mark.parametrize("path", ["dense", "radix"])
+def test_round3_join_paths_edge_cases(G, oracle, monkeypatch, path):
+    """No pair at all (every probe key outside the build keys), a probe side that is all NULL, a probe side of one row, on the
+    ordered dense probe / one-pass left join and on the radix join: empty or all-JoinNoMatch results of the right sizes."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(99)
+    nr = 70_000
+    if path == "radix":
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_BUILD", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_PROBE", "0")
+        rk = rng.permutation(200_000)[:nr].astype(np.int64) * 1_000_003
+        outside = (rng.integers(0, 100_000, 300_000).astype(np.int64) + 500_000) * 1_000_003
+    else:
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_MIN_ROWS", "1")
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_ORDERED_MIN_PROBE", "0")
+        rk = rng.permutation(100_000)[:nr].astype(np.int64) + 1_000
+        outside = np.concatenate([rng.integers(-50_000, 1_000, 150_000), rng.integers(101_000, 200_000, 150_000)]).astype(np.int64)
+    hj = HashJoin(cudf_amd.Table([G.to_device(rk)]), NullEquality.UNEQUAL)
+    cases = [(outside, None), (outside[:5000], np.zeros(5000, dtype=bool)), (rk[:1].copy(), None), (outside[:1].copy(), None)]
+    for lk, lv in cases:
+        t = cudf_amd.Table([G.to_device((lk, lv) if lv is not None else lk)])
+        for kind in ("inner", "left"):
+            gl, gr = getattr(hj, kind + "_join")(t)
+            el, er = oracle.join([(lk, lv) if lv is not None else lk], [rk], nulls_equal=False, kind=kind)
+            assert gl.size() == len(el), (kind, len(lk))
+            assert kat.sorted_pairs(gl.to_numpy()[0], gr.to_numpy()[0]) == kat.sorted_pairs(el, er)
