@@ -18,6 +18,7 @@
 #include <cudf/utilities/error.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace cudf::detail::join {
 namespace {
@@ -277,7 +278,8 @@ void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, 
                "partitioned dense join: arguments");
   hipLaunchKernelGGL(k_store_dense_part_args, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_build", stream};
-  for (int p0 = 0; p0 < a.P_used; p0 += 16) hipLaunchKernelGGL(k_dense_part_store, dim3(dense_part_grid()), dim3(256), 0, stream, d_args, p0, 2);
+  static int const G = std::getenv("CUDF_AMD_JOIN_STORE_G") ? std::max(1, std::atoi(std::getenv("CUDF_AMD_JOIN_STORE_G"))) : 2;
+  for (int p0 = 0; p0 < a.P_used; p0 += 8 * G) hipLaunchKernelGGL(k_dense_part_store, dim3(dense_part_grid()), dim3(256), 0, stream, d_args, p0, G);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
