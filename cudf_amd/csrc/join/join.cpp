@@ -448,7 +448,7 @@ class hash_join_impl {
     if ((h_ovf & 4) != 0) join::launch_radix_join(a, static_cast<join::radix_join_args*>(d_args2.data()), true, s);
     if (null_rows != 0)  // (pair_counts[nparts] = the number of pairs of the partitions: the cursor the NULL rows append at)
       join::launch_radix_null_rows(col.null_mask(), col.offset(), rows, row_base, a.out_probe, a.out_build, pairs_all, a.pair_counts + _rx_nparts, s);
-    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    // (no synchronisation: the scratch goes back to the pool in stream order, the caller reads the result on this stream)
     return join_index_pair{std::move(out_l), std::move(out_r)};
   }
 
@@ -608,7 +608,7 @@ class hash_join_impl {
     e.out_capacity = total;
     rmm::device_buffer d_args2{sizeof(join::radix_join_args), s, tmp};
     join::launch_radix_emit_staged(e, static_cast<join::radix_join_args*>(d_args2.data()), s);
-    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    // (no synchronisation: the scratch goes back to the pool in stream order, the caller reads the result on this stream)
     return join_index_pair{std::move(out_l), std::move(out_r)};
   }
 
@@ -658,7 +658,7 @@ class hash_join_impl {
     e.out_capacity = total;
     rmm::device_buffer d_args2{sizeof(join::radix_join_args), s, tmp};
     join::launch_radix_emit_staged(e, static_cast<join::radix_join_args*>(d_args2.data()), s);
-    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    // (no synchronisation: the scratch goes back to the pool in stream order, the caller reads the result on this stream)
     return join_index_pair{std::move(out_l), std::move(out_r)};
   }
 
@@ -841,7 +841,7 @@ class hash_join_impl {
     a.probe_row_base = row_base;
     rmm::device_buffer d_args{sizeof(join::dense_stage_args), s, cudf::get_current_device_resource_ref()};
     join::launch_dense_left_direct(a, static_cast<join::dense_stage_args*>(d_args.data()), out_l->data(), out_r->data(), s);
-    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    // (no synchronisation: the scratch goes back to the pool in stream order, the caller reads the result on this stream)
     return join_index_pair{std::move(out_l), std::move(out_r)};
   }
 

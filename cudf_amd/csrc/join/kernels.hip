@@ -961,7 +961,7 @@ void launch_key_minmax(join_args const& a, join_args* d_args, int is_signed, uin
   hipLaunchKernelGGL(k_store_args<range_init>, dim3(1), dim3(1), 0, stream, init, reinterpret_cast<range_init*>(out));
   hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_build", stream};
-  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((a.build.nrows + 4095) / 4096, 1, 1024));
+  unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((a.build.nrows + 4095) / 4096, 1, 4096));
   if (is_signed) hipLaunchKernelGGL(k_key_minmax<true>, dim3(grid), dim3(256), 0, stream, d_args, out);
   else hipLaunchKernelGGL(k_key_minmax<false>, dim3(grid), dim3(256), 0, stream, d_args, out);
   CUDF_HIP_TRY(hipGetLastError());
