@@ -327,6 +327,43 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # ---- N == 1, after the timed region: the LAST timed step's result against a per-group torch reference of the same rows
+    # (bincount / scatter_add_; nothing from oracle/). Keys and counts exactly; sums in units of the reference's own rule
+    # |x - y| <= 4 eps |x + y| (cpp/tests/utilities/column_utilities.cu:436-440) and against the worst-case bound of ANY summation
+    # order of m values below 1, m^2 eps (both sides add with unordered atomics, as the reference does).
+    result_check = None
+    if world == 1 and not force_dist:
+        try:
+            rkeys, rres = last[1]
+            k_out = rkeys.columns()[0].to_torch()
+            s_out = rres[0].columns()[0].to_torch()
+            c_out = rres[0].columns()[1].to_torch().to(torch.int64)
+            ref_c = torch.bincount(keys, minlength=groups)
+            ref_s = torch.zeros(groups, device=dev, dtype=torch.float64).scatter_add_(0, keys, vals)
+            present = int((ref_c > 0).sum().item())
+            in_range = bool(((k_out >= 0) & (k_out < groups)).all().item())
+            distinct = int(torch.unique(k_out).numel())
+            gc = ref_c[k_out] if in_range else None
+            gs = ref_s[k_out] if in_range else None
+            eps = 2.220446049250313e-16
+            err = (s_out - gs).abs() if in_range else None
+            units = float((err / (4 * eps * (s_out + gs).abs()).clamp_min(1e-300)).max().item()) if in_range else None
+            m = float(ref_c.max().item())
+            result_check = {
+                "groups_out": int(k_out.numel()), "groups_expected": present, "distinct_keys_out": distinct,
+                "sum_of_counts": int(c_out.sum().item()), "rows": n,
+                "counts_exact": bool(in_range and (c_out == gc).all().item()),
+                "max_abs_sum_error": float(err.max().item()) if in_range else None,
+                "max_sum_error_in_units_of_4eps_x_plus_y": units,
+                "worst_case_reorder_bound_abs": m * m * eps,
+                "ok": bool(in_range and k_out.numel() == present and distinct == present and int(c_out.sum().item()) == n
+                           and (c_out == gc).all().item() and float(err.max().item()) <= m * m * eps),
+                "reference": "torch.bincount / scatter_add_ over the same rows (float64 atomics, unordered)",
+            }
+            del ref_c, ref_s, gc, gs, err
+        except Exception as e:  # noqa: BLE001
+            result_check = {"error": repr(e)}
+
     # ---- N == 1, after the primary timed region: the other side of the cliffs next to the headline, in the driver's own record.
     # hash_table_variant: the same rows with every key multiplied by an odd constant (a bijection: same groups, same counts, but
     # the keys no longer span a small range, so the open-addressing hash tables serve the call instead of the direct-address ones);
@@ -435,6 +472,8 @@ def main():
                        "path": (last[0].last_path.name if (world == 1 and not force_dist) else "PARTITION+ALLTOALL+GROUPBY:" + dist_mode)},
             "roofline": roof,
         }
+        if result_check is not None:
+            line["result_check"] = result_check
         if pre is not None:
             name = "raw_row_shuffle_variant" if other_mode != "preaggregate" else "preaggregated_variant"
             what = ("C5 literal form: hash-range partition of the raw ROWS by owner rank -> RCCL Send/Recv (16 GB x (N-1)/N per GPU over the "

@@ -17,6 +17,8 @@
 #include <cudf/join/join.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -143,7 +145,13 @@ struct loopback_hub {
       cv.notify_all();
       return;
     }
-    cv.wait(lk, [&] { return generation != gen || failed; });
+    // (a deadline as well: a rank that died without telling anybody must not park its peers - and the device buffers they hold - for ever)
+    bool const released = cv.wait_for(lk, std::chrono::seconds(barrier_timeout_s()), [&] { return generation != gen || failed; });
+    if (!released) {
+      failed = true;
+      cv.notify_all();
+    }
+    CUDF_EXPECTS(released, "loopback transport: a rank did not reach the collective within CUDF_AMD_LOOPBACK_TIMEOUT_S");
     CUDF_EXPECTS(!failed || generation != gen, "loopback transport: another rank failed");
   }
   void fail()
@@ -151,6 +159,15 @@ struct loopback_hub {
     std::lock_guard<std::mutex> lk{mu};
     failed = true;
     cv.notify_all();
+  }
+  static long barrier_timeout_s()
+  {
+    static long const v = [] {
+      char const* e = std::getenv("CUDF_AMD_LOOPBACK_TIMEOUT_S");
+      long const x  = e != nullptr ? std::atol(e) : 0;
+      return x > 0 ? x : 120L;
+    }();
+    return v;
   }
 };
 class loopback_transport final : public transport {
@@ -229,6 +246,11 @@ class loopback_transport final : public transport {
       throw;
     }
   }
+
+ public:
+  void abort() noexcept override { _hub->fail(); }
+
+ private:
   std::shared_ptr<loopback_hub> _hub;
   int _rank;
   bool _open{false};
@@ -623,10 +645,25 @@ std::pair<std::unique_ptr<table>, std::vector<size_type>> range_partition(table_
 }
 
 // ------------------------------------------------------------------ shuffle
+namespace {
+std::unique_ptr<table> shuffle_body(table_view const& input, std::vector<size_type> const& key_columns, communicator& comm, stream_ref stream,
+                                    rmm::device_async_resource_ref mr);
+}
 std::unique_ptr<table> shuffle(table_view const& input, std::vector<size_type> const& key_columns, communicator& comm, stream_ref stream,
                                rmm::device_async_resource_ref mr)
 {
   CUDF_FUNC_RANGE();
+  try {
+    return shuffle_body(input, key_columns, comm, stream, mr);
+  } catch (...) {
+    comm.link().abort();  // (validation, an allocation, a too-long receive: the peers are told instead of waiting in the next collective)
+    throw;
+  }
+}
+namespace {
+std::unique_ptr<table> shuffle_body(table_view const& input, std::vector<size_type> const& key_columns, communicator& comm, stream_ref stream,
+                                    rmm::device_async_resource_ref mr)
+{
   hipStream_t const s = stream.value();
   int const N = comm.size(), me = comm.rank();
   transport& link = comm.link();
@@ -693,6 +730,7 @@ std::unique_ptr<table> shuffle(table_view const& input, std::vector<size_type> c
   }
   return assemble(input, f, std::move(recv), total, stream, mr);
 }
+}  // namespace
 
 // ------------------------------------------------------------------ shuffle_groupby (BASELINE config 5)
 std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> shuffle_groupby(

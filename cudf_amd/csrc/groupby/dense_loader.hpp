@@ -210,7 +210,7 @@ __device__ __forceinline__ void issue_dense_local(dense_local const& L, int64_t 
 {
   int64_t rowc[RPT];
 #pragma unroll
-  for (int k = 0; k < RPT; ++k) rowc[k] = min(tile + static_cast<int64_t>(k) * B + threadIdx.x, end - 1);
+  for (int k = 0; k < RPT; ++k) rowc[k] = max(min(tile + static_cast<int64_t>(k) * B + threadIdx.x, end - 1), int64_t{0});  // (never row -1; aggregate() returns before any launch when the input has no rows)
   load_col_local<RPT>(L.kc[0], rowc, t.raw[0], t.kmw[0]);
   if (L.nk > 1) load_col_local<RPT>(L.kc[1], rowc, t.raw[1], t.kmw[1]);
   load_col_local<RPT>(L.vc, rowc, t.vraw, t.vmw);
@@ -304,7 +304,7 @@ __device__ __forceinline__ void issue_dense_static(dense_local const& L, int64_t
 {
   int64_t rowc[RPT];
 #pragma unroll
-  for (int k = 0; k < RPT; ++k) rowc[k] = min(tile + static_cast<int64_t>(k) * B + threadIdx.x, end - 1);
+  for (int k = 0; k < RPT; ++k) rowc[k] = max(min(tile + static_cast<int64_t>(k) * B + threadIdx.x, end - 1), int64_t{0});  // (never row -1; aggregate() returns before any launch when the input has no rows)
 #pragma unroll
   for (int k = 0; k < RPT; ++k) t.k0[k] = load_key_static<SHAPE::W0>(L.kc[0], rowc[k]);
   if constexpr (SHAPE::W1 != 0) {

@@ -40,6 +40,10 @@ class transport {
   virtual void send(void const* buf, std::size_t bytes, int peer, hipStream_t stream)                   = 0;
   virtual void recv(void* buf, std::size_t bytes, int peer, hipStream_t stream)                         = 0;
   virtual void group_end()                                                                              = 0;
+  // A rank that leaves a collective operation by an exception OUTSIDE one of the calls above (input validation, an allocation
+  // between two exchanges) tells its peers, so that they fail instead of waiting for it (loopback: releases their barriers;
+  // RCCL: nothing to do here - the control plane that launched the ranks tears the job down).
+  virtual void abort() noexcept {}
   [[nodiscard]] virtual void* native_handle() const noexcept { return nullptr; }  // ncclComm_t of the RCCL transport
 };
 
