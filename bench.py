@@ -481,7 +481,8 @@ def main():
                     "local groupby -> hash-partition + RCCL all-to-all of the partial (key, sum, count) rows -> merge; "
                     "same result, xGMI carries MBs")
             line[name] = {"value": total_rows * args.steps / pre, "unit": "rows/s", "ms_per_step": pre / args.steps * 1e3,
-                          "what": what}
+                          "what": what, "implementation": ("cudf::distributed::combine_groupby (in the library)" if state.get("pre_mode") == "combine_native"
+                                                           else "cudf_amd.distributed (torch.distributed exchange)" if other_mode == "preaggregate" else "cudf::distributed::shuffle_groupby")}
         if pre_error is not None:
             line["raw_row_shuffle_variant" if other_mode != "preaggregate" else "preaggregated_variant"] = {"error": pre_error}
         if world == 1 and not force_dist:
@@ -517,8 +518,15 @@ def main():
     if world > 1 or force_dist:
         from cudf_amd import distributed as D2
 
+        # the combiner form comes from the library too (cudf::distributed::combine_groupby: local partials -> exchange of the partial
+        # groups -> merge); BENCH_COMBINER=torch keeps the round-3 form (the same steps through torch.distributed)
+        pre_mode = other_mode
+        if other_mode == "preaggregate" and os.environ.get("BENCH_COMBINER", "native") == "native":
+            pre_mode = "combine_native"
+        state["pre_mode"] = pre_mode
+
         def pre_step():
-            return D2.distributed_groupby_sum_count(keys, vals, stream=stream, mode=other_mode)
+            return D2.distributed_groupby_sum_count(keys, vals, stream=stream, mode=pre_mode)
 
         watchdog = threading.Timer(watchdog_s, emit_and_maybe_exit, args=(True,))
         watchdog.daemon = True

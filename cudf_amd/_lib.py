@@ -72,6 +72,8 @@ SYMBOLS = {
     "cudf_amd_shuffle": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.POINTER(C.c_int32), C.c_int32, _P, C.POINTER(_P)]),
     "cudf_amd_shuffle_groupby": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.c_int32, C.POINTER(AggregationRequest),
                                            C.c_int32, _P, C.POINTER(_P), C.POINTER(_P)]),
+    "cudf_amd_combine_groupby": (C.c_int, [_P, C.POINTER(ColumnView), C.c_int32, C.c_int32, C.POINTER(AggregationRequest),
+                                           C.c_int32, _P, C.POINTER(_P), C.POINTER(_P)]),
     "cudf_amd_murmurhash3_x86_32": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.c_uint32, _P, C.POINTER(_P)]),
     "cudf_amd_gather": (C.c_int, [C.POINTER(ColumnView), C.c_int32, C.POINTER(ColumnView), C.c_int32, _P, C.POINTER(_P)]),
 }

@@ -589,6 +589,34 @@ cudf_amd_status cudf_amd_shuffle_groupby(cudf_amd_comm_t comm, const cudf_amd_co
   });
 }
 
+cudf_amd_status cudf_amd_combine_groupby(cudf_amd_comm_t comm, const cudf_amd_column_view* keys, int32_t num_keys,
+                                         int32_t include_null_keys, const cudf_amd_aggregation_request* requests,
+                                         int32_t num_requests, void* stream, cudf_amd_table_t* out_keys,
+                                         cudf_amd_table_t* out_results)
+{
+  return guarded([&] {
+    *out_keys    = nullptr;
+    *out_results = nullptr;
+    CUDF_EXPECTS(comm != nullptr && comm->comm != nullptr, "null communicator", std::invalid_argument);
+    auto const kt = to_table(keys, num_keys);
+    std::vector<cudf::groupby::aggregation_request> reqs(num_requests);
+    for (int32_t r = 0; r < num_requests; ++r) {
+      reqs[r].values = to_view(requests[r].values);
+      for (int32_t k = 0; k < requests[r].num_kinds; ++k)
+        reqs[r].aggregations.push_back(make_agg(requests[r].kinds[k], requests[r].params ? requests[r].params + k : nullptr));
+    }
+    auto [ukeys, results] = cudf::distributed::combine_groupby(
+      kt, reqs, *comm->comm, include_null_keys ? cudf::null_policy::INCLUDE : cudf::null_policy::EXCLUDE, cudf::stream_ref{as_stream(stream)});
+    auto kh  = std::make_unique<cudf_amd_table_s>();
+    kh->cols = ukeys->release();
+    auto rh  = std::make_unique<cudf_amd_table_s>();
+    for (auto& r : results)
+      for (auto& c : r.results) rh->cols.push_back(std::move(c));
+    *out_keys    = kh.release();
+    *out_results = rh.release();
+  });
+}
+
 cudf_amd_status cudf_amd_murmurhash3_x86_32(const cudf_amd_column_view* input, int32_t num_columns, uint32_t seed,
                                             void* stream, cudf_amd_table_t* out_column)
 {

@@ -771,6 +771,209 @@ std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> shuf
   return gb.aggregate(local, stream, mr);
 }
 
+// ------------------------------------------------------------------ combine_groupby (the decomposable form of config 5)
+namespace {
+__global__ void __launch_bounds__(256) k_count_to_i32(int64_t const* in, int64_t n, int32_t* out)
+{
+  int64_t const i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) out[i] = static_cast<int32_t>(in[i]);
+}
+// mean = sum / count as FLOAT64 (the reference's MEAN target type for numeric columns); valid where count > 0
+template <typename S>
+__global__ void __launch_bounds__(256) k_mean_of(S const* sum, int64_t const* count, int64_t n, double* out, bitmask_type* mask, int32_t* nulls)
+{
+  int64_t const i  = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  bool const valid = i < n && count[i] > 0;
+  if (i < n) out[i] = valid ? static_cast<double>(sum[i]) / static_cast<double>(count[i]) : 0.0;
+  uint64_t const b = __ballot(valid);
+  int const lane   = threadIdx.x & 63;
+  if (i < n && (lane & 31) == 0) mask[i >> 5] = static_cast<bitmask_type>(lane == 0 ? b : b >> 32);
+  if (lane == 0) {
+    int64_t const in_range = min<int64_t>(64, n - (i - lane));
+    int const missing      = static_cast<int>(in_range > 0 ? in_range : 0) - __popcll(b);
+    if (missing > 0) atomicAdd(nulls, missing);
+  }
+}
+std::unique_ptr<groupby_aggregation> clone_groupby_agg(aggregation const& a)
+{
+  auto cl = a.clone();
+  auto* g = dynamic_cast<groupby_aggregation*>(cl.get());
+  CUDF_EXPECTS(g != nullptr, "not a groupby aggregation");
+  (void)cl.release();
+  return std::unique_ptr<groupby_aggregation>(g);
+}
+// the partial aggregations of one request and how the merge treats each
+struct partial_agg {
+  aggregation::Kind local;   // what the local groupby computes
+  aggregation::Kind merge;   // what the merge groupby applies to that partial column
+};
+}  // namespace
+
+std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> combine_groupby(
+  table_view const& keys, std::span<groupby::aggregation_request const> requests, communicator& comm, null_policy null_handling,
+  stream_ref stream, rmm::device_async_resource_ref mr)
+{
+  CUDF_FUNC_RANGE();
+  using K = aggregation::Kind;
+  hipStream_t const s = stream.value();
+  auto tmp            = cudf::get_current_device_resource_ref();
+  // ---- lowering (host only: every rank reaches the same verdict before anything is exchanged)
+  struct use {
+    int partial[2];  // indices into the request's partial list (MEAN: sum, count)
+  };
+  std::vector<std::vector<partial_agg>> partials(requests.size());
+  std::vector<std::vector<use>> uses(requests.size());
+  for (std::size_t r = 0; r < requests.size(); ++r) {
+    CUDF_EXPECTS(requests[r].values.size() == keys.num_rows(), "Size mismatch between request values and groupby keys.");
+    auto find_or_add = [&](K local, K merge) {
+      for (std::size_t i = 0; i < partials[r].size(); ++i)
+        if (partials[r][i].local == local) return static_cast<int>(i);
+      partials[r].push_back({local, merge});
+      return static_cast<int>(partials[r].size()) - 1;
+    };
+    for (auto const& a : requests[r].aggregations) {
+      use u{{-1, -1}};
+      switch (a->kind) {
+        case K::SUM: u.partial[0] = find_or_add(K::SUM, K::SUM); break;
+        case K::PRODUCT: u.partial[0] = find_or_add(K::PRODUCT, K::PRODUCT); break;
+        case K::SUM_OF_SQUARES: u.partial[0] = find_or_add(K::SUM_OF_SQUARES, K::SUM); break;
+        case K::MIN: u.partial[0] = find_or_add(K::MIN, K::MIN); break;
+        case K::MAX: u.partial[0] = find_or_add(K::MAX, K::MAX); break;
+        case K::COUNT_VALID: u.partial[0] = find_or_add(K::COUNT_VALID, K::SUM); break;
+        case K::COUNT_ALL: u.partial[0] = find_or_add(K::COUNT_ALL, K::SUM); break;
+        case K::MEAN: {
+          auto const id = requests[r].values.type().id();
+          bool const numeric = id == type_id::INT8 || id == type_id::INT16 || id == type_id::INT32 || id == type_id::INT64 || id == type_id::UINT8 ||
+                               id == type_id::UINT16 || id == type_id::UINT32 || id == type_id::UINT64 || id == type_id::FLOAT32 || id == type_id::FLOAT64;
+          CUDF_EXPECTS(numeric,
+                       "combine_groupby: MEAN of a numeric column only (decimal / duration means divide in integers)", std::invalid_argument);
+          u.partial[0] = find_or_add(K::SUM, K::SUM);
+          u.partial[1] = find_or_add(K::COUNT_VALID, K::SUM);
+          break;
+        }
+        default:
+          CUDF_FAIL("combine_groupby: this aggregation does not decompose into per-rank partials merged by SUM / MIN / MAX / PRODUCT", std::invalid_argument);
+      }
+      uses[r].push_back(u);
+    }
+  }
+  auto make_kind = [](K k) -> std::unique_ptr<groupby_aggregation> {
+    switch (k) {
+      case K::SUM: return make_sum_aggregation<groupby_aggregation>();
+      case K::PRODUCT: return make_product_aggregation<groupby_aggregation>();
+      case K::SUM_OF_SQUARES: return make_sum_of_squares_aggregation<groupby_aggregation>();
+      case K::MIN: return make_min_aggregation<groupby_aggregation>();
+      case K::MAX: return make_max_aggregation<groupby_aggregation>();
+      case K::COUNT_VALID: return make_count_aggregation<groupby_aggregation>(null_policy::EXCLUDE);
+      case K::COUNT_ALL: return make_count_aggregation<groupby_aggregation>(null_policy::INCLUDE);
+      default: CUDF_FAIL("combine_groupby: partial kind");
+    }
+  };
+  // ---- 1. local groupby with the partial aggregations
+  std::vector<groupby::aggregation_request> local(requests.size());
+  for (std::size_t r = 0; r < requests.size(); ++r) {
+    local[r].values = requests[r].values;
+    for (auto const& pa : partials[r]) local[r].aggregations.push_back(make_kind(pa.local));
+  }
+  std::unique_ptr<table> lkeys;
+  std::vector<groupby::aggregation_result> lres;
+  try {
+    groupby::groupby gb{keys, null_handling};
+    std::tie(lkeys, lres) = gb.aggregate(local, stream, tmp);
+  } catch (...) {
+    comm.link().abort();  // (the peers are about to enter the exchange)
+    throw;
+  }
+  // ---- 2. the partial groups travel to the rank that owns their key
+  std::vector<column_view> cols;
+  std::vector<size_type> key_idx(static_cast<std::size_t>(keys.num_columns()));
+  std::iota(key_idx.begin(), key_idx.end(), 0);
+  for (int c = 0; c < lkeys->num_columns(); ++c) cols.push_back(lkeys->view().column(c));
+  std::vector<std::vector<int>> col_of(requests.size());
+  for (std::size_t r = 0; r < requests.size(); ++r)
+    for (std::size_t i = 0; i < partials[r].size(); ++i) {
+      col_of[r].push_back(static_cast<int>(cols.size()));
+      cols.push_back(lres[r].results[i]->view());
+    }
+  auto mine     = shuffle(table_view{cols}, key_idx, comm, stream, tmp);
+  auto const mv = mine->view();
+  // ---- 3. merge on the owner: one request per partial column
+  std::vector<column_view> kcols;
+  for (int c = 0; c < keys.num_columns(); ++c) kcols.push_back(mv.column(c));
+  std::vector<groupby::aggregation_request> merge;
+  std::vector<std::vector<int>> merged_at(requests.size());
+  for (std::size_t r = 0; r < requests.size(); ++r)
+    for (std::size_t i = 0; i < partials[r].size(); ++i) {
+      merged_at[r].push_back(static_cast<int>(merge.size()));
+      groupby::aggregation_request q;
+      q.values = mv.column(col_of[r][i]);
+      q.aggregations.push_back(make_kind(partials[r][i].merge));
+      merge.push_back(std::move(q));
+    }
+  groupby::groupby mg{table_view{kcols}, null_handling};
+  auto [out_keys, mres] = mg.aggregate(merge, stream, mr);
+  size_type const G     = out_keys->num_rows();
+  // ---- 4. finalisation in request order (a partial used twice is copied the second time)
+  std::vector<std::vector<bool>> taken(requests.size());
+  for (std::size_t r = 0; r < requests.size(); ++r) taken[r].assign(partials[r].size(), false);
+  auto take = [&](std::size_t r, int i) -> std::unique_ptr<column> {
+    auto& slot = mres[static_cast<std::size_t>(merged_at[r][static_cast<std::size_t>(i)])].results[0];
+    if (!taken[r][static_cast<std::size_t>(i)]) {
+      taken[r][static_cast<std::size_t>(i)] = true;
+      return std::make_unique<column>(slot->view(), stream, mr);  // (kept: a later MEAN / repeat may read it; copies are G rows)
+    }
+    return std::make_unique<column>(slot->view(), stream, mr);
+  };
+  auto view_of = [&](std::size_t r, int i) { return mres[static_cast<std::size_t>(merged_at[r][static_cast<std::size_t>(i)])].results[0]->view(); };
+  std::vector<groupby::aggregation_result> out(requests.size());
+  int const blocks = static_cast<int>((static_cast<int64_t>(G) + 255) / 256);
+  for (std::size_t r = 0; r < requests.size(); ++r) {
+    for (std::size_t j = 0; j < requests[r].aggregations.size(); ++j) {
+      K const k    = requests[r].aggregations[j]->kind;
+      use const& u = uses[r][j];
+      if (k == K::COUNT_VALID || k == K::COUNT_ALL) {  // merged by SUM: INT64 -> the reference's INT32 counts
+        auto c = make_fixed_width_column(data_type{type_id::INT32}, G, mask_state::UNALLOCATED, stream, mr);
+        if (G > 0) {
+          hipLaunchKernelGGL(k_count_to_i32, dim3(blocks), dim3(256), 0, s, view_of(r, u.partial[0]).data<int64_t>(), static_cast<int64_t>(G),
+                             c->mutable_view().data<int32_t>());
+          CUDF_HIP_TRY(hipGetLastError());
+        }
+        out[r].results.push_back(std::move(c));
+      } else if (k == K::MEAN) {
+        auto c = make_fixed_width_column(data_type{type_id::FLOAT64}, G, mask_state::UNINITIALIZED, stream, mr);
+        int32_t h_nulls = 0;
+        if (G > 0) {
+          rmm::device_buffer d_nulls{sizeof(int32_t), s, tmp};
+          CUDF_HIP_TRY(hipMemsetAsync(d_nulls.data(), 0, sizeof(int32_t), s));
+          auto const sv = view_of(r, u.partial[0]);
+          auto const cv = view_of(r, u.partial[1]);
+          auto mvw      = c->mutable_view();
+          auto launch   = [&](auto const* sum) {
+            hipLaunchKernelGGL(k_mean_of, dim3(blocks), dim3(256), 0, s, sum, cv.data<int64_t>(), static_cast<int64_t>(G), mvw.data<double>(),
+                               mvw.null_mask(), static_cast<int32_t*>(d_nulls.data()));
+          };
+          switch (sv.type().id()) {
+            case type_id::INT64: launch(sv.data<int64_t>()); break;
+            case type_id::UINT64: launch(sv.data<uint64_t>()); break;
+            case type_id::FLOAT64: launch(sv.data<double>()); break;
+            case type_id::FLOAT32: launch(sv.data<float>()); break;
+            default: CUDF_FAIL("combine_groupby: sum type of a MEAN");
+          }
+          CUDF_HIP_TRY(hipGetLastError());
+          CUDF_HIP_TRY(hipMemcpyAsync(&h_nulls, d_nulls.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+          CUDF_HIP_TRY(hipStreamSynchronize(s));
+        }
+        if (h_nulls == 0) c->set_null_mask(rmm::device_buffer{}, 0);
+        else c->set_null_count(h_nulls);
+        out[r].results.push_back(std::move(c));
+      } else {
+        out[r].results.push_back(take(r, u.partial[0]));
+      }
+    }
+  }
+  return {std::move(out_keys), std::move(out)};
+}
+
 // ------------------------------------------------------------------ shuffle_join
 namespace {
 __global__ void __launch_bounds__(256) k_global_ids(int64_t first, int64_t n, int64_t* out)

@@ -47,9 +47,9 @@ namespace cudf::groupby::detail {
 // once per process: the test suite flips them between calls of one process (forced paths, shrunken tables).
 struct planner_env {
   int64_t lds_kb, agg_block, big_min_rows, estimate_min_rows, forced_p, s_items, preagg_min_pct, dense_log2p, scatter_block, rpt;
-  int64_t dense_nsplit, wc_g, chunk_rows, slices, plan_load_pct;  // -1: not set (the default depends on the plan)
-  bool dense, dense_composite, dense_one_table, dense_ring, dense_multi, chunked, hot, preagg, optimistic, optimistic2, exact, wc, cyclic,
-    stamps, debug, no_simple, vec16, trace, hash_ring, collapse_runs;
+  int64_t dense_nsplit, wc_g, slices, plan_load_pct;  // -1: not set (the default depends on the plan)
+  bool dense, dense_composite, dense_one_table, dense_ring, dense_multi, hot, preagg, optimistic, optimistic2, exact, wc, cyclic,
+    stamps, debug, no_simple, vec16, trace, collapse_runs;
   int64_t static_shapes;  // composite dense keys: 0 = run-time loader, 1 / 2 = compiled column shapes with one / two tiles of loads in flight
   static planner_env load();
 };
@@ -159,7 +159,7 @@ class aggregate_call {
   // ---- state that attempts change
   scratch sc;
   int32_t* d_overflow{nullptr};
-  bool allow_dense{false}, allow_optimistic{true}, allow_hash_ring{true}, pre_failed{false}, counted_all{false};
+  bool allow_dense{false}, allow_optimistic{true}, pre_failed{false}, counted_all{false};
   double safety{1.3};
   // ---- result of the successful attempt
   uint64_t* partial{nullptr};  // partial records: item i at [i*cap, i*cap + count[i])
@@ -190,7 +190,6 @@ class aggregate_call {
   // paths_hash.cpp
   outcome run_single_pass(attempt_plan& ap);
   outcome try_preaggregate(attempt_plan& ap);
-  outcome try_hash_ring(attempt_plan& ap);
   outcome run_partitioned(attempt_plan& ap);
   struct partition_plan {
     int64_t P1, P2;

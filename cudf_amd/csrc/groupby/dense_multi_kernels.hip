@@ -308,7 +308,8 @@ void launch_multi_t(ring_multi_args const& a, ring_multi_args const* d_args, hip
 {
   static std::once_flag attr_once;
   std::call_once(attr_once, [] { allow_full_lds(reinterpret_cast<void const*>(&k_dense_ring_scatter_multi<NV, DENSE, CAP, RPT, D>)); });
-  std::size_t const lds = DENSE ? dense_ring_multi_lds_bytes(NV, a.P, CAP) : hash_ring_lds_bytes(NV, a.P, CAP);
+  static_assert(DENSE, "the sparse-key (hash) form of this scatter was measured slower and removed (profiles/r3_sparse_ring.txt)");
+  std::size_t const lds = dense_ring_multi_lds_bytes(NV, a.P, CAP);
   cudf::detail::prof::scope prof_{"partition_scatter", stream};
   hipLaunchKernelGGL((k_dense_ring_scatter_multi<NV, DENSE, CAP, RPT, D>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
@@ -321,7 +322,6 @@ std::size_t dense_ring_multi_lds_bytes(int nval, int P, int cap)
   return static_cast<std::size_t>(P) * (static_cast<std::size_t>(nval) * cap * 8 + 128 * 2 + 8);
 }
 int dense_ring_multi_cap(int nval) { return nval <= 2 ? 48 : 32; }
-std::size_t hash_ring_lds_bytes(int nstreams, int P, int cap) { return static_cast<std::size_t>(P) * (static_cast<std::size_t>(nstreams) * cap * 8 + 8); }
 
 void store_args(ring_multi_args const& a, ring_multi_args* d_args, hipStream_t stream)
 {
@@ -345,16 +345,6 @@ void launch_dense_ring_scatter_multi(ring_multi_args const& a, ring_multi_args c
                "ring scatter: region geometry");
   if (a.nval == 2) return launch_multi_t<2, true, 48, 2, 2>(a, d_args, stream);
   return launch_multi_t<3, true, 32, 1, 4>(a, d_args, stream);
-}
-
-void launch_hash_ring_scatter(ring_multi_args const& a, ring_multi_args const* d_args, hipStream_t stream)
-{
-  CUDF_EXPECTS(a.plan.simple && a.plan.KU == 1 && a.plan.NPAY == 1 && a.nval == 2,
-               "hash ring scatter: one plain 8-byte key column and one plain 8-byte value column (two streams)");
-  CUDF_EXPECTS(a.P == 256 && a.cap == HASH_RING_CAP && hash_ring_lds_bytes(2, a.P, a.cap) + 64 <= 160 * 1024, "hash ring scatter: 256 partitions");
-  CUDF_EXPECTS(a.region_cap % 64 == 0 && a.shift >= 32 && a.shift < 64 && a.slices >= 1 && a.stream_stride % 16 == 0 && a.nrows >= 1,
-               "hash ring scatter: region geometry");
-  return launch_multi_t<2, false, HASH_RING_CAP, 2, 3>(a, d_args, stream);
 }
 
 void launch_dense_merge_dump_multi(dense_multi_merge_args const& a, dense_multi_merge_args const* d_args, int dsplit, hipStream_t stream)

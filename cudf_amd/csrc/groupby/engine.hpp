@@ -395,31 +395,6 @@ void launch_dense_ring_scatter_multi(ring_multi_args const& a, ring_multi_args c
 std::size_t dense_ring_multi_lds_bytes(int nval, int P, int cap);
 int dense_ring_multi_cap(int nval);  // ring capacity per partition for nval value streams at 128 partitions
 
-// ---- sparse single 8-byte keys (the hash-table side of the same scatter): launch_hash_ring_scatter writes TWO streams - the
-// key column (stream 0 at out_val) and the value column (stream 1 at out_val + stream_stride) - partitioned on the top bits of the
-// engine's key hash (shift >= 56 for 256 partitions), no tags; `map` and `out_tag` are unused. k_aggregate_k64 (hash_ring_kernels.hip)
-// aggregates a partition in an LDS table whose slot state IS the key word (no state words, one LDS round trip per probe).
-constexpr int HASH_RING_P = 256, HASH_RING_CAP = 32;
-void launch_hash_ring_scatter(ring_multi_args const& a, ring_multi_args const* d_args, hipStream_t stream);
-std::size_t hash_ring_lds_bytes(int nstreams, int P, int cap);
-struct k64_agg_args {
-  plan_dev plan;
-  uint64_t const* rec_key;   // region (d, w) at [(d * slices + w) * region_cap, + region_count[d * slices + w]) of both streams
-  uint64_t const* rec_val;
-  int32_t const* region_count;
-  int64_t region_cap;
-  int32_t slices;
-  int32_t cap;               // table slots (a multiple of 2); slot `cap` is reserved for the key that equals the empty marker
-  int32_t fill_limit;        // groups per table before the item reports overflow (bit 1 of *overflow)
-  uint64_t* out_records;     // item d at [d * (cap + 1) * (1 + NACC) ...], out_count[d] records
-  int32_t* out_count;
-  int32_t* overflow;
-  int32_t nitems;
-};
-int k64_table_slots(plan_dev const& plan, std::size_t lds_bytes);  // slots of a k_aggregate_k64 table in lds_bytes of LDS
-void store_args(k64_agg_args const& a, k64_agg_args* d_args, hipStream_t stream);
-void launch_aggregate_k64(k64_agg_args const& a, k64_agg_args const* d_args, hipStream_t stream);
-
 struct dense_multi_merge_args {
   plan_dev plan;         // the WHOLE plan (its NACC accumulators in order)
   dense_map map;

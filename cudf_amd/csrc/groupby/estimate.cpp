@@ -309,7 +309,6 @@ outcome aggregate_call::run_attempt(int attempt)
     o = try_preaggregate(ap);                              // A: sorted / clustered rows
     if (o == outcome::skip) o = try_dense_ring();          // D: dense keys, ring scatter
     if (o == outcome::skip) o = try_dense_wc();            // D: dense keys, write-combining scatter
-    if (o == outcome::skip) o = try_hash_ring(ap);         // P: sparse single 8-byte keys, ring scatter + key-word tables
     if (o == outcome::skip) o = run_partitioned(ap);       // P: radix partition on hash bits
   }
   if (o == outcome::retry_counted && env.debug)

@@ -83,7 +83,7 @@ outcome aggregate_call::try_dense_one_table()
 outcome aggregate_call::try_dense_ring()
 {
   // (heavy hitters in the sample: only the single-level ring scatter of one plain key takes them out of the partition)
-  bool const ring_env = env.dense_ring && !env.chunked;
+  bool const ring_env = env.dense_ring;
   if (!(allow_dense && env.forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !env.exact)) return outcome::skip;
   if (dense_candidate && p.NPAY > 1) return ring_env ? try_dense_ring_multi() : outcome::skip;  // one value stream per column
       dense_map dm{};
@@ -410,11 +410,11 @@ outcome aggregate_call::try_dense_ring_multi()
   return outcome::retry_free;
 }
 
-// ---- write-combining scatter with 16-byte records (CUDF_AMD_GB_DENSE_RING=0, or a geometry the rings do not take), optionally
-// chunk by chunk through the Infinity Cache (CUDF_AMD_GB_CHUNKED=1: profiles/r2_mall_pipeline.txt)
+// ---- write-combining scatter with 16-byte records (CUDF_AMD_GB_DENSE_RING=0, or a geometry the rings do not take). (Rounds 2-3 could
+// also run it chunk by chunk through the Infinity Cache; measured slower - profiles/r2_mall_pipeline.txt - and removed in round 4.)
 outcome aggregate_call::try_dense_wc()
 {
-  bool const ring_env = env.dense_ring && !env.chunked;
+  bool const ring_env = env.dense_ring;
   if (!(allow_dense && env.forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !env.exact)) return outcome::skip;
   if (dense_candidate && p.NPAY > 1) return outcome::skip;  // (16-byte records carry one value)
       dense_map dm{};
@@ -435,9 +435,7 @@ outcome aggregate_call::try_dense_wc()
         int const slots           = 1 << std::max(bits - log2P, 0);
         std::size_t const image   = dense_table_bytes(p, slots);
         dense_ok = dense_ok && dm.range <= (uint64_t{1} << bits) && bits <= 30 && bits - log2P >= 6 && log2P <= 20 && image <= 150 * 1024 &&
-                   static_cast<double>(dm.range) <= 8.0 * std::max(est_groups, 4096.0) &&
-                   // (the carried table images of a chunked single-level call travel to LDS and back once per chunk)
-                   (two_level || static_cast<double>(image) * (1 << log2P) <= 32.0 * 1024 * 1024 || !env.chunked);
+                   static_cast<double>(dm.range) <= 8.0 * std::max(est_groups, 4096.0);
         int64_t const PD = int64_t{1} << log2P1, P2D = int64_t{1} << log2P2;
         // scatter workgroups: one of 1024 threads per CU (128-byte granules up to 512 partitions), or - CUDF_AMD_GB_SCATTER_BLOCK=512 -
         // two of 512 threads per CU with 64-byte granules (measured slower: profiles/r2_mall_pipeline.txt)
@@ -452,14 +450,8 @@ outcome aggregate_call::try_dense_wc()
           dm.bits     = bits;
           dm.log2P    = log2P;
           int const DPU = (dm.nkeys > 0 ? p.KU : 1) + p.NACC;  // units of a dumped partial record
-          // chunks (single level, opt-in): a multiple of one tile per workgroup; the ring of a chunk's regions stays in the
-          // Infinity Cache. Measured: no gain (profiles/r2_mall_pipeline.txt); CUDF_AMD_GB_CHUNKED=1 keeps it testable.
           int64_t const S        = 256 * (1024 / SB), tile_rows = 5 * SB;
-          int64_t const quantum  = S * tile_rows;
-          int64_t const want     = std::max<int64_t>(quantum, (env.chunk_rows >= 0 ? env.chunk_rows : 8 * quantum));
-          int64_t const nchunks  = (!two_level && env.chunked) ? std::max<int64_t>(1, (n + want - 1) / want) : 1;
-          int64_t const C        = ((n + nchunks - 1) / nchunks + quantum - 1) / quantum * quantum;
-          double const cell_mean = static_cast<double>(std::min(C, n)) / static_cast<double>(S * PD);
+          double const cell_mean = static_cast<double>(n) / static_cast<double>(S * PD);
           double const keys_per_p = std::max(1.0, 0.5 * est_groups / static_cast<double>(PD));
           double const rel_sigma  = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, cell_mean));
           int64_t const capR      = (static_cast<int64_t>(cell_mean * (1.0 + 6.0 * std::min(rel_sigma, 1.0)) + 16.0) + 7) / 8 * 8;
@@ -535,7 +527,7 @@ outcome aggregate_call::try_dense_wc()
           da.occ_acc      = dense_occ_acc(p);
           da.KU           = dm.nkeys > 0 ? p.KU : 1;
           nitems          = static_cast<int32_t>(int64_t{1} << log2P);
-          da.tables       = sc.alloc<uint64_t>(nchunks > 1 ? static_cast<size_t>(nitems) * image / 8 : 2);
+          da.tables       = sc.alloc<uint64_t>(2);
           partial         = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * slots * DPU);
           d_count         = sc.alloc<int32_t>(nitems);
           da.out_records  = partial;
@@ -545,17 +537,14 @@ outcome aggregate_call::try_dense_wc()
           da.block        = 1024;
           dense_agg_args* d_da = sc.alloc<dense_agg_args>(1);
           store_args(da, d_da, s);
-          for (int64_t c = 0; c < nchunks; ++c) {
-            chunk_range const cr{c * C, std::min(n, (c + 1) * C)};
-            launch_partition_scatter(pa, d_pa, s, nchunks > 1 ? cr : chunk_range{0, 0});
-            if (two_level) launch_partition_scatter(pb, d_pb, s);
-            launch_aggregate_dense(da, d_da, c == 0, c == nchunks - 1, s);
-          }
+          launch_partition_scatter(pa, d_pa, s);
+          if (two_level) launch_partition_scatter(pb, d_pb, s);
+          launch_aggregate_dense(da, d_da, true, true, s);
           final_cap          = slots;
           int32_t const h_ov = overflow_and_counts();
           if (env.debug)
-            fprintf(stderr, "[cudf_amd] dense keys: nkeys=%d lo=%lld range=%llu bits=%d P=%ld x %ld slots=%d image=%zu B chunks=%ld capR=%ld cap2=%ld overflow=%d\n",
-                    dm.nkeys, (long long)dm.lo, (unsigned long long)dm.range, bits, (long)PD, (long)P2D, slots, image, (long)nchunks, (long)capR, (long)cap2, h_ov);
+            fprintf(stderr, "[cudf_amd] dense keys: nkeys=%d lo=%lld range=%llu bits=%d P=%ld x %ld slots=%d image=%zu B capR=%ld cap2=%ld overflow=%d\n",
+                    dm.nkeys, (long long)dm.lo, (unsigned long long)dm.range, bits, (long)PD, (long)P2D, slots, image, (long)capR, (long)cap2, h_ov);
           if (h_ov == 0) return outcome::done;
           // a region overflowed (skewed or clustered keys) or a key lay outside the sampled range: redo by hash
           allow_dense = false;

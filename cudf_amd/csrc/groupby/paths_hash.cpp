@@ -267,81 +267,6 @@ int32_t aggregate_call::wc_granule_for(int64_t P) const
   return (RU == 3 && partition_wc_fits(RU, static_cast<int>(P), 4)) ? 4 : 0;  // 24-byte records: 96-byte granules
 }
 
-// ---------------- path P for one plain 8-byte key column and one plain 8-byte value column whose keys are NOT dense (sparse
-// integers: the north star's "open-addressing hash build / probe"): the ring scatter of the dense path (two barriers per tile,
-// whole 128-byte granules only) writes a key stream and a value stream partitioned on the top 8 bits of the key hash, and
-// k_aggregate_k64 aggregates each of the 256 partitions in an LDS table whose slot state is the key word itself (20 bytes per
-// group for SUM + COUNT: 1M groups sit at load 0.48; one LDS round trip per probe). Up to ~1.1M groups; more groups, heavy
-// hitters, clustered rows and every other record shape take run_partitioned below.
-outcome aggregate_call::try_hash_ring(attempt_plan& ap)
-{
-  (void)ap;
-  if (!(env.hash_ring && allow_hash_ring && p.simple && p.KU == 1 && p.NPAY == 1 && p.narg == 0 && p.flags_unit < 0 && hot_keys.empty() &&
-        env.forced_p == 0 && !env.exact && allow_optimistic && n >= env.big_min_rows))
-    return outcome::skip;
-  for (int q = 0; q < p.NACC; ++q)
-    if (p.acc[q].op == ANY_U64) return outcome::skip;
-  int const cap = k64_table_slots(p, static_cast<std::size_t>(env.lds_kb) * 1024);
-  int64_t const P = HASH_RING_P, S = 256;
-  // planned load up to 0.7 at the estimate WITH its safety factor (1M groups: 0.48 expected, 0.62 planned); the table reports
-  // overflow at 0.85
-  if (cap < 256 || std::min(est_groups * safety, static_cast<double>(n)) / static_cast<double>(P) > 0.7 * cap) return outcome::skip;
-  int64_t const ring_tile = 2 * 1024, wg_rows = std::min<int64_t>(n, ((n + ring_tile - 1) / ring_tile + S - 1) / S * ring_tile);
-  double const mean       = static_cast<double>(wg_rows) / static_cast<double>(P);
-  double const keys_per_p = std::max(1.0, 0.5 * est_groups / static_cast<double>(P));
-  double const rel_sigma  = std::sqrt(1.0 / keys_per_p + 1.0 / std::max(1.0, mean));
-  if (6.0 * rel_sigma > 1.0) return outcome::skip;  // (few keys per partition: the regions would need more than twice the memory)
-  int64_t const capR = (static_cast<int64_t>(mean * (1.0 + 6.0 * rel_sigma) + 64.0) + 63) / 64 * 64;
-  path = hash_path::PARTITIONED_LDS;
-  ring_multi_args ra{};
-  ra.plan          = p;
-  ra.nrows         = n;
-  ra.nval          = 2;  // two streams: the key column, the value column
-  ra.P             = static_cast<int32_t>(P);
-  ra.cap           = HASH_RING_CAP;
-  ra.shift         = 64 - 8;
-  ra.slices        = static_cast<int32_t>(S);
-  ra.region_cap    = capR;
-  ra.stream_stride = S * P * capR;
-  ra.region_count  = sc.alloc<int32_t>(static_cast<size_t>(S * P));
-  ra.overflow      = d_overflow;
-  ra.out_val       = sc.alloc<uint64_t>(static_cast<size_t>(ra.stream_stride) * 2);
-  ring_multi_args* d_ra = sc.alloc<ring_multi_args>(1);
-  store_args(ra, d_ra, s);
-  launch_hash_ring_scatter(ra, d_ra, s);
-  k64_agg_args ka{};
-  ka.plan         = p;
-  ka.rec_key      = ra.out_val;
-  ka.rec_val      = ra.out_val + ra.stream_stride;
-  ka.region_count = ra.region_count;
-  ka.region_cap   = capR;
-  ka.slices       = static_cast<int32_t>(S);
-  ka.cap          = cap;
-  ka.fill_limit   = static_cast<int32_t>(cap * 0.85);
-  nitems          = static_cast<int32_t>(P);
-  partial         = sc.alloc<uint64_t>(static_cast<size_t>(nitems) * (cap + 1) * PU);
-  d_count         = sc.alloc<int32_t>(nitems);
-  ka.out_records  = partial;
-  ka.out_count    = d_count;
-  ka.overflow     = d_overflow;
-  ka.nitems       = nitems;
-  k64_agg_args* d_ka = sc.alloc<k64_agg_args>(1);
-  store_args(ka, d_ka, s);
-  launch_aggregate_k64(ka, d_ka, s);
-  final_cap          = cap + 1;
-  int32_t const h_ov = overflow_and_counts();
-  if (env.debug)
-    fprintf(stderr, "[cudf_amd] sparse keys (ring scatter + key-word tables): P=%ld table slots=%d (fill limit %d) capR=%ld estimate %.0f groups overflow=%d\n",
-            (long)P, cap, ka.fill_limit, (long)capR, est_groups, h_ov);
-  if (h_ov == 0) return outcome::done;
-  // a region overflowed (skewed or clustered keys) or a table did (the estimate was low): the partition pipeline below, which
-  // knows how to escalate
-  allow_hash_ring = false;
-  final_cap       = 0;
-  fresh_scratch();
-  return outcome::retry_free;
-}
-
 // ---------------- path P: radix-partition raw records on hash bits, then one LDS table per partition
 outcome aggregate_call::run_partitioned(attempt_plan& ap)
 {

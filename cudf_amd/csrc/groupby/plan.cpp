@@ -41,7 +41,6 @@ planner_env planner_env::load()
   e.rpt               = env_i64("CUDF_AMD_GB_RPT", 8);
   e.dense_nsplit      = env_i64("CUDF_AMD_GB_DENSE_NSPLIT", -1);
   e.wc_g              = env_i64("CUDF_AMD_GB_WC_G", -1);
-  e.chunk_rows        = env_i64("CUDF_AMD_GB_CHUNK_ROWS", -1);
   e.slices            = env_i64("CUDF_AMD_GB_SLICES", -1);
   e.plan_load_pct     = env_i64("CUDF_AMD_GB_PLAN_LOAD_PCT", -1);
   e.dense             = env_i64("CUDF_AMD_GB_DENSE", 1) != 0;
@@ -49,7 +48,6 @@ planner_env planner_env::load()
   e.dense_one_table   = env_i64("CUDF_AMD_GB_DENSE_ONE_TABLE", 1) != 0;
   e.dense_ring        = env_i64("CUDF_AMD_GB_DENSE_RING", 1) != 0;
   e.dense_multi       = env_i64("CUDF_AMD_GB_DENSE_MULTI", 1) != 0;
-  e.chunked           = env_i64("CUDF_AMD_GB_CHUNKED", 0) != 0;
   e.hot               = env_i64("CUDF_AMD_GB_HOT", 1) != 0;
   e.preagg            = env_i64("CUDF_AMD_GB_PREAGG", 1) != 0;
   e.optimistic        = env_i64("CUDF_AMD_GB_OPTIMISTIC", 1) != 0;
@@ -64,7 +62,6 @@ planner_env planner_env::load()
   e.vec16             = env_i64("CUDF_AMD_GB_VEC16", 0) != 0;
   e.trace             = env_i64("CUDF_AMD_GB_TRACE", 0) != 0;
   // (off by default: measured SLOWER than the write-combining scatter + tagged tables - profiles/r3_sparse_ring.txt)
-  e.hash_ring         = env_i64("CUDF_AMD_GB_HASH_RING", 0) != 0;
   e.static_shapes     = env_i64("CUDF_AMD_GB_STATIC_SHAPES", 2);
   return e;
 }

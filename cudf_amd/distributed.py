@@ -112,7 +112,7 @@ def shuffle(comm: Communicator, table: Table, key_columns, stream=None) -> Table
     return Table._from_handle(out, stream)
 
 
-def shuffle_groupby(comm: Communicator, keys: Table, requests, null_handling=0, stream=None):
+def shuffle_groupby(comm: Communicator, keys: Table, requests, null_handling=0, stream=None, _entry="cudf_amd_shuffle_groupby"):
     """BASELINE config 5 inside the library: hash-range partition of the rows -> RCCL exchange -> local hash groupby.
     requests: cudf_amd.groupby.GroupByRequest list. -> (keys Table, [results Table per request]) of the groups this rank owns."""
     reqs, keep = [], []
@@ -124,14 +124,21 @@ def shuffle_groupby(comm: Communicator, keys: Table, requests, null_handling=0, 
         reqs.append(_lib.AggregationRequest(r._values._view(), kinds, len(r._aggregations), params))
     rarr = (_lib.AggregationRequest * max(1, len(reqs)))(*reqs)
     out_keys, out_res = C.c_void_p(), C.c_void_p()
-    _lib.check(_lib.load().cudf_amd_shuffle_groupby(comm._handle, keys._views(), keys.num_columns(), int(null_handling), rarr,
-                                                    len(reqs), _stream_ptr(stream), C.byref(out_keys), C.byref(out_res)))
+    _lib.check(getattr(_lib.load(), _entry)(comm._handle, keys._views(), keys.num_columns(), int(null_handling), rarr,
+                                             len(reqs), _stream_ptr(stream), C.byref(out_keys), C.byref(out_res)))
     flat = Table._from_handle(out_res, stream).columns()
     results, p = [], 0
     for r in requests:
         results.append(Table(flat[p:p + len(r._aggregations)]))
         p += len(r._aggregations)
     return Table._from_handle(out_keys, stream), results
+
+
+def combine_groupby(comm: Communicator, keys: Table, requests, null_handling=0, stream=None):
+    """The decomposable form of config 5 inside the library (cudf::distributed::combine_groupby): local groupby with partial
+    aggregations -> exchange of the partial GROUPS -> merge on the owner -> finalisation (MEAN after the merge). Same results as
+    shuffle_groupby; SUM / PRODUCT / SUM_OF_SQUARES / MIN / MAX / COUNT / MEAN only."""
+    return shuffle_groupby(comm, keys, requests, null_handling, stream, _entry="cudf_amd_combine_groupby")
 
 
 def shuffle_join(comm: Communicator, left_keys: Table, right_keys: Table, nulls_equal=True, stream=None):
@@ -282,6 +289,14 @@ def distributed_groupby_sum_count(keys, vals, stream=None, mode="shuffle", backe
         comm = _native_comm(group)
         req = gb.GroupByRequest(cudf_amd.Column.from_torch(vals), [agg.sum(), agg.count(NullPolicy.EXCLUDE)])
         uk, res = shuffle_groupby(comm, cudf_amd.Table([cudf_amd.Column.from_torch(keys)]), [req], stream=stream)
+        return uk.columns()[0].to_torch(), res[0].columns()[0].to_torch(), res[0].columns()[1].to_torch()
+    if mode == "combine_native":  # the decomposable form, entirely inside the library
+        import cudf_amd
+        from cudf_amd import aggregation as agg, groupby as gb
+        from cudf_amd.types import NullPolicy
+        comm = _native_comm(group)
+        req = gb.GroupByRequest(cudf_amd.Column.from_torch(vals), [agg.sum(), agg.count(NullPolicy.EXCLUDE)])
+        uk, res = combine_groupby(comm, cudf_amd.Table([cudf_amd.Column.from_torch(keys)]), [req], stream=stream)
         return uk.columns()[0].to_torch(), res[0].columns()[0].to_torch(), res[0].columns()[1].to_torch()
     backend = backend or GpuBackend(stream)
     world = dist.get_world_size(group)

@@ -94,6 +94,20 @@ std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> shuf
   null_policy null_handling = null_policy::EXCLUDE, stream_ref stream = get_default_stream(),
   rmm::device_async_resource_ref mr = get_current_device_resource_ref());
 
+// The DECOMPOSABLE ("combiner") form of config 5 - the only one whose exchange does not grow with the rows (SURVEY.md section 8e,
+// reference cpp/src/groupby/streaming_groupby/merge.cu:91-144): the local hash groupby of this rank's rows with the PARTIAL
+// aggregations of every request (SUM -> sum, COUNT_* -> count, MIN / MAX -> themselves, MEAN -> sum + count of valid values,
+// PRODUCT -> product, SUM_OF_SQUARES -> sum of squares), the shuffle of the partial GROUPS by key (hash-range ownership: at most
+// groups x world rows travel), the merge groupby on the owner (SUM of sums and of counts, MIN of minima, MAX of maxima, PRODUCT of
+// products), and the finalisation after the merge (counts back to INT32, MEAN = merged sum / merged count, NULL where no valid value
+// arrived). Same result types and nullability as groupby::aggregate on the union of the ranks' rows; the ranks' results are disjoint.
+// Aggregations that do not decompose this way (M2 / VARIANCE / STD, ARGMIN / ARGMAX, SUM_WITH_OVERFLOW, MEAN of a decimal or duration
+// column) raise std::invalid_argument on every rank before anything is exchanged. Collective.
+std::pair<std::unique_ptr<table>, std::vector<groupby::aggregation_result>> combine_groupby(
+  table_view const& keys, std::span<groupby::aggregation_request const> requests, communicator& comm,
+  null_policy null_handling = null_policy::EXCLUDE, stream_ref stream = get_default_stream(),
+  rmm::device_async_resource_ref mr = get_current_device_resource_ref());
+
 // Inner join of two tables sharded by rows over the ranks (data flow of the reference's
 // cpp/libcudf_streaming/src/partition_utils.cpp:72-185 with a hash join as the local step): both sides are shuffled by key with the
 // same hash-range ownership, the GLOBAL row id (this rank's first row id + local index; first row id = rows of the lower ranks)

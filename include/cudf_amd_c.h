@@ -177,7 +177,12 @@ cudf_amd_status cudf_amd_hash_partition(const cudf_amd_column_view* input, int32
  *   out_offsets receives num_destinations + 1 row offsets.
  * cudf_amd_shuffle: collective; every rank receives the rows it owns (from rank 0, then rank 1, ...).
  * cudf_amd_shuffle_groupby: BASELINE config 5 = cudf_amd_shuffle of (keys, values) + the local hash groupby; the ranks'
- *   results are disjoint, their union is the global result. */
+ *   results are disjoint, their union is the global result.
+ * cudf_amd_combine_groupby: the decomposable form (cudf::distributed::combine_groupby; reference
+ *   cpp/src/groupby/streaming_groupby/merge.cu:91-144): local groupby with partial aggregations -> cudf_amd_shuffle of the partial
+ *   GROUPS -> merge groupby on the owner -> finalisation (counts to INT32, MEAN = merged sum / merged count). Same arguments and
+ *   results as cudf_amd_shuffle_groupby; SUM / PRODUCT / SUM_OF_SQUARES / MIN / MAX / COUNT_* / MEAN of numeric columns, anything
+ *   else: CUDF_AMD_INVALID_ARGUMENT before the exchange. */
 typedef struct cudf_amd_comm_s* cudf_amd_comm_t;
 cudf_amd_status cudf_amd_comm_unique_id(uint8_t* out_id_128_bytes);
 cudf_amd_status cudf_amd_comm_create(const uint8_t* id_128_bytes, int32_t world_size, int32_t rank, cudf_amd_comm_t* out);
@@ -205,6 +210,10 @@ cudf_amd_status cudf_amd_range_partition(const cudf_amd_column_view* input, int3
 cudf_amd_status cudf_amd_shuffle(cudf_amd_comm_t comm, const cudf_amd_column_view* input, int32_t num_columns,
                                  const int32_t* key_columns, int32_t num_key_columns, void* stream, cudf_amd_table_t* out_table);
 cudf_amd_status cudf_amd_shuffle_groupby(cudf_amd_comm_t comm, const cudf_amd_column_view* keys, int32_t num_keys,
+                                         int32_t include_null_keys, const cudf_amd_aggregation_request* requests,
+                                         int32_t num_requests, void* stream, cudf_amd_table_t* out_keys,
+                                         cudf_amd_table_t* out_results);
+cudf_amd_status cudf_amd_combine_groupby(cudf_amd_comm_t comm, const cudf_amd_column_view* keys, int32_t num_keys,
                                          int32_t include_null_keys, const cudf_amd_aggregation_request* requests,
                                          int32_t num_requests, void* stream, cudf_amd_table_t* out_keys,
                                          cudf_amd_table_t* out_results);

@@ -273,13 +273,10 @@ def test_narrow_key_nullable_value_partitioned(G, oracle, kt, vt):
                           expect_path="PARTITIONED_LDS")
 
 
-@pytest.mark.parametrize("hash_ring", ["1", "0"])
-def test_optimistic_partition_and_its_fallback(G, oracle, monkeypatch, hash_ring):
-    """n >= 4M rows takes the optimistic single-pass partition (no histogram pass): through the ring scatter + key-word tables
-    (one plain 8-byte key, one plain 8-byte value) or - CUDF_AMD_GB_HASH_RING=0 - through the write-combining scatter + tagged
+def test_optimistic_partition_and_its_fallback(G, oracle):
+    """n >= 4M rows takes the optimistic single-pass partition (no histogram pass) through the write-combining scatter + tagged
     tables. Uniform keys must stay on it; a heavy-hitter key overflows its fixed-capacity region and must be repaired by the
     exact pipeline."""
-    monkeypatch.setenv("CUDF_AMD_GB_HASH_RING", hash_ring)
     rng = np.random.default_rng(17)
     n = 5_000_000
     k = rng.integers(0, 200_000, n, dtype=np.int64)
@@ -293,13 +290,11 @@ def test_optimistic_partition_and_its_fallback(G, oracle, monkeypatch, hash_ring
 @pytest.mark.parametrize("groups,vt,kinds", [(900_000, "float64", ["sum", "count_valid"]), (1_100_000, "int64", ["sum", "count_all", "mean"]),
                                              (40_000, "float64", ["min", "max", "mean"]), (300_000, "float64", ["sum_of_squares", "product", "count_valid", "max", "sum"]),
                                              (5_000, "uint64", ["sum"])])
-def test_sparse_keys_ring_scatter_and_key_word_tables(G, oracle, monkeypatch, groups, vt, kinds):
-    """Sparse int64 keys (no small range: never the direct-address tables), one plain 8-byte value column, n >= 4M: the ring scatter
-    writes a key stream and a value stream into 256 hash partitions and k_aggregate_k64 aggregates each in an LDS table whose slot
-    state is the key word (hash_ring_kernels.hip). The keys include the table's empty marker and 0 / -1 / INT64_MIN / INT64_MAX.
-    Same call with CUDF_AMD_GB_HASH_RING=0 (tagged tables behind the write-combining scatter) must agree."""
+def test_sparse_keys_with_edge_values(G, oracle, groups, vt, kinds):
+    """Sparse int64 keys (no small range: never the direct-address tables), one plain 8-byte value column, n >= 4M: the
+    write-combining scatter + tagged LDS tables. The keys include 0 / -1 / INT64_MIN / INT64_MAX and a golden-ratio pattern.
+    (Round 3 also had a ring scatter + key-word tables for this shape; measured slower - profiles/r3_sparse_ring.txt - and removed.)"""
     from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
-    monkeypatch.setenv("CUDF_AMD_GB_HASH_RING", "1")  # (off by default: measured slower than the tagged tables, profiles/r3_sparse_ring.txt)
     rng = np.random.default_rng(groups)
     n = 4_400_000
     pool = rng.integers(-2**62, 2**62, groups, dtype=np.int64)
@@ -311,14 +306,11 @@ def test_sparse_keys_ring_scatter_and_key_word_tables(G, oracle, monkeypatch, gr
         v = np.where(rng.random(n) < 0.999, 1.0, 1.0 + 2.0 ** -20)
     _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), kinds)], expect_path="PARTITIONED_LDS")
     assert G.last_path.name == "PARTITIONED_LDS"
-    monkeypatch.setenv("CUDF_AMD_GB_HASH_RING", "0")
-    _check_against_oracle(G, oracle, [k], [(HostColumn(v, None, vt), kinds)], expect_path="PARTITIONED_LDS")
 
 
-def test_sparse_keys_ring_scatter_overflows_fall_back(G, oracle, monkeypatch):
-    """The sparse-key ring path rules itself out and the partition pipeline repairs the call: a skewed sample that hides most of
-    the groups (the key-word tables overflow), and keys clustered in the row order (a region overflows)."""
-    monkeypatch.setenv("CUDF_AMD_GB_HASH_RING", "1")
+def test_sparse_keys_hidden_groups_and_clustered_rows(G, oracle):
+    """The optimistic partition repairs itself: a skewed sample that hides most of the groups (the tables overflow), and keys
+    clustered in the row order (a region overflows)."""
     rng = np.random.default_rng(909)
     n = 4_500_000
     # 95 % of the rows on 2000 keys, the rest on 1.5M more: the sample estimates far too few groups
@@ -347,18 +339,16 @@ def test_dense_keys_direct_address(G, oracle, monkeypatch, lo, groups, vt, ring)
     assert G.last_path.name == "PARTITIONED_LDS"
 
 
-def test_dense_keys_chunked_and_fallbacks(G, oracle, monkeypatch):
-    """The chunked form of the dense path (table images carried from chunk to chunk); a key outside the sampled range and a
+def test_dense_keys_write_combining_and_fallbacks(G, oracle, monkeypatch):
+    """The write-combining form of the dense path (CUDF_AMD_GB_DENSE_RING=0: 16-byte records); a key outside the sampled range and a
     sparse key column must fall back to the hash tables."""
     rng = np.random.default_rng(72)
     n = 6_000_000
     k = rng.integers(0, 500_000, n, dtype=np.int64)
     v = rng.random(n)
-    monkeypatch.setenv("CUDF_AMD_GB_CHUNKED", "1")
-    monkeypatch.setenv("CUDF_AMD_GB_CHUNK_ROWS", str(256 * 5120))  # 5 chunks
+    monkeypatch.setenv("CUDF_AMD_GB_DENSE_RING", "0")
     _check_against_oracle(G, oracle, [k], [(v, ["sum", "count_all", "max"])], expect_path="DENSE_DIRECT")
-    monkeypatch.delenv("CUDF_AMD_GB_CHUNKED")
-    monkeypatch.delenv("CUDF_AMD_GB_CHUNK_ROWS")
+    monkeypatch.delenv("CUDF_AMD_GB_DENSE_RING")
     k2 = k.copy()
     k2[n // 2 + 12345] = 10**12  # one outlier the sample will not see: the attempt is void, the call is redone by hash
     _check_against_oracle(G, oracle, [k2], [(v, ["sum", "count_all"])], expect_path="PARTITIONED_LDS")

@@ -131,6 +131,75 @@ def test_shuffle_groupby_with_peers(gpu, oracle, world):
         kat.compare_columns(a, e, name, atol=kat.sum_atol(64, 1.0) if name == "sum" else 0.0)
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("vt", ["float64", "int32"])
+def test_combine_groupby_with_peers(gpu, oracle, world, vt):
+    """cudf::distributed::combine_groupby (the decomposable form of config 5; reference streaming_groupby/merge.cu:91-144) with peers:
+    local partials -> exchange of the partial groups -> merge -> MEAN finalised after the merge. Union of the ranks' groups == the
+    single-process groupby of all rows for SUM / COUNT_VALID / COUNT_ALL / MIN / MAX / MEAN over a nullable value column (a key
+    whose values are NULL on every rank comes back NULL for SUM / MIN / MAX / MEAN and 0 for COUNT_VALID), no group on two ranks."""
+    import cudf_amd
+    import gpu_backend as G
+    import kat
+    from oracle.oracle import HostColumn
+    from cudf_amd import aggregation as agg, distributed as D, groupby as gb
+    from cudf_amd.types import NullPolicy
+    rng = np.random.default_rng(400 + world)
+    shards = _shards(rng, world, [150_000, 40_000, 99_999], 15_000, empty_rank=world - 1 if world > 2 else None)
+    names = ["sum", "count_valid", "count_all", "min", "max", "mean"]
+    hv = []
+    for k, v, vv, _ in shards:
+        vv = vv & (k % 97 != 0)  # every value of some keys is NULL on every rank
+        data = v if vt == "float64" else (v * 2000 - 1000).astype(np.int32)
+        hv.append(HostColumn(data, vv, vt))
+    keys = [cudf_amd.Table([G.to_device(k)]) for k, _, _, _ in shards]
+    vals = [G.to_device(h) for h in hv]
+
+    def rank_fn(r, comm, stream):
+        req = gb.GroupByRequest(vals[r], [agg.sum(), agg.count(NullPolicy.EXCLUDE), agg.count(NullPolicy.INCLUDE), agg.min(), agg.max(), agg.mean()])
+        uk, out = D.combine_groupby(comm, keys[r], [req], stream=stream)
+        return [G.from_device(c) for c in uk.columns()], [G.from_device(c) for c in out[0].columns()]
+
+    res = _run_ranks(world, rank_fn)
+    allk = np.concatenate([s[0] for s in shards])
+    allv = HostColumn(np.concatenate([h.data for h in hv]), np.concatenate([h.valid for h in hv]), vt)
+    exp = kat.sort_groups(*oracle.groupby([allk], [(allv, names)]))
+    seen = np.concatenate([kc[0][0] for kc, _ in res])
+    assert len(np.unique(seen)) == len(seen), "a group came back from two ranks"
+    for r, (kc, _) in enumerate(res):
+        if len(kc[0][0]):
+            h = oracle.row_hash([kc[0][0]], 0).astype(np.uint64)
+            assert (((h * np.uint64(world)) >> np.uint64(32)).astype(np.int64) == r).all()
+
+    def cat(cols):
+        data = np.concatenate([c[0] for c in cols])
+        valid = None if all(c[1] is None for c in cols) else np.concatenate([np.ones(len(c[0]), bool) if c[1] is None else c[1] for c in cols])
+        return (data, valid, cols[0][2])
+
+    got = kat.sort_groups([cat([kc[0] for kc, _ in res])], [[cat([rc[j] for _, rc in res]) for j in range(len(names))]])
+    kat.compare_columns(got[0][0], exp[0][0], "keys")
+    for a, e, name in zip(got[1][0], exp[1][0], names):
+        kat.compare_columns(a, e, name, atol=kat.sum_atol(64, 1.0) if (name in ("sum", "mean") and vt == "float64") else (1e-9 if name == "mean" else 0.0))
+
+
+def test_combine_groupby_rejects_what_does_not_decompose(gpu):
+    """VARIANCE / ARGMAX do not merge by SUM / MIN / MAX: std::invalid_argument on every rank BEFORE the exchange (nobody is left waiting)."""
+    import cudf_amd
+    import gpu_backend as G
+    from cudf_amd import aggregation as agg, distributed as D, groupby as gb
+    k = [cudf_amd.Table([G.to_device(np.arange(100, dtype=np.int64) % 7)]) for _ in range(2)]
+    v = [G.to_device(np.arange(100, dtype=np.float64)) for _ in range(2)]
+
+    def rank_fn(r, comm, stream):
+        for bad in (agg.variance(), agg.argmax()):
+            with pytest.raises(ValueError):
+                D.combine_groupby(comm, k[r], [gb.GroupByRequest(v[r], [agg.sum(), bad])], stream=stream)
+        uk, out = D.combine_groupby(comm, k[r], [gb.GroupByRequest(v[r], [agg.sum()])], stream=stream)  # the communicator still works
+        return uk.num_rows()
+
+    assert sum(_run_ranks(2, rank_fn)) == 7
+
+
 @pytest.mark.parametrize("world,limit", [(2, None), (4, 16 * 1024)])
 def test_shuffle_join_with_peers(gpu, oracle, world, limit):
     """cudf::distributed::shuffle_join: every matching pair of the WHOLE tables comes back exactly once, as global row ids."""
