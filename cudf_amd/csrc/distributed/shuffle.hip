@@ -373,7 +373,9 @@ __device__ __forceinline__ void move_column(device_column const& col, void* out,
   }
   __syncthreads();
 }
-__global__ void __launch_bounds__(RP_BLOCK) k_rp_scatter(rp_args const* __restrict__ ap)
+// Columns [c0, c1) of the flat table (every launch ranks the rows again: a pipelined shuffle moves one column per launch so that the
+// exchange of column c runs beside the scatter of column c + 1).
+__global__ void __launch_bounds__(RP_BLOCK) k_rp_scatter(rp_args const* __restrict__ ap, int c0, int c1)
 {
   __shared__ uint64_t stage64[RP_TILE];        // one column's values of a tile, in destination order
   __shared__ uint8_t sdest[RP_TILE];           // destination of every staged position
@@ -431,7 +433,7 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_scatter(rp_args const* __restri
       }
     }
     __syncthreads();
-    for (int c = 0; c < a.all.ncols; ++c) {
+    for (int c = c0; c < c1; ++c) {
       device_column const col = a.all.col[c];
       switch (col.width) {
         case 1: move_column<uint8_t>(col, a.out[c], tile, end, lpos, reinterpret_cast<uint8_t*>(stage64), sdest, doff, gcur, tile_rows); break;
@@ -523,9 +525,39 @@ std::unique_ptr<table> assemble(table_view const& like, flat_table const& f, std
   return std::make_unique<table>(std::move(cols));
 }
 
+// The side stream of a pipelined shuffle: column c of the local split is scattered there while the exchange of the columns before it
+// runs on the caller's stream; column_ready[c] is recorded behind column c's scatter (reference: the chunked pipeline of
+// cpp/libcudf_streaming/src/partition.cpp:20-88 overlaps partition and exchange chunk by chunk; here the unit is a column).
+struct scatter_pipeline {
+  hipStream_t side{nullptr};
+  hipEvent_t scan_done{nullptr};
+  std::vector<hipEvent_t> column_ready;
+  scatter_pipeline() = default;
+  scatter_pipeline(scatter_pipeline const&)            = delete;
+  scatter_pipeline& operator=(scatter_pipeline const&) = delete;
+  void open(std::size_t ncols)
+  {
+    CUDF_HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    CUDF_HIP_TRY(hipEventCreateWithFlags(&scan_done, hipEventDisableTiming));
+    column_ready.assign(ncols, nullptr);
+    for (auto& e : column_ready) CUDF_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  ~scatter_pipeline()
+  {
+    if (side != nullptr) (void)hipStreamSynchronize(side);  // (nothing of this call may outlive its buffers, whatever path left the scope)
+    for (auto e : column_ready)
+      if (e != nullptr) (void)hipEventDestroy(e);
+    if (scan_done != nullptr) (void)hipEventDestroy(scan_done);
+    if (side != nullptr) (void)hipStreamDestroy(side);
+  }
+};
+
 // Partitions the flat columns by the hash range of `hashed`'s rows; returns one buffer per flat column and N + 1 offsets.
+// pipe != nullptr: the offsets are final on return but the columns are not - column c's buffer is complete once pipe->column_ready[c]
+// has happened (the caller makes its stream wait for that event before it reads the buffer).
 std::pair<std::vector<rmm::device_buffer>, std::vector<int64_t>> partition_flat(flat_table const& f, table_view const& hashed, int N,
-                                                                                stream_ref stream, rmm::device_async_resource_ref mr)
+                                                                                stream_ref stream, rmm::device_async_resource_ref mr,
+                                                                                scatter_pipeline* pipe = nullptr)
 {
   CUDF_EXPECTS(N >= 1 && N <= RP_MAX_PARTS, "distributed shuffle: 1 to 64 destinations", std::invalid_argument);
   hipStream_t const s = stream.value();
@@ -533,7 +565,14 @@ std::pair<std::vector<rmm::device_buffer>, std::vector<int64_t>> partition_flat(
   std::vector<rmm::device_buffer> out;
   for (auto const& c : f.cols) out.emplace_back(static_cast<std::size_t>(std::max<int64_t>(n, 1)) * size_of_id(c.type().id()), s, mr);
   std::vector<int64_t> h_off(static_cast<std::size_t>(N) + 1, 0);
-  if (n == 0) return {std::move(out), std::move(h_off)};
+  auto all_ready_on_main = [&] {  // (no side work: every column is ready where the caller's stream stands)
+    if (pipe != nullptr)
+      for (auto e : pipe->column_ready) CUDF_HIP_TRY(hipEventRecord(e, s));
+  };
+  if (n == 0) {
+    all_ready_on_main();
+    return {std::move(out), std::move(h_off)};
+  }
   if (N == 1) {  // one destination: the rows stay as they are
     for (std::size_t c = 0; c < f.cols.size(); ++c) {
       auto const w = size_of_id(f.cols[c].type().id());
@@ -541,6 +580,7 @@ std::pair<std::vector<rmm::device_buffer>, std::vector<int64_t>> partition_flat(
                                   static_cast<std::size_t>(n) * w, hipMemcpyDeviceToDevice, s));
     }
     h_off[1] = n;
+    all_ready_on_main();
     return {std::move(out), std::move(h_off)};
   }
   auto tmp = cudf::get_current_device_resource_ref();
@@ -564,13 +604,26 @@ std::pair<std::vector<rmm::device_buffer>, std::vector<int64_t>> partition_flat(
     hipLaunchKernelGGL(k_rp_hist, dim3(a.wgs), dim3(RP_BLOCK), 0, s, da);
   }
   hipLaunchKernelGGL(k_rp_scan, dim3(1), dim3(64), 0, s, da);
-  {
+  if (pipe == nullptr) {
     cudf::detail::prof::scope p_{"range_partition_scatter", s};
-    hipLaunchKernelGGL(k_rp_scatter, dim3(a.wgs), dim3(RP_BLOCK), 0, s, da);
+    hipLaunchKernelGGL(k_rp_scatter, dim3(a.wgs), dim3(RP_BLOCK), 0, s, da, 0, a.all.ncols);
+  } else {
+    // one launch per column on the side stream, behind the scan; the caller's stream goes on to the count exchange
+    CUDF_HIP_TRY(hipEventRecord(pipe->scan_done, s));
+    CUDF_HIP_TRY(hipStreamWaitEvent(pipe->side, pipe->scan_done, 0));
+    for (int c = 0; c < a.all.ncols; ++c) {
+      hipLaunchKernelGGL(k_rp_scatter, dim3(a.wgs), dim3(RP_BLOCK), 0, pipe->side, da, c, c + 1);
+      CUDF_HIP_TRY(hipEventRecord(pipe->column_ready[static_cast<std::size_t>(c)], pipe->side));
+    }
   }
   CUDF_HIP_TRY(hipGetLastError());
   CUDF_HIP_TRY(hipMemcpyAsync(h_off.data(), a.offsets, sizeof(int64_t) * (N + 1), hipMemcpyDeviceToHost, s));
   CUDF_HIP_TRY(hipStreamSynchronize(s));
+  if (pipe != nullptr) {
+    // the scratch of this function (histogram cells, argument block) is read by the side stream's launches: its stream-ordered release
+    // on `s` waits for the last of them
+    CUDF_HIP_TRY(hipStreamWaitEvent(s, pipe->column_ready.back(), 0));
+  }
   return {std::move(out), std::move(h_off)};
 }
 
@@ -684,8 +737,16 @@ std::unique_ptr<table> shuffle_body(table_view const& input, std::vector<size_ty
   for (int p = 0; p < N; ++p) with_validity |= static_cast<uint64_t>(h_all[static_cast<std::size_t>(p) * (N + 1) + N]);
 
   // ---- local split by owner rank
-  auto f           = flatten(input, with_validity, s);
-  auto [bufs, off] = partition_flat(f, hashed, N, stream, tmp);
+  auto f = flatten(input, with_validity, s);
+  // (the columns are scattered one per launch on a side stream: the count exchange below and the payload rounds of column c run
+  // beside the scatter of the columns after c. CUDF_AMD_SHUFFLE_PIPELINE=0: one fused scatter on the caller's stream.)
+  static bool const pipelined = [] {
+    char const* e = std::getenv("CUDF_AMD_SHUFFLE_PIPELINE");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  scatter_pipeline pipe;  // (partition_flat returns with `s` waiting for the last column's event: buffers released on `s` are safe)
+  if (pipelined && f.cols.size() > 1) pipe.open(f.cols.size());
+  auto [bufs, off] = partition_flat(f, hashed, N, stream, tmp, pipe.side != nullptr ? &pipe : nullptr);
 
   // ---- counts: every rank learns what every rank sends to every rank
   for (int p = 0; p < N; ++p) h_send[p] = off[p + 1] - off[p];
@@ -710,6 +771,7 @@ std::unique_ptr<table> shuffle_body(table_view const& input, std::vector<size_ty
   cudf::detail::prof::scope p_{"shuffle_exchange", s};
   for (std::size_t c = 0; c < f.cols.size(); ++c) {
     int64_t const w = static_cast<int64_t>(size_of_id(f.cols[c].type().id()));
+    if (pipe.side != nullptr) CUDF_HIP_TRY(hipStreamWaitEvent(s, pipe.column_ready[c], 0));  // column c has been scattered
     recv.emplace_back(static_cast<std::size_t>(std::max<int64_t>(total, 1) * w), s, c < static_cast<std::size_t>(f.ninput) ? mr : tmp);
     char const* src = static_cast<char const*>(bufs[c].data());
     char* dst       = static_cast<char*>(recv.back().data());
