@@ -52,9 +52,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=int(os.environ.get("BENCH_ROWS", 1_000_000_000)))
     ap.add_argument("--groups", type=int, default=int(os.environ.get("BENCH_GROUPS", 1_000_000)))
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c3sparse", "c4"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c3sparse", "c3inrange", "c4"],
                     help="c2 (default, the headline); c3 = configs[2] inner join; c3sparse = the same with keys that do not span a small "
-                         "range (hash table instead of the direct-address table); c4 = configs[3] multi-key groupby. One GPU only.")
+                         "range (hash table instead of the direct-address table); c3inrange = dense keys whose misses lie INSIDE the build side's key range "
+                         "(no free range reject); c4 = configs[3] multi-key groupby. One GPU only.")
     ap.add_argument("--scale", type=float, default=1.0, help="c3 / c4: fraction of the BASELINE size (parity / smoke runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -139,11 +140,12 @@ def run_config(args, json_fd):
         metric = "rows/s hash-groupby MEAN+MIN+MAX, 1B rows, keys (int64, int32), 10M groups, 10% nulls"
         workload = "C4: 1xMI355X multi-key groupby (int64+int32) with mean/min/max, 1B rows, 10M groups, 10% nulls on k1 and on the value"
     else:
-        run, check, rows, algo_of, _ = BC.make_c3(args.scale, sparse=args.config == "c3sparse")
+        run, check, rows, algo_of, _ = BC.make_c3(args.scale, sparse=args.config == "c3sparse", inrange=args.config == "c3inrange")
         algo = lambda res: algo_of(res[0].size())  # noqa: E731
         metric = "rows/s hash inner_join, 500M x 50M int64 keys, 5% nulls"
         workload = ("C3: 1xMI355X hash inner_join, 500M x 50M int64 keys with 5% null mask, selectivity 0.3, null_equality::UNEQUAL"
-                    + (" [keys x 1,000,003: sparse, served by the hash table]" if args.config == "c3sparse" else ""))
+                    + (" [keys x 1,000,003: sparse, served by the hash table]" if args.config == "c3sparse" else "")
+                    + (" [build = the even keys of [0, 100M), misses = odd keys of the same range: no range reject]" if args.config == "c3inrange" else ""))
     for _ in range(max(args.warmup, 1)):
         run()
     torch.cuda.synchronize()
@@ -164,12 +166,31 @@ def run_config(args, json_fd):
     name, (launches, total_ms) = max(prof.items(), key=lambda kv: kv[1][1])
     avg_ms = total_ms / max(launches, 1)
     per_launch = nbytes * (args.steps / max(launches, 1))  # a kernel launched several times per step shares the step's bytes
+    # counter traffic of this label's kernels at this configuration and scale (bench_micro/collect_profiles.sh), quoted only if it was
+    # taken from the source tree this library is built from
+    traffic, traffic_note, traffic_all = None, None, None
+    try:
+        pmc_file = next(f for f in ("r4_pmc_traffic_configs.json", "r3_pmc_traffic_configs.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+            doc = json.load(f)
+        if doc.get("sources_sha256") != _sources_sha256():
+            traffic_note = f"profiles/{pmc_file} was collected from a different source tree: not quoted"
+        elif args.scale != 1.0:
+            traffic_note = "counters were taken at scale 1.0"
+        else:
+            lab = doc.get("labels", {}).get(args.config, {})
+            if name in lab:
+                traffic = lab[name]["hbm_bytes_per_step"] / max(launches / args.steps, 1)
+            traffic_all = {k: v["hbm_bytes_per_step"] for k, v in lab.items()}
+    except Exception as e:  # noqa: BLE001
+        traffic_note = f"no PMC file: {e!r}"
     line = {"metric": metric, "value": rows * args.steps / dt, "unit": "rows/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64" if args.config.startswith("c3") else "f64", "data": "synthetic",
             "config": {"workload": workload, "scale": args.scale, "rows": rows, "checks": checks},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                         "frac": per_launch / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_bytes_per_step_by_label": traffic_all, "avg_launch_ms": avg_ms,
                          "launches_per_step": launches / args.steps, "algorithmic_bytes_per_step": nbytes,
                          "kernels_ms_per_step": {k: v[1] / args.steps for k, v in sorted(prof.items())},
                          "whole_call_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
@@ -185,8 +206,9 @@ def run_secondary_children():
     budget_s = float(os.environ.get("BENCH_SECONDARY_TIMEOUT_S", "100"))
     # (c3_partitioned_probe: C3 with the probe rows partitioned by key range instead of the ordered direct probe that is the default
     # - less time in the join, pairs partition-major instead of in probe-row order: DESIGN.md section 4)
+    # (c3inrange: dense keys whose misses lie inside the build side's key range - the direct-address table without its free range reject)
     for name, cfg, env_extra in (("c3", "c3", {}), ("c3_partitioned_probe", "c3", {"CUDF_AMD_JOIN_DENSE_PROBE": "2"}), ("c3sparse", "c3sparse", {}),
-                                 ("c4", "c4", {})):
+                                 ("c3inrange", "c3inrange", {}), ("c4", "c4", {})):
         t0 = time.perf_counter()
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
@@ -200,6 +222,8 @@ def run_secondary_children():
             out[name] = {"ms_per_step": doc["ms_per_step"], "value": doc["value"], "unit": doc["unit"], "steps": doc["steps"],
                         "frac": doc["roofline"]["frac"], "whole_call_frac": doc["roofline"]["whole_call_frac"],
                         "dominant_kernel": doc["roofline"]["kernel"], "kernels_ms_per_step": doc["roofline"]["kernels_ms_per_step"],
+                        "traffic": doc["roofline"].get("traffic"), "traffic_bytes_per_step_by_label": doc["roofline"].get("traffic_bytes_per_step_by_label"),
+                        "traffic_note": doc["roofline"].get("traffic_note"),
                         "checks": checks, "checks_ok": all(v for k, v in checks.items()
                                          if isinstance(v, bool) and (k.endswith("_ok") or k in ("keys_equal", "no_null_rows", "pairs_distinct"))),
                         "wall_s": time.perf_counter() - t0}

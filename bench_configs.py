@@ -121,10 +121,13 @@ def c4(scale):
                       "algorithmic_GBps": algo_bytes / dt / 1e9, "path": checks["path"], "kernels_ms": prof, "checks": checks}), flush=True)
 
 
-def make_c3(scale, dev=None, sparse=False):
+def make_c3(scale, dev=None, sparse=False, inrange=False):
     """-> (run callable, check callable(result) -> dict, L + R rows, algorithmic bytes given the pair count).
     sparse: the same tables with every key multiplied by an odd constant (keys no longer span a small range: the hash table
-    instead of the direct-address table)."""
+    instead of the direct-address table).
+    inrange: dense keys whose MISSES lie inside the build side's key range - build = the even keys of [0, 2 nr), a probe row
+    that matches carries an even key, one that does not an odd key of the same range - so that the direct-address table's range test
+    rejects nothing and every probe row costs a table access."""
     dev = dev or torch.device("cuda", 0)
     nl, nr = int(500_000_000 * scale), int(50_000_000 * scale)
     g = torch.Generator(device=dev).manual_seed(12345)
@@ -133,9 +136,12 @@ def make_c3(scale, dev=None, sparse=False):
     lk = torch.where(sel, torch.randint(0, nr, (nl,), generator=g, device=dev, dtype=torch.int64),
                      torch.randint(nr, 2 * nr, (nl,), generator=g, device=dev, dtype=torch.int64))
     del sel
+    if inrange:
+        rk = rk * 2
+        lk = torch.where(lk < nr, lk * 2, (lk - nr) * 2 + 1)
     lm, lnulls, lvalid = bernoulli_mask(nl, 0.05, 44, dev)
     rm, rnulls, rvalid = bernoulli_mask(nr, 0.05, 45, dev)
-    present = torch.zeros(2 * nr, dtype=torch.bool, device=dev)
+    present = torch.zeros(2 * nr + 2, dtype=torch.bool, device=dev)
     present[rk[rvalid]] = True
     expect = int((present[lk] & lvalid).sum())
     del present
@@ -158,14 +164,14 @@ def make_c3(scale, dev=None, sparse=False):
     return run, check, nl + nr, lambda M: 8 * (nl + nr) + (nl + nr) / 8 + 8 * M, (nl, nr, dev)
 
 
-def c3(scale, sparse=False):
-    run, check, rows, algo, (nl, nr, dev) = make_c3(scale, sparse=sparse)
+def c3(scale, sparse=False, inrange=False):
+    run, check, rows, algo, (nl, nr, dev) = make_c3(scale, sparse=sparse, inrange=inrange)
     (li, ri), dt, prof = timed(run, 3, 2)
     checks = check((li, ri))
     M = checks["pairs"]
     li_t = li.to_torch().long()
     algo_bytes = algo(M)
-    out = {"config": "C3" + (" (sparse keys: hash table)" if sparse else ""), "left_rows": nl, "right_rows": nr, "pairs": M, "join_ms": dt * 1e3,
+    out = {"config": "C3" + (" (sparse keys: hash table)" if sparse else "") + (" (dense keys, misses inside the key range)" if inrange else ""), "left_rows": nl, "right_rows": nr, "pairs": M, "join_ms": dt * 1e3,
            "rows_per_s": (nl + nr) / dt, "algorithmic_GBps": algo_bytes / dt / 1e9, "kernels_ms": prof, "checks": checks}
     # gather 2 + 2 float64 payload columns by the returned indices
     lp = cudf_amd.Table([cudf_amd.Column.from_torch(torch.rand(nl, device=dev, dtype=torch.float64)) for _ in range(2)])
@@ -194,3 +200,6 @@ if __name__ == "__main__":
         torch.cuda.empty_cache()
     if "c3sparse" in which:
         c3(scale, sparse=True)
+        torch.cuda.empty_cache()
+    if "c3inrange" in which:
+        c3(scale, inrange=True)

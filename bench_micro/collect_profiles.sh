@@ -18,7 +18,7 @@ python3 $ROOT/bench_micro/summarize_profiles.py $OUT
 for c in c3 c4; do timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$c -o stats -- python3 $ROOT/bench.py --config $c --steps 3 --warmup 2 --no-cpu-baseline > $OUT/stats_$c.log 2>&1; done
 # PMC traffic of the C3 / C3-sparse / C4 kernels: the same two counter passes per configuration
 if [ "${PMC_CONFIGS:-1}" = "1" ]; then
-  for c in c3 c3sparse c4; do
+  for c in c3 c3sparse c3inrange c4; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
       timeout -k 10 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${c}_$ctr -o pmc -- python3 $ROOT/bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_${c}_$ctr.log 2>&1
     done

@@ -13,14 +13,55 @@ out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def sources_sha256():
+    """Hash of the kernel / host sources the library is built from: bench.py quotes the PMC traffic only for a matching tree."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "cudf_amd", "csrc")
+    for d, _, fs in sorted(os.walk(base)):
+        if os.sep + "build" in d:
+            continue
+        for f in sorted(fs):
+            if f.endswith((".hip", ".cpp", ".hpp", ".inl", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def label_map():
+    """kernel function name -> profiler labels, read off the sources: every hipLaunchKernelGGL behind a prof::scope of its function."""
+    import re
+    m = {}
+    base = os.path.join(ROOT, "cudf_amd", "csrc")
+    for f in glob.glob(os.path.join(base, "**", "*.hip"), recursive=True) + glob.glob(os.path.join(base, "**", "*.cpp"), recursive=True):
+        label = None
+        for line in open(f, errors="ignore"):
+            sc = re.search(r'prof::scope \w+\{([^}]*)\}', line)
+            if sc:
+                label = re.findall(r'"([a-z0-9_]+)"', sc.group(1))
+            for k in re.findall(r'hipLaunchKernelGGL\(\(?\s*(k_[A-Za-z0-9_]+)', line):
+                if label:
+                    m.setdefault(k, set()).update(label)
+            if line.startswith("}"):
+                label = None
+    return {k: sorted(v) for k, v in m.items()}
+
+
 def config_traffic():
     """PMC traffic per kernel NAME for the C3 / C3-sparse / C4 runs (pmc_<config>_<counter>/): pmc_traffic_configs.json."""
     import re
     doc = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --config <c> "
                   "--steps 2 --warmup 1 --no-cpu-baseline`; per-launch averages over every dispatch of a kernel; read bytes = 2 x FETCH_SIZE "
                   "(gfx950: 128-B requests tallied at 64 B), WRITE_SIZE as is; warm-up launches included in the average", "configs": {}}
-    for c in ("c3", "c3sparse", "c4"):
+    labels_of = label_map()
+    doc["sources_sha256"] = sources_sha256()
+    doc["how"] += ("; `labels`: HBM bytes per STEP of the kernels that run under each profiler label of the library (the names bench.py's "
+                   "`roofline.kernel` carries), = sum over their dispatches / 3 runs (2 steps + 1 warm-up); a kernel that runs under two "
+                   "labels (k_radix_join: count and retrieve) is charged to both")
+    doc["labels"] = {}
+    RUNS = 3
+    for c in ("c3", "c3sparse", "c3inrange", "c4"):
         per = {}
+        lab = defaultdict(float)
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             fs = glob.glob(os.path.join(out, f"pmc_{c}_{counter}", "**", "*counter_collection.csv"), recursive=True)
             if not fs:
@@ -34,13 +75,19 @@ def config_traffic():
                 name = (m.group(1) + (m.group(2) or "")[:48]) if m else full[:64]
                 acc[name][0] += float(r["Counter_Value"])
                 acc[name][1].add(r.get("Dispatch_Id"))
+                if m:
+                    for l in labels_of.get(m.group(1), []):
+                        lab[l] += float(r["Counter_Value"]) * 1024 * (2 if counter == "FETCH_SIZE" else 1) / RUNS
             for k, (tot, ids) in acc.items():
                 per.setdefault(k, {})[counter + "_KB_per_launch"] = tot / max(1, len(ids))
                 per[k]["launches"] = len(ids)
         for k, d in per.items():
             d["read_GB"] = round(2 * d.get("FETCH_SIZE_KB_per_launch", 0) * 1024 / 1e9, 3)
             d["write_GB"] = round(d.get("WRITE_SIZE_KB_per_launch", 0) * 1024 / 1e9, 3)
+        if not per:
+            continue
         doc["configs"][c] = {k: v for k, v in sorted(per.items(), key=lambda kv: -(kv[1]["read_GB"] + kv[1]["write_GB"]))[:10]}
+        doc["labels"][c] = {l: {"hbm_bytes_per_step": b} for l, b in sorted(lab.items())}
     json.dump(doc, open(os.path.join(out, "pmc_traffic_configs.json"), "w"), indent=1)
     print(json.dumps({c: {k: (v["read_GB"], v["write_GB"]) for k, v in d.items()} for c, d in doc["configs"].items()})[:1500])
 
@@ -48,20 +95,6 @@ def config_traffic():
 if len(sys.argv) > 2 and sys.argv[2] == "configs":
     config_traffic()
     sys.exit(0)
-
-
-def sources_sha256():
-    """Hash of the kernel / host sources the library is built from: bench.py quotes the PMC traffic only for a matching tree."""
-    h = hashlib.sha256()
-    base = os.path.join(ROOT, "cudf_amd", "csrc")
-    for d, _, fs in sorted(os.walk(base)):
-        if os.sep + "build" in d:
-            continue
-        for f in sorted(fs):
-            if f.endswith((".hip", ".cpp", ".hpp", ".inl", ".h")):
-                h.update(f.encode())
-                h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()
 
 
 def find(sub, pat):

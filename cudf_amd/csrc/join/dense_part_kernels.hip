@@ -198,6 +198,30 @@ __global__ void __launch_bounds__(256) k_dense_probe_staged(dense_stage_args con
   if (lane == 0) a.pair_counts[w] = npairs;
 }
 
+// (engine.hpp launch_dense_inrange_sample) out[0] += sampled rows, out[1] += sampled rows whose key is valid and inside the table's range
+__global__ void __launch_bounds__(256) k_dense_inrange_sample(dense_stage_args const* __restrict__ ap, int64_t stride, unsigned long long* __restrict__ out)
+{
+  dense_stage_args const& a = *ap;
+  int64_t const r = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * stride;
+  bool in = false, sampled = r < a.nrows;
+  if (sampled) {
+    uint64_t idx;
+    if (a.key_width == 4) {
+      uint32_t const k32 = gload(reinterpret_cast<uint32_t const*>(a.keys) + r);
+      idx = (a.key_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32)) - a.dense_lo;
+    } else {
+      idx = gload(a.keys + r) - a.dense_lo;
+    }
+    in = idx < a.dense_range;
+    if (in && a.mask != nullptr) in = (gload(a.mask + ((a.mask_offset + r) >> 5)) >> ((a.mask_offset + r) & 31)) & 1u;
+  }
+  unsigned long long const ns = __popcll(__ballot(sampled)), ni = __popcll(__ballot(in));
+  if ((threadIdx.x & 63) == 0 && ns > 0) {
+    atomicAdd(out, ns);
+    if (ni > 0) atomicAdd(out + 1, ni);
+  }
+}
+
 // (engine.hpp launch_dense_left_direct)
 __global__ void __launch_bounds__(256) k_dense_left_direct(dense_stage_args const* __restrict__ ap, size_type* __restrict__ out_probe,
                                                            size_type* __restrict__ out_build)
@@ -242,6 +266,18 @@ __global__ void __launch_bounds__(256) k_dense_left_direct(dense_stage_args cons
 }
 
 }  // namespace
+
+void launch_dense_inrange_sample(dense_stage_args const& a, dense_stage_args* d_args, int64_t samples, unsigned long long* out, hipStream_t stream)
+{
+  CUDF_EXPECTS(a.keys != nullptr && out != nullptr && a.nrows >= 1 && samples >= 1 && (a.key_width == 4 || a.key_width == 8), "dense join, probe sample: arguments");
+  hipLaunchKernelGGL(k_store_dense_stage_args, dim3(1), dim3(1), 0, stream, a, d_args);
+  CUDF_HIP_TRY(hipMemsetAsync(out, 0, 2 * sizeof(unsigned long long), stream));
+  int64_t const stride = std::max<int64_t>(1, a.nrows / samples);
+  int64_t const n      = (a.nrows + stride - 1) / stride;
+  cudf::detail::prof::scope prof_{"join_sample", stream};
+  hipLaunchKernelGGL(k_dense_inrange_sample, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, d_args, stride, out);
+  CUDF_HIP_TRY(hipGetLastError());
+}
 
 void launch_dense_left_direct(dense_stage_args const& a, dense_stage_args* d_args, size_type* out_probe, size_type* out_build, hipStream_t stream)
 {

@@ -220,6 +220,10 @@ void launch_dense_probe_staged(dense_stage_args const& a, dense_stage_args* d_ar
 // out_build[i] = head[key_i - lo] (or JoinNoMatch for a NULL key, a key outside the range, an empty entry). Uses dense_stage_args'
 // keys / mask / nrows / dense_* / head / probe_row_base.
 void launch_dense_left_direct(dense_stage_args const& a, dense_stage_args* d_args, size_type* out_probe, size_type* out_build, hipStream_t stream);
+// A strided sample of about `samples` probe rows: out[0] = rows sampled, out[1] = those whose key is valid and inside [dense_lo,
+// dense_lo + dense_range) - the share of the probe side that costs the direct probe a random table access (the rest is rejected by the
+// range test for free). Uses dense_stage_args' keys / mask / nrows / dense_*.
+void launch_dense_inrange_sample(dense_stage_args const& a, dense_stage_args* d_args, int64_t samples, unsigned long long* out, hipStream_t stream);
 
 void launch_dense_part_store(dense_part_args const& a, dense_part_args* d_args, hipStream_t stream);
 void launch_dense_count_filled(int32_t const* head, uint64_t n, unsigned long long* out, hipStream_t stream);

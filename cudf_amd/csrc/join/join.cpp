@@ -802,8 +802,19 @@ class hash_join_impl {
     }
     // a dense unique table. CUDF_AMD_JOIN_DENSE_PROBE: 1 (default) inner joins by the ordered direct probe (pairs in probe-row
     // order), 2 by probe rows partitioned by key range (~0.6 ms less at C3, pairs partition-major), 0 neither; left joins in one pass
-    int64_t const dense_probe = env_flag("CUDF_AMD_JOIN_DENSE_PROBE", 1);
-    bool const unique_table   = (_dense && !_dense_has_dups) || _dense_part;
+    int64_t dense_probe     = env_flag("CUDF_AMD_JOIN_DENSE_PROBE", -1);
+    bool const unique_table = (_dense && !_dense_has_dups) || _dense_part;
+    if (dense_probe < 0) {
+      // The ordered direct probe pays one random access into the table per probe key INSIDE the table's range (a key outside is
+      // rejected by the range test for free): with 30 % of C3's probe keys in range it takes 3.3 ms, with 95 % in range 9.3 ms - the
+      // probe rows partitioned by key range (L2-local lookups) take 6.0 ms + the pairs partition-major (profiles/r4_c3_inrange.txt).
+      // A strided sample of the probe keys decides; the table must be large enough for the partitions to matter.
+      dense_probe = 1;
+      if (_dense_part && k == 0 && left.num_rows() >= env_flag("CUDF_AMD_JOIN_DENSE_PART_MIN_PROBE", 8 << 20) && single_int_width(left) == _keyw) {
+        double const share = dense_inrange_share(left, stream);
+        if (share > 0.01 * static_cast<double>(env_flag("CUDF_AMD_JOIN_DENSE_PART_INRANGE_PCT", 55))) dense_probe = 2;
+      }
+    }
     if (unique_table && k == 0 && dense_probe == 1) {
       if (auto r = or_nothing([&] { return dense_ordered_probe(left, stream, mr, row_base); }); r.has_value()) return r;
     }
@@ -814,6 +825,30 @@ class hash_join_impl {
       if (auto r = or_nothing([&] { return dense_part_probe(left, stream, mr, row_base); }); r.has_value()) return r;
     }
     return std::nullopt;
+  }
+
+  // share of the probe rows whose key is valid and inside the dense table's range (a sample of ~64K rows; one small kernel + read-back)
+  [[nodiscard]] double dense_inrange_share(table_view const& left, stream_ref stream) const
+  {
+    auto const& col        = left.column(0);
+    bool const probe_nulls = _has_nulls && col.has_nulls();
+    hipStream_t const s    = stream.value();
+    auto tmp               = cudf::get_current_device_resource_ref();
+    join::dense_stage_args a{};
+    a.keys        = key_bytes(col, _keyw);
+    a.key_width   = _keyw;
+    a.key_signed  = _key_signed ? 1 : 0;
+    a.mask        = probe_nulls ? col.null_mask() : nullptr;
+    a.mask_offset = col.offset();
+    a.nrows       = left.num_rows();
+    a.dense_lo    = _dense_lo;
+    a.dense_range = _dense_range;
+    rmm::device_buffer d_args{sizeof(join::dense_stage_args), s, tmp}, d_out{2 * sizeof(unsigned long long), s, tmp};
+    join::launch_dense_inrange_sample(a, static_cast<join::dense_stage_args*>(d_args.data()), 1 << 16, static_cast<unsigned long long*>(d_out.data()), s);
+    unsigned long long h[2] = {0, 0};
+    CUDF_HIP_TRY(hipMemcpyAsync(h, d_out.data(), sizeof(h), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    return h[0] == 0 ? 0.0 : static_cast<double>(h[1]) / static_cast<double>(h[0]);
   }
 
   // LEFT join against a dense unique table: one pair per probe row, in order - a single pass (engine.hpp launch_dense_left_direct)

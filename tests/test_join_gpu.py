@@ -578,6 +578,26 @@ def force_dense_part(monkeypatch):
     monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_PROBE", "2")  # (the default, 1, is the ordered direct probe: test_dense_ordered_probe_*)
 
 
+@pytest.mark.parametrize("inrange,expect_partitioned", [(0.95, True), (0.30, False)])
+def test_dense_probe_is_chosen_from_the_in_range_share_of_the_probe_keys(G, oracle, monkeypatch, inrange, expect_partitioned):
+    """With no CUDF_AMD_JOIN_DENSE_PROBE the join samples the probe keys: mostly INSIDE the table's range (every row costs the direct
+    probe a random access) -> probe rows partitioned by key range; mostly outside (the range test rejects them for free) -> the
+    ordered direct probe. Misses inside the range: the build side holds the even keys, the misses are odd (bench.py --config c3inrange)."""
+    monkeypatch.delenv("CUDF_AMD_JOIN_DENSE_PROBE", raising=False)
+    for k, v in (("MIN_ROWS", "1"), ("PART_MIN_BUILD", "0"), ("PART_MIN_RANGE", "0"), ("PART_MIN_PROBE", "0"), ("PART_SLICE_LOG2", "10"), ("ORDERED_MIN_PROBE", "0")):
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_" + k, v)
+    rng = np.random.default_rng(int(inrange * 100))
+    nl, nr = 700_000, 150_000
+    rk = rng.permutation(nr).astype(np.int64) * 2 + 10_000                                  # even keys of [10000, 10000 + 2 nr)
+    inside = rng.random(nl) < inrange
+    lk = np.where(inside, rng.integers(0, 2 * nr, nl) + 10_000, rng.integers(0, 2 * nr, nl) + 10_000 + 4 * nr).astype(np.int64)
+    (li, ri), kernels = _kernels_of(lambda: G.join([lk], [rk], nulls_equal=True, kind="inner"))
+    assert kernels.get("join_sample") == 1, kernels
+    assert (kernels.get("join_partition", 0) == 2) == expect_partitioned, kernels  # (2: the build side's stores and the probe side)
+    el, er = oracle.join([lk], [rk], nulls_equal=True, kind="inner")
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+
+
 @pytest.mark.parametrize("shape", ["unique", "nulls", "negative", "one_partition"])
 def test_dense_part_join_matches_oracle(G, oracle, force_dense_part, monkeypatch, shape):
     """Unique dense build keys, probe keys inside and outside the build range (the latter are dropped by the partition pass),
