@@ -379,9 +379,11 @@ class hash_join_impl {
   }
   static constexpr int32_t RADIX_TABLE_SLOTS = 8192, RADIX_FILL_LIMIT = 5200;
 
-  // inner join of a big probe side against the radix-partitioned build side; nullopt: this probe side does not take it
+  // inner join of a big probe side against the radix-partitioned build side; nullopt: this probe side does not take it.
+  // size_only != nullptr: the count pass only - *size_only = the number of pairs, the pair holds no vectors (inner / left_join_size
+  // against a radix build: no second copy of the build side in an open-addressing table just to count)
   std::optional<join_index_pair> radix_probe(table_view const& left, stream_ref stream, rmm::device_async_resource_ref mr, int64_t row_base,
-                                             bool left_join = false) const
+                                             bool left_join = false, std::size_t* size_only = nullptr) const
   {
     auto const& col = left.column(0);
     bool const probe_nulls = _has_nulls && col.has_nulls();
@@ -436,6 +438,10 @@ class hash_join_impl {
     // (left join: the probe rows with a NULL key never entered a partition; their {row, JoinNoMatch} pairs follow the partitions')
     unsigned long long const null_rows = (left_join && probe_nulls) ? static_cast<unsigned long long>(col.null_count()) : 0ull;
     unsigned long long const pairs_all = total + null_rows;
+    if (size_only != nullptr) {
+      *size_only = static_cast<std::size_t>(pairs_all);
+      return join_index_pair{nullptr, nullptr};
+    }
     CUDF_EXPECTS(pairs_all <= static_cast<unsigned long long>(std::numeric_limits<size_type>::max()),
                  "Join result exceeds the maximum column size; use the *_join_size API and chunk the probe side.", std::overflow_error);
     auto out_l = std::make_unique<rmm::device_uvector<size_type>>(static_cast<std::size_t>(pairs_all), s, mr);
@@ -683,6 +689,13 @@ class hash_join_impl {
       // needs the matched set of the build side: run the real join and take its size
       auto r = probe(left, kind, std::nullopt, stream, cudf::get_current_device_resource_ref());
       return r.first->size();
+    }
+    if (_radix) {  // the radix join's count pass (partition the probe side, count per partition): nothing else is built
+      std::size_t pairs = 0;
+      try {
+        if (radix_probe(left, stream, cudf::get_current_device_resource_ref(), 0, kind == join_kind::LEFT_JOIN, &pairs).has_value()) return pairs;
+      } catch (std::bad_alloc const&) {  // (its scratch did not fit: the tables below)
+      }
     }
     ensure_classic(stream);
     join_args a = base_args(left, kind == join_kind::INNER_JOIN ? 0 : 1);

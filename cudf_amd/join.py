@@ -48,6 +48,11 @@ class JoinPartitionContext:
         self.left_end_idx = int(left_end_idx)
 
 
+def _sync_stream(stream):
+    """hipStreamSynchronize of a torch stream / raw hipStream_t / the default stream (None), through the library."""
+    _lib.check(_lib.load().cudf_amd_stream_synchronize(_stream_ptr(stream)))
+
+
 class HashJoin:
     """cudf::hash_join(right, [has_nulls], compare_nulls, [load_factor]). `has_nulls`: True / False / None
     (None selects the two-argument constructor, which assumes nulls may be present)."""
@@ -64,11 +69,22 @@ class HashJoin:
     def __del__(self):
         try:
             if self._h:
+                # probes return without synchronising their stream and the object's tables go back to the pool on the BUILD stream:
+                # the probe streams used since the last synchronisation are drained first (include/cudf/join/hash_join.hpp, Lifetime)
+                for s in getattr(self, "_probe_streams", ()):
+                    _sync_stream(s)
                 _lib.load().cudf_amd_hash_join_destroy(self._h)
         except Exception:
             pass
 
+    def _note_stream(self, stream):
+        if not hasattr(self, "_probe_streams"):
+            self._probe_streams = []
+        if not any(s is stream for s in self._probe_streams):
+            self._probe_streams.append(stream)
+
     def _probe(self, left_keys, kind, output_size, stream):
+        self._note_stream(stream)
         out = C.c_void_p()
         _lib.check(_lib.load().cudf_amd_hash_join_probe(self._h, left_keys._views(), left_keys.num_columns(), _KIND[kind],
                                                         -1 if output_size is None else int(output_size),
@@ -83,6 +99,7 @@ class HashJoin:
         return n.value
 
     def _match_context(self, left_keys, kind, stream):
+        self._note_stream(stream)
         out = C.c_void_p()
         _lib.check(_lib.load().cudf_amd_hash_join_match_counts(self._h, left_keys._views(), left_keys.num_columns(),
                                                                _KIND[kind], _stream_ptr(stream), C.byref(out)))

@@ -2,6 +2,12 @@
 // cudf::hash_join — build once on `right`, probe many times. Signatures follow reference
 // cpp/include/cudf/join/hash_join.hpp:62 (nullable_join: YES == false!), :71 (class), ctor pair, inner_join,
 // left_join, full_join, *_join_size. Probes are const and may run concurrently on different streams.
+// Lifetime (as in libcudf): a probe returns without synchronising its stream; the hash_join object - whose tables the probe kernels
+// read and which go back to the pool on the BUILD stream when it is destroyed - must outlive, or be stream-synchronised with, every
+// probe stream it was used on (the Python mirror synchronises the last probe stream before cudf_amd_hash_join_destroy). Against a
+// build side that took the radix partitions, *_join_size runs the radix join's count pass; every other probe that the partitioned
+// paths do not take (small probe sides, full joins, match contexts) builds the open-addressing table lazily on first use, on the
+// probe's stream with the memory resource given to the constructor - which therefore has to stay alive as long as the object.
 #pragma once
 #include <cudf/join/join.hpp>
 #include <cudf/utilities/span.hpp>

@@ -219,5 +219,25 @@ def run_join_table_case(backend, c):
     assert got == gold, f"join rows differ:\n{got}\n{gold}"
 
 
+def partitioned_case_tables(c):
+    """(left host columns, right host columns) of a `partitioned_cases` entry; a generated case builds its columns from the recipe the
+    reference test states (join_tests.cpp:3636-3709: left[i] = i % 200 sliced to [1234, 3734), right[i] = i)."""
+    if "generator" in c:
+        g = c["generator"]
+        assert g["left_value"] == "i % 200" and g["right_value"] == "i"
+        a, b = g["left_slice"]
+        left = [host_col((np.arange(g["left_full_rows"]) % 200)[a:b].tolist(), "int32", None)]
+        right = [host_col(np.arange(g["right_rows"]).tolist(), "int32", None)]
+        return left, right
+    return table_cols(c["left"]), table_cols(c["right"])
+
+
+def match_counts_from_pairs(li, nrows, kind):
+    """Per-left-row match counts a join's pairs imply (what *_join_match_context holds): inner = matches, left / full = matches or 1."""
+    li = np.asarray([x for x in li if x != -2**31], dtype=np.int64)
+    counts = np.bincount(li, minlength=nrows).astype(np.int64) if nrows else np.zeros(0, np.int64)
+    return counts.tolist()
+
+
 def sorted_pairs(li, ri):
     return sorted(zip([int(x) for x in li], [int(x) for x in ri]))

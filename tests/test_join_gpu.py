@@ -41,6 +41,73 @@ def test_hash_join_kat(G, c):
         assert kat.sorted_pairs(li.to_numpy()[0], ri.to_numpy()[0]) == kat.sorted_pairs(p["gold_left"], p["gold_right"])
 
 
+@pytest.mark.parametrize("c", kat.load("kat_join.json")["match_context_cases"], ids=lambda c: c["name"])
+def test_match_context_golden(G, c):
+    """Every match-context vector of the reference (join_tests.cpp:2418-2651), from tests/golden/kat_join.json."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    lt, rt = kat.table_cols(c["left"]), kat.table_cols(c["right"])
+    right = cudf_amd.Table([G.to_device(rt[i]) for i in c["on"]])
+    left = cudf_amd.Table([G.to_device(lt[i]) for i in c["on"]])
+    hj = HashJoin(right, NullEquality.EQUAL if c["nulls"] == "equal" else NullEquality.UNEQUAL)
+    ctx = getattr(hj, f"{c['kind']}_join_match_context")(left)
+    counts = ctx._match_counts.to_numpy()[0]
+    assert counts.dtype == np.int32 and counts.tolist() == c["match_counts"]
+    if c["size_equals_sum"]:
+        assert getattr(hj, f"{c['kind']}_join_size")(left) == sum(c["match_counts"])
+
+
+@pytest.mark.parametrize("c", kat.load("kat_join.json")["sorted_index_cases"], ids=lambda c: c["name"])
+def test_sorted_index_golden(G, c):
+    """HashJoinWithNullsOneSide (join_tests.cpp:2271-2378): sizes, then the two index columns sorted independently."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    right = cudf_amd.Table([G.to_device(x) for x in kat.table_cols(c["right"])])
+    left = cudf_amd.Table([G.to_device(x) for x in kat.table_cols(c["left"])])
+    hj = HashJoin(right, NullEquality.EQUAL if c["nulls"] == "equal" else NullEquality.UNEQUAL)
+    for p in c["probes"]:
+        size = getattr(hj, p["kind"] + "_join_size")(left)
+        assert size == p["size"]
+        li, ri = getattr(hj, p["kind"] + "_join")(left, output_size=size)
+        assert sorted(li.to_numpy()[0].tolist()) == p["sorted_left"] and sorted(ri.to_numpy()[0].tolist()) == p["sorted_right"]
+
+
+@pytest.mark.parametrize("c", kat.load("kat_join.json")["partitioned_cases"], ids=lambda c: c["name"])
+def test_partitioned_golden(G, oracle, c):
+    """The reference's partitioned-join tests (join_tests.cpp:3347-3709): partitioned_*_join over the stated row ranges, concatenated
+    (a full join through finalize_partitioned_full_join), equals the whole join; an empty range yields nothing."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin, JoinPartitionContext
+    from cudf_amd.types import NullEquality
+    left_all, right_all = kat.partitioned_case_tables(c)
+    lcols, rcols = [left_all[i] for i in c["on"]], [right_all[i] for i in c["on"]]
+    right = cudf_amd.Table([G.to_device(x) for x in rcols])
+    left = cudf_amd.Table([G.to_device(x) for x in lcols])
+    hj = HashJoin(right, NullEquality.EQUAL if c["nulls"] == "equal" else NullEquality.UNEQUAL)
+    ctx = getattr(hj, f"{c['kind']}_join_match_context")(left)
+    lparts, rparts = [], []
+    for a, b in c["ranges"]:
+        li, ri = getattr(hj, f"partitioned_{c['kind']}_join")(JoinPartitionContext(ctx, a, b))
+        lparts.append(li)
+        rparts.append(ri)
+    if "expect_pairs" in c:
+        assert sum(x.size() for x in lparts) == c["expect_pairs"]
+    if c["kind"] == "full":
+        fl, fr = HashJoin.finalize_partitioned_full_join(lparts, rparts, len(lcols[0].data), len(rcols[0].data))
+        got_l, got_r = fl.to_numpy()[0], fr.to_numpy()[0]
+    else:
+        got_l = np.concatenate([x.to_numpy()[0] for x in lparts])
+        got_r = np.concatenate([x.to_numpy()[0] for x in rparts])
+    covered = sorted(x for a, b in c["ranges"] for x in range(a, b))
+    if covered == list(range(len(lcols[0].data))):
+        wl, wr = getattr(hj, f"{c['kind']}_join")(left)
+        assert kat.sorted_pairs(got_l, got_r) == kat.sorted_pairs(wl.to_numpy()[0], wr.to_numpy()[0])
+        el, er = oracle.join(lcols, rcols, nulls_equal=(c["nulls"] == "equal"), kind=c["kind"])
+        assert kat.sorted_pairs(got_l, got_r) == kat.sorted_pairs(el, er)
+
+
 def test_join_generated_kats(G):
     import cudf_amd
     from cudf_amd.join import HashJoin
@@ -836,3 +903,27 @@ def test_round3_join_paths_edge_cases(G, oracle, monkeypatch, path):
             el, er = oracle.join([(lk, lv) if lv is not None else lk], [rk], nulls_equal=False, kind=kind)
             assert gl.size() == len(el), (kind, len(lk))
             assert kat.sorted_pairs(gl.to_numpy()[0], gr.to_numpy()[0]) == kat.sorted_pairs(el, er)
+
+
+def test_join_size_against_a_radix_build_runs_the_count_pass_only(G, oracle, force_radix_join):
+    """inner_join_size / left_join_size on a hash_join whose build side took the radix partitions: the radix join's count pass answers
+    (no open-addressing copy of the build side is built just to count - ADVICE r3), and the sizes equal the joins' pair counts."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng(77)
+    nl, nr = 400_000, 60_000
+    rk = (rng.permutation(200_000)[:nr].astype(np.int64)) * 1_000_003
+    lk = (rng.integers(0, 260_000, nl, dtype=np.int64)) * 1_000_003
+    lv = rng.random(nl) > 0.05
+    hj = HashJoin(cudf_amd.Table([G.to_device(rk)]), NullEquality.UNEQUAL)
+    t = cudf_amd.Table([G.to_device((lk, lv))])
+    n_inner, kernels = _kernels_of(lambda: hj.inner_join_size(t))
+    assert kernels.get("join_build", 0) == 0, kernels  # (nothing built by the size call)
+    n_left = hj.left_join_size(t)
+    el, _ = oracle.join([(lk, lv)], [rk], nulls_equal=False, kind="inner")
+    assert n_inner == len(el)
+    assert n_left == len(el) + int(nl - len(np.unique(el)))
+    li, _ = hj.inner_join(t)
+    assert li.size() == n_inner
+    del hj  # (destroyed right behind an unsynchronised probe: the mirror drains the probe stream first)

@@ -57,6 +57,52 @@ def test_hash_join_kat(c):
         assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(p["gold_left"], p["gold_right"])
 
 
+@pytest.mark.parametrize("c", kat.load("kat_join.json")["match_context_cases"], ids=lambda c: c["name"])
+def test_match_context_kat(c):
+    """The reference's match-context vectors (join_tests.cpp:2418-2651) against the oracle's joins: the pairs of the LEFT (for left /
+    full contexts) or INNER join imply the per-row counts."""
+    left = [kat.table_cols(c["left"])[i] for i in c["on"]]
+    right = [kat.table_cols(c["right"])[i] for i in c["on"]]
+    kind = "inner" if c["kind"] == "inner" else "left"
+    li, _ = O.join(left, right, nulls_equal=(c["nulls"] == "equal"), kind=kind)
+    assert kat.match_counts_from_pairs(li, len(c["left"]["cols"][0]), c["kind"]) == c["match_counts"]
+    if c["size_equals_sum"]:
+        assert O.join_size(left, right, nulls_equal=(c["nulls"] == "equal"), kind=kind) == sum(c["match_counts"])
+
+
+@pytest.mark.parametrize("c", kat.load("kat_join.json")["sorted_index_cases"], ids=lambda c: c["name"])
+def test_sorted_index_kat(c):
+    left, right = kat.table_cols(c["left"]), kat.table_cols(c["right"])
+    for p in c["probes"]:
+        li, ri = O.join(left, right, nulls_equal=(c["nulls"] == "equal"), kind=p["kind"])
+        assert O.join_size(left, right, nulls_equal=(c["nulls"] == "equal"), kind=p["kind"]) == p["size"] == len(li)
+        assert sorted(int(x) for x in li) == p["sorted_left"] and sorted(int(x) for x in ri) == p["sorted_right"]
+
+
+@pytest.mark.parametrize("c", kat.load("kat_join.json")["partitioned_cases"], ids=lambda c: c["name"])
+def test_partitioned_kat(c):
+    """join_tests.cpp:3347-3709 on the oracle: joining the row ranges of the left table one by one (indices shifted back to the whole
+    table; a full join's unmatched right rows appended once, as finalize_partitioned_full_join does) gives the whole join."""
+    left_all, right_all = kat.partitioned_case_tables(c)
+    left = [left_all[i] for i in c["on"]]
+    right = [right_all[i] for i in c["on"]]
+    ne = c["nulls"] == "equal"
+    pairs, matched_right = [], set()
+    for a, b in c["ranges"]:
+        part = [O.HostColumn(col.data[a:b], None if col.valid is None else col.valid[a:b]) for col in left]  # (int32 columns throughout)
+        li, ri = O.join(part, right, nulls_equal=ne, kind="inner" if c["kind"] == "inner" else "left") if b > a else ([], [])
+        pairs += [(int(l) + a, int(r)) for l, r in zip(li, ri)]
+        matched_right |= {int(r) for r in ri if r != -2**31}
+    if "expect_pairs" in c:
+        assert len(pairs) == c["expect_pairs"]
+    if c["kind"] == "full":
+        pairs += [(-2**31, r) for r in range(len(right[0].data)) if r not in matched_right]
+    covered = sorted(x for a, b in c["ranges"] for x in range(a, b))
+    if covered == list(range(len(left[0].data))):
+        el, er = O.join(left, right, nulls_equal=ne, kind=c["kind"])
+        assert sorted(pairs) == kat.sorted_pairs(el, er)
+
+
 def test_join_generated_kats():
     z = np.zeros(65567, np.int32)  # join_tests.cpp:2379-2394
     assert O.join_size([z], [z], nulls_equal=False) == 65567 * 65567
