@@ -107,6 +107,7 @@ struct radix_scatter_args {
   uint64_t const* keys;        // element i = key of row i (key_width bytes each)
   int32_t key_width;           // 8, or 4: a 4-byte integer column, widened to 64 bits by the scatter (key_signed: sign-extended)
   int32_t key_signed;
+  int32_t key_class;           // CLS_F32 / CLS_F64: a float column - its normalised bits (-0 -> +0, one NaN) are the key; 0: integers
   // two 4-byte integer key columns (keys, keys2), packed into the 8-byte key; mask2: the second column's validity (nullptr: none)
   uint32_t const* keys2;
   bitmask_type const* mask2;

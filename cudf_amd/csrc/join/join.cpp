@@ -58,15 +58,23 @@ bool is_single64(table_view const& t)
   return size_of_id(id) == 8 && (cls == CLS_SINT || cls == CLS_UINT);
 }
 
-// 8 or 4: the table is ONE integer key column of that width (what the partitioned joins take; 4-byte keys are widened by their
-// first scatter level); 0 otherwise
+// 8 or 4: the table is ONE key column of that width that the partitioned joins take - an integer (timestamps, durations and
+// decimals included; 4-byte keys are widened by the first scatter level) or, for the radix join only, a float whose NORMALISED bits
+// (-0 -> +0, one NaN: the row equality of common/device_table.hpp) serve as the 8-byte key; 0 otherwise
 int single_int_width(table_view const& t)
 {
   if (t.num_columns() != 1) return 0;
   auto const id  = t.column(0).type().id();
   auto const cls = class_of(id);
   auto const w   = size_of_id(id);
+  if (cls == CLS_F64) return 8;
+  if (cls == CLS_F32) return 4;
   return (cls == CLS_SINT || cls == CLS_UINT) && (w == 8 || w == 4) ? static_cast<int>(w) : 0;
+}
+bool is_float_key(table_view const& t)
+{
+  auto const cls = t.num_columns() == 1 ? class_of(t.column(0).type().id()) : CLS_NONE;
+  return cls == CLS_F32 || cls == CLS_F64;
 }
 // the table is TWO 4-byte integer key columns: the radix join packs them into its 8-byte key
 bool is_two_int32(table_view const& t)
@@ -144,11 +152,12 @@ class hash_join_impl {
     _pack2        = (!build_check_nulls || _nulls_equal != null_equality::EQUAL) && is_two_int32(right);
     if (_pack2) _keyw = 4;
     _key_signed   = _keyw != 0 && class_of(right.column(0).type().id()) == CLS_SINT;
+    _key_class    = (_keyw != 0 && !_pack2 && is_float_key(right)) ? static_cast<int32_t>(class_of(right.column(0).type().id())) : 0;
     _key64        = key64;
     _classic_load = load_factor;
     // Dense build keys (one 8-byte integer key column, NULLs never match, valid values within a small range): a direct-address
     // table over [min, max] replaces the hash table - see engine.hpp. Decided from the exact minimum / maximum of the build keys.
-    if (_keyw != 0 && !_pack2 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
+    if (_keyw != 0 && !_pack2 && _key_class == 0 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
       hipStream_t const s = stream.value();
       auto tmp            = cudf::get_current_device_resource_ref();
       bool const is_signed = class_of(right.column(0).type().id()) == CLS_SINT;
@@ -302,6 +311,7 @@ class hash_join_impl {
     a1.keys         = keys;
     a1.key_width    = _keyw;
     a1.key_signed   = _key_signed ? 1 : 0;
+    a1.key_class    = _key_class;
     a1.keys2        = k2.keys;
     a1.mask2        = k2.mask;
     a1.mask2_offset = k2.mask_offset;
@@ -1084,6 +1094,7 @@ class hash_join_impl {
   bool _key64{false};
   int _keyw{0};             // 8 / 4: one integer key column of that width whose NULLs never match (the partitioned joins); 0: none
   bool _key_signed{false};
+  int32_t _key_class{0};    // CLS_F32 / CLS_F64: the one key column is a float (radix join only: its normalised bits are the key); 0: integer
   bool _pack2{false};       // two 4-byte integer key columns, packed into the radix join's 8-byte key (_keyw == 4)
   double _classic_load{0.5};
   // the open-addressing table in HBM: built by the constructor, or on first need when the build side took the radix partitions

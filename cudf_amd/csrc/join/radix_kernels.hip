@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
           } else {
             t.k[k] = gload(a.keys + row);
           }
+          if (a.key_class != 0) t.k[k] = normalize_key_bits(t.k[k], a.key_class);  // (a float key: equal values, equal bits)
           t.r[k] = a.mask != nullptr ? gload(a.mask + ((a.mask_offset + row) >> 5)) : 0xffffffffu;
           // (a NULL in the second column drops the row as well: the word the later test reads becomes all zeros)
           if (a.mask2 != nullptr && !((gload(a.mask2 + ((a.mask2_offset + row) >> 5)) >> ((a.mask2_offset + row) & 31)) & 1u)) t.r[k] = 0;

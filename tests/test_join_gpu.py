@@ -540,6 +540,29 @@ def force_radix_join(monkeypatch):
     monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_PROBE", "0")
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("kind", ["inner", "left"])
+def test_radix_join_takes_float_keys(G, oracle, force_radix_join, dtype, kind):
+    """One FLOAT key column goes through the LDS radix join as well (round 4): the scatter's key is the value's NORMALISED bits, so
+    -0.0 meets +0.0 and every NaN meets every NaN, as the row equality of the table probes has it (reference
+    row_operator/equality.cuh:59-89)."""
+    rng = np.random.default_rng(5 if dtype == "float64" else 6)
+    nl, nr = 300_000, 40_000
+    npt = np.dtype(dtype)
+    pool = (rng.integers(-30_000, 30_000, 50_000) / 8.0).astype(npt)
+    pool[:6] = [0.0, -0.0, np.nan, np.inf, -np.inf, npt.type(1e-30)]
+    rk = pool[rng.integers(0, len(pool), nr)]
+    rk[:3] = [-0.0, np.nan, 0.0]
+    lk = pool[rng.integers(0, len(pool), nl)]
+    lk[:4] = [0.0, np.array(np.nan).astype(npt).view(np.uint32 if dtype == "float32" else np.uint64).__or__(1).view(npt), -0.0, np.nan]  # a second NaN pattern
+    lk = np.concatenate([lk, (rng.integers(40_000, 90_000, 50_000) / 8.0).astype(npt)])  # keys the build side does not hold
+    (li, ri), kernels = _kernels_of(lambda: G.join([lk], [rk], nulls_equal=True, kind=kind))
+    assert kernels.get("join_partition", 0) >= 2, kernels  # (both sides were radix-partitioned)
+    el, er = oracle.join([lk], [rk], nulls_equal=True, kind=kind)
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
+
+
 def _kernels_of(fn):
     from cudf_amd import _lib
     _lib.profile_reset()
