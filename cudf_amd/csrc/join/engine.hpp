@@ -112,11 +112,17 @@ struct radix_scatter_args {
   uint32_t const* keys2;
   bitmask_type const* mask2;
   int64_t mask2_offset;
+  // kw == 2 (round 4): TWO key columns of 4 or 8 bytes each, any class - the row's key is the pair of their (normalised, zero-extended)
+  // bits, carried as two 8-byte streams (out_key / out_key1); key2 / key2_width / key2_class describe the second column, mask2 its validity
+  int32_t kw;                  // 8-byte words of a key: 1 (default: 0 is read as 1) or 2
+  void const* key2;
+  int32_t key2_width, key2_class;
   bitmask_type const* mask;    // validity of the key column (bit mask_offset + i), nullptr: no NULLs; NULL rows are dropped
   int64_t mask_offset;
   int64_t nrows;
   // level 2: work item (seg, s) reads the level-1 regions (seg, w), w = s, s + slices, ... < in_slices as one virtual row range
   uint64_t const* in_key;
+  uint64_t const* in_key1;     // kw == 2: the second key word
   uint32_t const* in_row;
   int32_t const* in_region_count;
   int64_t in_region_cap;
@@ -124,10 +130,11 @@ struct radix_scatter_args {
   int32_t nseg;
   // both
   int32_t P;          // fan-out: a power of two, 16 ... 256
-  int32_t capl;       // log2 of the ring capacity per partition: P << capl = RADIX_RING_SLOTS
+  int32_t capl;       // log2 of the ring capacity per partition: P << capl = RADIX_RING_SLOTS / kw
   int32_t shift;      // digit = (key hash >> shift) & (P - 1)
   int32_t slices;
   uint64_t* out_key;
+  uint64_t* out_key1;          // kw == 2
   uint32_t* out_row;
   int64_t region_cap; // a multiple of 32 records
   int32_t* region_count;
@@ -142,6 +149,10 @@ struct radix_scatter_args {
 };
 struct radix_join_args {
   uint64_t const* b_key;   // build partitions: regions (q, s), s < b_slices
+  uint64_t const* b_key1;  // kw == 2: the second key word of the build / probe records (p_key1)
+  uint64_t const* p_key1;
+  int32_t kw;              // 1 (0 is read as 1): the table's slot state is the key; 2: the state is a 64-bit hash of the two words, a slot
+                           // points at the build record and every candidate is verified against the partition's records (L2-resident)
   uint32_t const* b_row;
   int32_t const* b_count;
   int64_t b_cap;

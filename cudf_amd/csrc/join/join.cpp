@@ -87,6 +87,24 @@ bool is_two_int32(table_view const& t)
   }
   return true;
 }
+// TWO key columns of 4 or 8 bytes each (integers of any kind, floats), other than the two 4-byte integers is_two_int32 packs into one
+// word: the radix join carries them as two 8-byte key words (round 4)
+bool is_two_word_key(table_view const& t)
+{
+  if (t.num_columns() != 2 || is_two_int32(t)) return false;
+  for (int c = 0; c < 2; ++c) {
+    auto const id  = t.column(c).type().id();
+    auto const cls = class_of(id);
+    auto const w   = size_of_id(id);
+    if (!((cls == CLS_SINT || cls == CLS_UINT || cls == CLS_F32 || cls == CLS_F64) && (w == 4 || w == 8))) return false;
+  }
+  return true;
+}
+int32_t float_class_of(column_view const& c)
+{
+  auto const cls = class_of(c.type().id());
+  return (cls == CLS_F32 || cls == CLS_F64) ? static_cast<int32_t>(cls) : 0;
+}
 uint64_t const* key_bytes(column_view const& c, int width)
 {
   return reinterpret_cast<uint64_t const*>(c.head<uint8_t>() + static_cast<std::size_t>(c.offset()) * static_cast<std::size_t>(width));
@@ -120,7 +138,8 @@ struct dev_scalar {  // one T in device memory, stream ordered
 };
 }  // namespace
 
-struct second_key {  // the second of two packed 4-byte key columns (radix_scatter_args::keys2)
+struct second_key {  // the second key column: of two packed 4-byte columns (radix_scatter_args::keys2) or of a two-word key (key2)
+  int32_t width{0}, cls{0};  // two-word keys
   uint32_t const* keys{nullptr};
   bitmask_type const* mask{nullptr};
   int64_t mask_offset{0};
@@ -151,13 +170,15 @@ class hash_join_impl {
     // (two 4-byte integer key columns: the radix join packs them into its 8-byte key; no dense table for those)
     _pack2        = (!build_check_nulls || _nulls_equal != null_equality::EQUAL) && is_two_int32(right);
     if (_pack2) _keyw = 4;
+    _kw2          = (!build_check_nulls || _nulls_equal != null_equality::EQUAL) && is_two_word_key(right);
+    if (_kw2) _keyw = static_cast<int>(size_of_id(right.column(0).type().id()));
     _key_signed   = _keyw != 0 && class_of(right.column(0).type().id()) == CLS_SINT;
-    _key_class    = (_keyw != 0 && !_pack2 && is_float_key(right)) ? static_cast<int32_t>(class_of(right.column(0).type().id())) : 0;
+    _key_class    = (_keyw != 0 && !_pack2 && (is_float_key(right) || _kw2)) ? float_class_of(right.column(0)) : 0;
     _key64        = key64;
     _classic_load = load_factor;
     // Dense build keys (one 8-byte integer key column, NULLs never match, valid values within a small range): a direct-address
     // table over [min, max] replaces the hash table - see engine.hpp. Decided from the exact minimum / maximum of the build keys.
-    if (_keyw != 0 && !_pack2 && _key_class == 0 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
+    if (_keyw != 0 && !_pack2 && !_kw2 && _key_class == 0 && rows >= static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_DENSE_MIN_ROWS", 1 << 16)) && env_flag("CUDF_AMD_JOIN_DENSE", 1) != 0) {
       hipStream_t const s = stream.value();
       auto tmp            = cudf::get_current_device_resource_ref();
       bool const is_signed = class_of(right.column(0).type().id()) == CLS_SINT;
@@ -267,15 +288,18 @@ class hash_join_impl {
   // (too small or too big for 2048 ... 32768 partitions, a region or a partition that overflows: heavily duplicated keys)
   struct radix_side {
     rmm::device_buffer key1, row1, cnt1, key2, row2, cnt2;
+    rmm::device_buffer key1w, key2w;  // two-word keys: the second word of level 1 / level 2
     int64_t cap2{0};
     int32_t slices2{0};
   };
   second_key second_of(table_view const& t) const
   {
     second_key k2{};
-    if (_pack2) {
+    if (_pack2 || _kw2) {
       auto const& c = t.column(1);
-      k2.keys       = reinterpret_cast<uint32_t const*>(key_bytes(c, 4));
+      k2.width      = _kw2 ? static_cast<int32_t>(size_of_id(c.type().id())) : 0;
+      k2.cls        = _kw2 ? float_class_of(c) : 0;
+      k2.keys       = reinterpret_cast<uint32_t const*>(key_bytes(c, _kw2 ? k2.width : 4));
       k2.mask       = (_has_nulls && c.has_nulls()) ? c.null_mask() : nullptr;
       k2.mask_offset = c.offset();
     }
@@ -298,6 +322,10 @@ class hash_join_impl {
     out.key1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1 * cap1) * 8, s, tmp};
     out.row1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1 * cap1) * 4, s, tmp};
     out.cnt1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1) * 4, s, tmp};
+    if (_kw2) {
+      out.key1w = rmm::device_buffer{static_cast<std::size_t>(P1 * S1 * cap1) * 8, s, tmp};
+      out.key2w = rmm::device_buffer{static_cast<std::size_t>(_rx_nparts * slices2 * cap2) * 8, s, mr2};
+    }
     out.key2 = rmm::device_buffer{static_cast<std::size_t>(_rx_nparts * slices2 * cap2) * 8, s, mr2};
     out.row2 = rmm::device_buffer{static_cast<std::size_t>(_rx_nparts * slices2 * cap2) * 4, s, mr2};
     out.cnt2 = rmm::device_buffer{static_cast<std::size_t>(_rx_nparts * slices2) * 4, s, mr2};
@@ -312,14 +340,20 @@ class hash_join_impl {
     a1.key_width    = _keyw;
     a1.key_signed   = _key_signed ? 1 : 0;
     a1.key_class    = _key_class;
-    a1.keys2        = k2.keys;
+    a1.keys2        = _kw2 ? nullptr : k2.keys;
+    a1.kw           = _kw2 ? 2 : 1;
+    a1.key2         = _kw2 ? static_cast<void const*>(k2.keys) : nullptr;
+    a1.key2_width   = k2.width;
+    a1.key2_class   = k2.cls;
+    a1.out_key1     = _kw2 ? static_cast<uint64_t*>(out.key1w.data()) : nullptr;
     a1.mask2        = k2.mask;
     a1.mask2_offset = k2.mask_offset;
     a1.mask         = mask;
     a1.mask_offset  = mask_offset;
     a1.nrows        = nrows;
     a1.P            = static_cast<int32_t>(P1);
-    a1.capl         = 13 - log2i(P1);
+    int const ring_log2 = _kw2 ? 12 : 13;  // (two-word keys: half as many ring slots, 2048-row tiles)
+    a1.capl         = ring_log2 - log2i(P1);
     a1.shift        = 64 - log2i(P1);
     a1.slices       = static_cast<int32_t>(S1);
     a1.out_key      = static_cast<uint64_t*>(out.key1.data());
@@ -331,13 +365,16 @@ class hash_join_impl {
     join::radix_scatter_args a2{};
     a2.level           = 2;
     a2.in_key          = a1.out_key;
+    a2.kw              = a1.kw;
+    a2.in_key1         = a1.out_key1;
+    a2.out_key1        = _kw2 ? static_cast<uint64_t*>(out.key2w.data()) : nullptr;
     a2.in_row          = a1.out_row;
     a2.in_region_count = a1.region_count;
     a2.in_region_cap   = cap1;
     a2.in_slices       = static_cast<int32_t>(S1);
     a2.nseg            = static_cast<int32_t>(P1);
     a2.P               = static_cast<int32_t>(P2);
-    a2.capl            = 13 - log2i(P2);
+    a2.capl            = ring_log2 - log2i(P2);
     a2.shift           = 64 - log2i(P1) - log2i(P2);
     a2.slices          = static_cast<int32_t>(slices2);
     a2.out_key         = static_cast<uint64_t*>(out.key2.data());
@@ -350,7 +387,8 @@ class hash_join_impl {
     int32_t h_ovf = 0;
     CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     CUDF_HIP_TRY(hipStreamSynchronize(s));
-    out.key1 = rmm::device_buffer{};  // (the first level's regions go back to the pool)
+    out.key1  = rmm::device_buffer{};  // (the first level's regions go back to the pool)
+    out.key1w = rmm::device_buffer{};
     out.row1 = rmm::device_buffer{};
     out.cnt1 = rmm::device_buffer{};
     return h_ovf == 0;
@@ -361,11 +399,11 @@ class hash_join_impl {
     auto const& col     = right.column(0);
     int64_t const rows  = right.num_rows();
     // (two packed columns: the rows with a NULL in either are dropped; their number is at least the larger of the two null counts)
-    int64_t const valid = rows - std::max<int64_t>(col.nullable() ? col.null_count() : 0, (_pack2 && right.column(1).nullable()) ? right.column(1).null_count() : 0);
+    int64_t const valid = rows - std::max<int64_t>(col.nullable() ? col.null_count() : 0, ((_pack2 || _kw2) && right.column(1).nullable()) ? right.column(1).null_count() : 0);
     // partitions: a power of two with at most ~3500 build rows each (LDS tables of 8192 slots: load <= 0.43), 128 x (16 ... 256)
     int64_t const part_rows = std::clamp<int64_t>(env_flag("CUDF_AMD_JOIN_RADIX_PART_ROWS", 3500), 256, 3500);
     int64_t nparts = 2048;
-    while (nparts < 32768 && valid > nparts * part_rows) nparts <<= 1;
+    while (nparts < (_kw2 ? 16384 : 32768) && valid > nparts * part_rows) nparts <<= 1;  // (two-word keys: second-level rings of at least 32 slots)
     if (valid < env_flag("CUDF_AMD_JOIN_RADIX_MIN_BUILD", 3 << 20) || valid > nparts * 3500) return false;
     _rx_nparts = static_cast<int32_t>(nparts);
     hipStream_t const s = stream.value();
@@ -397,11 +435,11 @@ class hash_join_impl {
   {
     auto const& col = left.column(0);
     bool const probe_nulls = _has_nulls && col.has_nulls();
-    bool const second_nulls = _pack2 && _has_nulls && left.num_columns() == 2 && left.column(1).has_nulls();
-    if ((_pack2 ? !is_two_int32(left) : single_int_width(left) != _keyw) || ((probe_nulls || second_nulls) && _nulls_equal == null_equality::EQUAL))
+    bool const second_nulls = (_pack2 || _kw2) && _has_nulls && left.num_columns() == 2 && left.column(1).has_nulls();
+    if ((_kw2 ? !is_two_word_key(left) : _pack2 ? !is_two_int32(left) : single_int_width(left) != _keyw) || ((probe_nulls || second_nulls) && _nulls_equal == null_equality::EQUAL))
       return std::nullopt;
     // (left join of two packed columns with NULLs: the rows dropped for a NULL in either column are not one column's null count)
-    if (left_join && _pack2 && (probe_nulls || second_nulls)) return std::nullopt;
+    if (left_join && (_pack2 || _kw2) && (probe_nulls || second_nulls)) return std::nullopt;
     int64_t const rows  = left.num_rows();
     int64_t const valid = rows - std::max<int64_t>(col.nullable() ? col.null_count() : 0, second_nulls ? left.column(1).null_count() : 0);
     if (rows < env_flag("CUDF_AMD_JOIN_RADIX_MIN_PROBE", 8 << 20) || rows > (int64_t{1} << 31) - 1) return std::nullopt;
@@ -414,6 +452,9 @@ class hash_join_impl {
       d_args{sizeof(join::radix_join_args), s, tmp};
     CUDF_HIP_TRY(hipMemsetAsync(ovf.data(), 0, sizeof(int32_t), s));
     join::radix_join_args a{};
+    a.kw     = _kw2 ? 2 : 1;
+    a.b_key1 = _kw2 ? static_cast<uint64_t const*>(_rx_build.key2w.data()) : nullptr;
+    a.p_key1 = _kw2 ? static_cast<uint64_t const*>(probe.key2w.data()) : nullptr;
     a.b_key = static_cast<uint64_t const*>(_rx_build.key2.data());
     a.b_row = static_cast<uint32_t const*>(_rx_build.row2.data());
     a.b_count = static_cast<int32_t const*>(_rx_build.cnt2.data());
@@ -1095,6 +1136,7 @@ class hash_join_impl {
   int _keyw{0};             // 8 / 4: one integer key column of that width whose NULLs never match (the partitioned joins); 0: none
   bool _key_signed{false};
   int32_t _key_class{0};    // CLS_F32 / CLS_F64: the one key column is a float (radix join only: its normalised bits are the key); 0: integer
+  bool _kw2{false};         // two key columns of 4 / 8 bytes each as a two-word radix key (is_two_word_key)
   bool _pack2{false};       // two 4-byte integer key columns, packed into the radix join's 8-byte key (_keyw == 4)
   double _classic_load{0.5};
   // the open-addressing table in HBM: built by the constructor, or on first need when the build side took the radix partitions

@@ -27,15 +27,23 @@ __global__ void k_store_radix_args(T v, T* dst)
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint64_t radix_hash(uint64_t key) { return mix64(0x9e3779b97f4a7c15ull ^ key); }
+// two-word keys: ONE 64-bit word that stands for the pair in the partition digits and as the LDS table's slot state (every candidate it
+// yields is verified against both words)
+__device__ __forceinline__ uint64_t fold_key(uint64_t k0, uint64_t k1)
+{
+  uint64_t const h1 = mix64(0xc2b2ae3d27d4eb4full ^ k1);
+  return k0 ^ ((h1 << 31) | (h1 >> 33)) ^ 0x165667b19e3779f9ull;
+}
 
 constexpr int RADIX_MAX_REGION_LIST = 256;
 
 // DENSE (level 1 only; the dense direct-address join's partition pass, dense_part_kernels.hip): a row is the ONE 8-byte record
 // {key - dense_lo (32 bits) | row id << 32}, its partition the top bits of that offset (a contiguous slice of the direct-address
 // table); rows whose key lies outside [dense_lo, dense_lo + dense_range) are dropped like NULL rows. No row-id stream.
-template <int LEVEL, int RPT, int D, bool DENSE, int B = 1024>
+template <int LEVEL, int RPT, int D, bool DENSE, int B = 1024, int KW = 1>
 __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* __restrict__ ap)
 {
+  static_assert(KW == 1 || (KW == 2 && !DENSE), "two-word keys: the hash-partitioned (radix) join only");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int s_pending, s_abort, s_rounds;
   __shared__ int32_t s_pre[RADIX_MAX_REGION_LIST + 1];
@@ -45,7 +53,8 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
   uint32_t const CAP = 1u << capl, cmask = CAP - 1u, tcmask = (CAP << 1) - 1u;
   uint32_t const nslots = static_cast<uint32_t>(P) << capl;
   uint64_t* rkey  = reinterpret_cast<uint64_t*>(lds_raw);                        // [P << capl]
-  uint32_t* rrow  = reinterpret_cast<uint32_t*>(rkey + nslots);                   // [P << (capl + 1)] (not DENSE)
+  [[maybe_unused]] uint64_t* rkey1 = rkey + nslots;                               // [P << capl] (KW == 2)
+  uint32_t* rrow  = reinterpret_cast<uint32_t*>(rkey + static_cast<uint32_t>(KW) * nslots);  // [P << (capl + 1)] (not DENSE)
   uint32_t* tail  = rrow + (DENSE ? 0u : 2u * nslots);                            // [P] next virtual position
   uint32_t* limit = tail + P;                                                     // [P] head + CAP as of the last flush
   int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = B >> 6;
@@ -103,6 +112,7 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
   };
   struct tile_regs {
     uint64_t k[RPT];
+    uint64_t k1[KW == 2 ? RPT : 1];  // the second key word
     uint32_t r[RPT];  // level 1: the validity word of the row; level 2: the row id
   };
   auto issue = [&](int64_t tile, tile_regs& t) {
@@ -121,12 +131,18 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
             t.k[k] = gload(a.keys + row);
           }
           if (a.key_class != 0) t.k[k] = normalize_key_bits(t.k[k], a.key_class);  // (a float key: equal values, equal bits)
+          if constexpr (KW == 2) {  // the second column: raw bits zero-extended (equal values have equal bits once floats are normalised)
+            uint64_t b1 = a.key2_width == 4 ? static_cast<uint64_t>(gload(static_cast<uint32_t const*>(a.key2) + row)) : gload(static_cast<uint64_t const*>(a.key2) + row);
+            if (a.key2_class != 0) b1 = normalize_key_bits(b1, a.key2_class);
+            t.k1[k] = b1;
+          }
           t.r[k] = a.mask != nullptr ? gload(a.mask + ((a.mask_offset + row) >> 5)) : 0xffffffffu;
           // (a NULL in the second column drops the row as well: the word the later test reads becomes all zeros)
           if (a.mask2 != nullptr && !((gload(a.mask2 + ((a.mask2_offset + row) >> 5)) >> ((a.mask2_offset + row) & 31)) & 1u)) t.r[k] = 0;
         } else {
           int64_t const ri = record_of(row, reg_hint[k]);
           t.k[k]           = gload(a.in_key + ri);
+          if constexpr (KW == 2) t.k1[k] = gload(a.in_key1 + ri);
           t.r[k]           = gload(a.in_row + ri);
         }
       }
@@ -162,6 +178,11 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
           u64x2 const v      = *reinterpret_cast<u64x2 const*>(rkey + (static_cast<uint32_t>(d) << capl) + (pos & cmask));
           if (q + 1 < mr) gstore(reinterpret_cast<u64x2*>(a.out_key + rbase + pos), v);
           else gstore(a.out_key + rbase + pos, static_cast<uint64_t>(v.x));
+          if constexpr (KW == 2) {
+            u64x2 const v1 = *reinterpret_cast<u64x2 const*>(rkey1 + (static_cast<uint32_t>(d) << capl) + (pos & cmask));
+            if (q + 1 < mr) gstore(reinterpret_cast<u64x2*>(a.out_key1 + rbase + pos), v1);
+            else gstore(a.out_key1 + rbase + pos, static_cast<uint64_t>(v1.x));
+          }
         }
       }
     }
@@ -192,8 +213,9 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
       limit[dmine] = head + CAP;
     }
   };
-  auto put = [&](uint32_t d, uint32_t pos, uint64_t key, uint32_t rowid) {
+  auto put = [&](uint32_t d, uint32_t pos, uint64_t key, [[maybe_unused]] uint64_t key1, uint32_t rowid) {
     rkey[(d << capl) + (pos & cmask)] = key;
+    if constexpr (KW == 2) rkey1[(d << capl) + (pos & cmask)] = key1;
     if constexpr (!DENSE) rrow[(d << (capl + 1)) + (pos & tcmask)] = rowid;
   };
 
@@ -207,11 +229,14 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
       bool keep[RPT];
       uint32_t d[RPT], rowid[RPT];
       uint64_t key[RPT];
+      [[maybe_unused]] uint64_t key1[RPT];
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         int64_t const row = t0 + static_cast<int64_t>(k) * B + threadIdx.x;
         keep[k]           = row < end;
         key[k]            = pre[j].k[k];
+        key1[k]           = 0;
+        if constexpr (KW == 2) key1[k] = pre[j].k1[k];
         if constexpr (LEVEL == 1) {
           rowid[k] = static_cast<uint32_t>(row);
           keep[k]  = keep[k] && ((pre[j].r[k] >> ((a.mask_offset + row) & 31)) & 1u);  // a NULL key joins nothing (UNEQUAL)
@@ -224,7 +249,7 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
           d[k]               = keep[k] ? static_cast<uint32_t>(off >> shift) : 0u;
           key[k]             = off | (static_cast<uint64_t>(rowid[k]) << 32);
         } else {
-          d[k] = keep[k] ? static_cast<uint32_t>(radix_hash(key[k]) >> shift) & pmask : 0u;
+          d[k] = keep[k] ? static_cast<uint32_t>(radix_hash(KW == 2 ? fold_key(key[k], key1[k]) : key[k]) >> shift) & pmask : 0u;
         }
       }
       issue(t0 + D * step, pre[j]);
@@ -244,7 +269,7 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         pend[k] = keep[k] && static_cast<int32_t>(pos[k] - lim[k]) >= 0;
-        if (keep[k] && !pend[k]) put(d[k], pos[k], key[k], rowid[k]);
+        if (keep[k] && !pend[k]) put(d[k], pos[k], key[k], key1[k], rowid[k]);
         any_pend = any_pend || pend[k];
       }
       if (any_pend) s_pending = 1;
@@ -266,7 +291,7 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
         for (int k = 0; k < RPT; ++k) {
           if (pend[k]) {
             if (static_cast<int32_t>(pos[k] - limit[d[k]]) < 0) {
-              put(d[k], pos[k], key[k], rowid[k]);
+              put(d[k], pos[k], key[k], key1[k], rowid[k]);
               pend[k] = false;
             } else {
               any_pend = true;
@@ -318,7 +343,9 @@ constexpr int RJ_RPT = 4;  // probe records a thread loads before it walks the t
 
 // LEFT: a probe record without a partner yields the pair {probe row, JoinNoMatch} (left join; the probe rows the scatter dropped
 // - NULL keys - get theirs from k_radix_null_rows)
-template <bool RETRIEVE, bool LEFT>
+// KW == 2: the slot state is fold_key(k0, k1), rows[] holds the build record's offset inside the partition, and a candidate counts only
+// if both words of the build record (read back from the partition's regions: they were loaded a moment ago, L2) equal the probe's.
+template <bool RETRIEVE, bool LEFT, int KW = 1>
 __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __restrict__ ap)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -379,7 +406,12 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
       bv[s]             = static_cast<int32_t>(threadIdx.x) < cnt;
       if (bv[s]) {
         bk[s] = gload(a.b_key + reg * a.b_cap + threadIdx.x);
-        br[s] = gload(a.b_row + reg * a.b_cap + threadIdx.x);
+        if constexpr (KW == 2) {
+          bk[s] = fold_key(bk[s], gload(a.b_key1 + reg * a.b_cap + threadIdx.x));
+          br[s] = static_cast<uint32_t>(s * a.b_cap + threadIdx.x);  // (the record's offset inside the partition)
+        } else {
+          br[s] = gload(a.b_row + reg * a.b_cap + threadIdx.x);
+        }
       }
     }
   }
@@ -396,7 +428,8 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
     int32_t const cnt  = min(max(a.b_count[reg], 0), static_cast<int32_t>(a.b_cap));
     int64_t const base = reg * a.b_cap;
     for (int32_t i = threadIdx.x + (s < 4 ? B : 0); i < cnt; i += B) {
-      insert(gload(a.b_key + base + i), gload(a.b_row + base + i));
+      if constexpr (KW == 2) insert(fold_key(gload(a.b_key + base + i), gload(a.b_key1 + base + i)), static_cast<uint32_t>(s * a.b_cap + i));
+      else insert(gload(a.b_key + base + i), gload(a.b_row + base + i));
       ++nb;
     }
   }
@@ -437,27 +470,48 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
     if (w0) put(base + __popcll(m0 & below), prow, b0);
     if (w1) put(base + n0 + __popcll(m1 & below), prow, b1);
   };
+  // KW == 2: the build record a slot points at - does it carry these two words? / its row id
+  int64_t const pbase = static_cast<int64_t>(q) * a.b_slices * a.b_cap;
+  [[maybe_unused]] auto verified = [&](uint32_t off, uint64_t k0, uint64_t k1) { return gload(a.b_key + pbase + off) == k0 && gload(a.b_key1 + pbase + off) == k1; };
+  [[maybe_unused]] auto build_row = [&](uint32_t off) { return gload(a.b_row + pbase + off); };
   // one record of every lane the wave-uniform way: pairs are emitted while the chains are walked (any number of matches per row)
-  auto walk_and_emit = [&](bool live, uint64_t key, size_type prow) {
+  auto walk_and_emit = [&](bool live, uint64_t key, [[maybe_unused]] uint64_t k0, [[maybe_unused]] uint64_t k1, size_type prow) {
     bool const special = live && key == RJ_EMPTY;
     bool walking       = live && !special;
-    bool found         = special && nspec != 0;
+    bool found         = KW == 1 && special && nspec != 0;
     uint32_t bkt       = table_hash(key) >> bshift;
     while (__any(walking)) {
       u64x2 pr{RJ_EMPTY, RJ_EMPTY};
       if (walking) pr = *reinterpret_cast<u64x2 const*>(keys + 2u * bkt);
-      bool const w0 = walking && pr.x == key, w1 = walking && pr.x != RJ_EMPTY && pr.y == key;
-      found         = found || w0 || w1;
-      emit2(prow, w0, w0 ? static_cast<size_type>(rows[2u * bkt]) : 0, w1, w1 ? static_cast<size_type>(rows[2u * bkt + 1]) : 0);
+      bool w0 = walking && pr.x == key, w1 = walking && pr.x != RJ_EMPTY && pr.y == key;
+      size_type b0 = w0 ? static_cast<size_type>(rows[2u * bkt]) : 0, b1 = w1 ? static_cast<size_type>(rows[2u * bkt + 1]) : 0;
+      if constexpr (KW == 2) {
+        w0 = w0 && verified(static_cast<uint32_t>(b0), k0, k1);
+        w1 = w1 && verified(static_cast<uint32_t>(b1), k0, k1);
+        b0 = w0 ? static_cast<size_type>(build_row(static_cast<uint32_t>(b0))) : 0;
+        b1 = w1 ? static_cast<size_type>(build_row(static_cast<uint32_t>(b1))) : 0;
+      }
+      found = found || w0 || w1;
+      emit2(prow, w0, b0, w1, b1);
       walking = walking && pr.x != RJ_EMPTY && pr.y != RJ_EMPTY;  // an entry takes the first empty slot of its sequence
       bkt     = (bkt + 1) & bmask;
     }
     if (nspec != 0 && __any(special))
-      for (uint32_t t = 0; t < nspec; ++t) emit2(prow, special, s_spec_rows[t], false, 0);
+      for (uint32_t t = 0; t < nspec; ++t) {
+        if constexpr (KW == 2) {
+          bool const ok = special && verified(static_cast<uint32_t>(s_spec_rows[t]), k0, k1);
+          found         = found || ok;
+          emit2(prow, ok, ok ? static_cast<size_type>(build_row(static_cast<uint32_t>(s_spec_rows[t]))) : 0, false, 0);
+        } else {
+          emit2(prow, special, s_spec_rows[t], false, 0);
+        }
+      }
+    if constexpr (KW == 2) found = found && live;
     if constexpr (LEFT) emit2(prow, live && !found, JoinNoMatch, false, 0);
   };
   struct batch {
     uint64_t k[RJ_RPT];
+    uint64_t k1[KW == 2 ? RJ_RPT : 1];
     uint32_t w[RJ_RPT];
   };
   for (int s = 0; upstream_ok && s < a.p_slices; ++s) {
@@ -470,8 +524,10 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
         int32_t const i = i0 + j * B + static_cast<int32_t>(threadIdx.x);
         t.k[j]          = 0;
         t.w[j]          = 0;
+        if constexpr (KW == 2) t.k1[j] = 0;
         if (i < cnt) {
           t.k[j] = gload(a.p_key + base + i);
+          if constexpr (KW == 2) t.k1[j] = gload(a.p_key1 + base + i);
           t.w[j] = gload(a.p_row + base + i);
         }
       }
@@ -487,6 +543,9 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
       // slot can equal, so that a step needs no branch: a bucket's second slot is taken only after its first, hence "the bucket
       // is full" = "its second slot is not empty", and a key in the second slot implies the first is taken.
       bool live[RJ_RPT];
+      uint64_t hk[RJ_RPT];  // the word the table knows the record by
+#pragma unroll
+      for (int j = 0; j < RJ_RPT; ++j) hk[j] = KW == 2 ? fold_key(cur.k[j], cur.k1[j]) : cur.k[j];
       uint64_t wk[RJ_RPT];
       uint32_t bkt[RJ_RPT], at[RJ_RPT], nmatch[RJ_RPT], mslot[RJ_RPT], brow[RJ_RPT];
       bool slow = false, any_walking = false;
@@ -494,10 +553,10 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
 #pragma unroll
       for (int j = 0; j < RJ_RPT; ++j) {
         live[j]            = i0 + j * B + static_cast<int32_t>(threadIdx.x) < cnt;
-        bool const walking = live[j] && cur.k[j] != RJ_EMPTY;
-        slow               = slow || (live[j] && cur.k[j] == RJ_EMPTY && nspec != 0);
-        wk[j]              = walking ? cur.k[j] : ~RJ_EMPTY;
-        bkt[j]             = table_hash(cur.k[j]) >> bshift;
+        bool const walking = live[j] && hk[j] != RJ_EMPTY;
+        slow               = slow || (live[j] && hk[j] == RJ_EMPTY && nspec != 0);
+        wk[j]              = walking ? hk[j] : ~RJ_EMPTY;
+        bkt[j]             = table_hash(hk[j]) >> bshift;
         at[j]              = walking ? bkt[j] : spare;
         nmatch[j]          = 0;
         mslot[j]           = 0;
@@ -523,6 +582,22 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
       for (int j = 0; j < RJ_RPT; ++j) brow[j] = rows[mslot[j]];  // (meaningful where nmatch == 1)
 #pragma unroll
       for (int j = 0; j < RJ_RPT; ++j) slow = slow || nmatch[j] > 1;
+      if constexpr (KW == 2) {  // the single candidates: both words against the build record, then its row id (loads of all four go out together)
+        uint64_t c0[RJ_RPT], c1[RJ_RPT];
+        uint32_t cr[RJ_RPT];
+#pragma unroll
+        for (int j = 0; j < RJ_RPT; ++j) {
+          uint32_t const off = nmatch[j] == 1 ? brow[j] : 0u;
+          c0[j] = gload(a.b_key + pbase + off);
+          c1[j] = gload(a.b_key1 + pbase + off);
+          cr[j] = gload(a.b_row + pbase + off);
+        }
+#pragma unroll
+        for (int j = 0; j < RJ_RPT; ++j) {
+          if (nmatch[j] == 1 && !(c0[j] == cur.k[j] && c1[j] == cur.k1[j])) nmatch[j] = 0;  // (two keys with one fold: not a match)
+          brow[j] = cr[j];
+        }
+      }
       if (!__any(slow)) {
         // at most one pair per record: one reservation for the wave's pairs of all four records
         unsigned long long m[RJ_RPT];
@@ -549,7 +624,7 @@ __global__ void __launch_bounds__(1024) k_radix_join(radix_join_args const* __re
 #pragma unroll
         for (int j = 0; j < RJ_RPT; ++j) {
           if (i0 + j * B >= cnt) break;  // (uniform)
-          walk_and_emit(live[j], cur.k[j], static_cast<size_type>(cur.w[j] + a.probe_row_base));
+          walk_and_emit(live[j], hk[j], cur.k[j], KW == 2 ? cur.k1[j] : 0, static_cast<size_type>(cur.w[j] + a.probe_row_base));
         }
       }
     }
@@ -639,15 +714,18 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
                "radix join scatter: geometry");
   CUDF_EXPECTS(dense ? (a.level == 1 && (a.P << a.capl) <= 2 * RADIX_RING_SLOTS && a.dense_range <= (uint64_t{1} << 32) &&
                         ((a.dense_range - 1) >> a.shift) < static_cast<uint64_t>(a.P))
-                     : ((a.P << a.capl) == RADIX_RING_SLOTS && a.shift >= 32),
+                     : ((a.P << a.capl) == RADIX_RING_SLOTS / std::max(a.kw, 1) && a.shift >= 32),
                "radix join scatter: geometry");
+  CUDF_EXPECTS(a.kw <= 1 || (a.kw == 2 && !dense && a.out_key1 != nullptr && (a.level == 2 ? a.in_key1 != nullptr : (a.key2 != nullptr && (a.key2_width == 4 || a.key2_width == 8) && a.keys2 == nullptr))),
+               "radix join scatter: two-word keys");
   CUDF_EXPECTS(a.level == 1 || (a.in_slices + a.slices - 1) / a.slices <= RADIX_MAX_REGION_LIST, "radix join scatter: region list too long");
-  std::size_t const lds = static_cast<std::size_t>(a.P << a.capl) * (dense ? 8 : 16) + 2048;
+  std::size_t const lds = static_cast<std::size_t>(a.P << a.capl) * (dense ? 8 : (a.kw == 2 ? 24 : 16)) + 2048;
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     for (void const* fn : {reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false>), reinterpret_cast<void const*>(&k_radix_scatter<2, 4, 2, false>),
                            reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true>), reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true, 512>),
-                           reinterpret_cast<void const*>(&k_radix_scatter<1, 8, 2, true>)}) {
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 8, 2, true>), reinterpret_cast<void const*>(&k_radix_scatter<1, 2, 2, false, 1024, 2>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<2, 2, 2, false, 1024, 2>)}) {
       hipFuncAttributes attr{};
       CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
       CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
@@ -658,6 +736,8 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
   if (dense && a.block == 512) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true, 512>), dim3(a.slices), dim3(512), lds, stream, d_args);
   else if (dense && a.rpt == 8) hipLaunchKernelGGL((k_radix_scatter<1, 8, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else if (dense) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (a.kw == 2 && a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 2, 2, false, 1024, 2>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (a.kw == 2) hipLaunchKernelGGL((k_radix_scatter<2, 2, 2, false, 1024, 2>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
   else if (a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else hipLaunchKernelGGL((k_radix_scatter<2, 4, 2, false>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
@@ -678,7 +758,9 @@ void launch_radix_join(radix_join_args const& a, radix_join_args* d_args, bool r
   static std::once_flag attr_once;
   std::call_once(attr_once, [] {
     for (void const* fn : {reinterpret_cast<void const*>(&k_radix_join<false, false>), reinterpret_cast<void const*>(&k_radix_join<true, false>),
-                           reinterpret_cast<void const*>(&k_radix_join<false, true>), reinterpret_cast<void const*>(&k_radix_join<true, true>)}) {
+                           reinterpret_cast<void const*>(&k_radix_join<false, true>), reinterpret_cast<void const*>(&k_radix_join<true, true>),
+                           reinterpret_cast<void const*>(&k_radix_join<false, false, 2>), reinterpret_cast<void const*>(&k_radix_join<true, false, 2>),
+                           reinterpret_cast<void const*>(&k_radix_join<false, true, 2>), reinterpret_cast<void const*>(&k_radix_join<true, true, 2>)}) {
       hipFuncAttributes attr{};
       CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
       CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
@@ -686,7 +768,16 @@ void launch_radix_join(radix_join_args const& a, radix_join_args* d_args, bool r
   });
   hipLaunchKernelGGL(k_store_radix_args<radix_join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{retrieve ? "join_retrieve" : "join_count", stream};
-  if (a.left != 0) {
+  if (a.kw == 2) {
+    CUDF_EXPECTS(a.b_key1 != nullptr && a.p_key1 != nullptr && static_cast<int64_t>(a.b_slices) * a.b_cap < (int64_t{1} << 31), "radix join: two-word keys");
+    if (a.left != 0) {
+      if (retrieve) hipLaunchKernelGGL((k_radix_join<true, true, 2>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
+      else hipLaunchKernelGGL((k_radix_join<false, true, 2>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
+    } else {
+      if (retrieve) hipLaunchKernelGGL((k_radix_join<true, false, 2>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
+      else hipLaunchKernelGGL((k_radix_join<false, false, 2>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
+    }
+  } else if (a.left != 0) {
     if (retrieve) hipLaunchKernelGGL((k_radix_join<true, true>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
     else hipLaunchKernelGGL((k_radix_join<false, true>), dim3(a.nparts), dim3(1024), lds, stream, d_args);
   } else {

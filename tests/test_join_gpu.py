@@ -563,6 +563,44 @@ def test_radix_join_takes_float_keys(G, oracle, force_radix_join, dtype, kind):
     assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
 
 
+@pytest.mark.parametrize("kind", ["inner", "left"])
+@pytest.mark.parametrize("shape", ["i64_i64", "i64_i32", "f64_i64", "u32_f32", "low_cardinality_first", "nulls_unequal"])
+def test_radix_join_takes_two_key_columns(G, oracle, force_radix_join, shape, kind):
+    """TWO key columns of 4 or 8 bytes each go through the LDS radix join as a two-word key (round 4): the partition digit and the LDS
+    table's slot state are a 64-bit fold of the two words, every candidate is verified against the build record's two words. A first
+    column with a handful of distinct values (all the identity is in the second), duplicated tuples on both sides, 5 % NULLs in either
+    column (UNEQUAL: such rows join nothing; a left join keeps them... on the table path: the radix left join leaves NULLs to it)."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng({"i64_i64": 1, "i64_i32": 2, "f64_i64": 3, "u32_f32": 4, "low_cardinality_first": 5, "nulls_unequal": 6}[shape])
+    nl, nr = 260_000, 50_000
+    t0, t1 = {"i64_i64": ("int64", "int64"), "i64_i32": ("int64", "int32"), "f64_i64": ("float64", "int64"), "u32_f32": ("uint32", "float32"),
+              "low_cardinality_first": ("int64", "int64"), "nulls_unequal": ("int64", "int32")}[shape]
+    card0 = 5 if shape == "low_cardinality_first" else 3_000
+
+    def col(n, card, t):
+        v = rng.integers(0, card, n)
+        if t.startswith("float"):
+            v = v / 4.0 - 100.0
+        elif t.startswith("int"):
+            v = v - card // 2
+        return v.astype(np.dtype(t))
+    pool0, pool1 = col(40_000, card0, t0), col(40_000, 20_000, t1)          # 40K tuples, some of them equal
+    ri, li_ = rng.integers(0, 30_000, nr), rng.integers(0, 40_000, nl)       # the probe side also draws tuples the build side lacks
+    right = [HostColumn(pool0[ri], None, t0), HostColumn(pool1[ri], None, t1)]
+    left = [HostColumn(pool0[li_], None, t0), HostColumn(pool1[li_], None, t1)]
+    nulls_equal = True
+    if shape == "nulls_unequal":
+        nulls_equal = False
+        right = [HostColumn(c.data, rng.random(nr) > 0.05, t) for c, t in zip(right, (t0, t1))]
+        if kind == "inner":
+            left = [HostColumn(c.data, rng.random(nl) > 0.05, t) for c, t in zip(left, (t0, t1))]
+    (li, rj), kernels = _kernels_of(lambda: G.join(left, right, nulls_equal=nulls_equal, kind=kind))
+    assert kernels.get("join_partition", 0) >= 2, kernels  # (both sides were radix-partitioned)
+    el, er = oracle.join(left, right, nulls_equal=nulls_equal, kind=kind)
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, rj) == kat.sorted_pairs(el, er)
+
+
 def _kernels_of(fn):
     from cudf_amd import _lib
     _lib.profile_reset()
