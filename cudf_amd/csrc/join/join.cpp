@@ -837,6 +837,17 @@ class hash_join_impl {
       }
     }
     int const k = kind == join_kind::INNER_JOIN ? 0 : kind == join_kind::LEFT_JOIN ? 1 : 2;
+    // FULL join (round 4): the LEFT join of the partitioned paths (radix partitions, dense unique table) + the build rows nobody
+    // matched - marked from the left join's build indices, appended by the complement kernel of the table path (reference
+    // hash_join.cu full-join complement, join_utils.cu:45-221)
+    if (k == 2 && env_flag("CUDF_AMD_JOIN_FULL_PARTITIONED", 1) != 0) {
+      if (auto r = probe_partitioned_paths(left, 1, stream, cudf::get_current_device_resource_ref(), row_base); r.has_value()) {
+        auto full = full_from_left(std::move(*r), stream, mr);
+        if (output_size.has_value())
+          CUDF_EXPECTS(*output_size == full.first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
+        return full;
+      }
+    }
     if (auto r = probe_partitioned_paths(left, k, stream, mr, row_base); r.has_value()) {
       if (output_size.has_value())
         CUDF_EXPECTS(*output_size == r->first->size(), "hash join: output_size does not match the number of matches", std::invalid_argument);
@@ -846,6 +857,43 @@ class hash_join_impl {
   }
 
  private:
+  // the pairs of a LEFT join + {JoinNoMatch, build row} for every build row that appears in none of them
+  [[nodiscard]] join_index_pair full_from_left(join_index_pair lp, stream_ref stream, rmm::device_async_resource_ref mr) const
+  {
+    hipStream_t const s = stream.value();
+    auto tmp            = cudf::get_current_device_resource_ref();
+    std::size_t const P = lp.first->size(), nr = static_cast<std::size_t>(_right.num_rows());
+    rmm::device_buffer matched{nr, s, tmp};
+    CUDF_HIP_TRY(hipMemsetAsync(matched.data(), 0, nr, s));
+    if (P > 0) join::launch_mark_matched(lp.second->data(), P, static_cast<uint8_t*>(matched.data()), s);
+    rmm::device_uvector<size_type> comp_l{nr, s, tmp}, comp_r{nr, s, tmp};
+    dev_scalar<unsigned long long> cursor{0ull, s};
+    join_args a{};
+    a.build         = _build_dev;
+    a.build_matched = static_cast<uint8_t*>(matched.data());
+    a.total         = cursor.ptr();
+    a.out_probe     = comp_l.data();
+    a.out_build     = comp_r.data();
+    a.out_capacity  = nr;
+    rmm::device_buffer d_args{sizeof(join_args), s, tmp};
+    join::launch_complement(a, static_cast<join_args*>(d_args.data()), s);
+    std::size_t const U = static_cast<std::size_t>(cursor.value());  // (synchronises)
+    CUDF_EXPECTS(P + U <= static_cast<std::size_t>(std::numeric_limits<size_type>::max()),
+                 "Join result exceeds the maximum column size; use the *_join_size API and chunk the probe side.", std::overflow_error);
+    auto out_l = std::make_unique<rmm::device_uvector<size_type>>(P + U, s, mr);
+    auto out_r = std::make_unique<rmm::device_uvector<size_type>>(P + U, s, mr);
+    if (P > 0) {
+      CUDF_HIP_TRY(hipMemcpyAsync(out_l->data(), lp.first->data(), P * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+      CUDF_HIP_TRY(hipMemcpyAsync(out_r->data(), lp.second->data(), P * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+    }
+    if (U > 0) {
+      CUDF_HIP_TRY(hipMemcpyAsync(out_l->data() + P, comp_l.data(), U * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+      CUDF_HIP_TRY(hipMemcpyAsync(out_r->data() + P, comp_r.data(), U * sizeof(size_type), hipMemcpyDeviceToDevice, s));
+    }
+    // (the left join's vectors and the scratch go back to the pool in stream order behind these copies)
+    return join_index_pair{std::move(out_l), std::move(out_r)};
+  }
+
   // ---- round 3: the paths in front of the tables' count / retrieve passes (engine.hpp), in the order they are tried. nullopt: none
   // of them takes this call (kind, key shape, size, a region that overflowed, no room for the scratch).
   std::optional<join_index_pair> probe_partitioned_paths(table_view const& left, int k, stream_ref stream, rmm::device_async_resource_ref mr,

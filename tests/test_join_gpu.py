@@ -988,3 +988,37 @@ def test_join_size_against_a_radix_build_runs_the_count_pass_only(G, oracle, for
     li, _ = hj.inner_join(t)
     assert li.size() == n_inner
     del hj  # (destroyed right behind an unsynchronised probe: the mirror drains the probe stream first)
+
+
+@pytest.mark.parametrize("path", ["radix", "radix_two_columns", "dense"])
+def test_full_join_on_the_partitioned_paths(G, oracle, monkeypatch, path):
+    """FULL joins no longer need the open-addressing table (round 4): the partitioned LEFT join + the build rows that appear in none of
+    its pairs (marked from the build indices, appended by the complement kernel). Sizes agree with full_join_size."""
+    import cudf_amd
+    from cudf_amd.join import HashJoin
+    from cudf_amd.types import NullEquality
+    rng = np.random.default_rng({"radix": 21, "radix_two_columns": 22, "dense": 23}[path])
+    nl, nr = 300_000, 60_000
+    if path == "dense":
+        for k, v in (("MIN_ROWS", "1"), ("ORDERED_MIN_PROBE", "0")):
+            monkeypatch.setenv("CUDF_AMD_JOIN_DENSE_" + k, v)
+        rk = rng.permutation(90_000)[:nr].astype(np.int64) + 5_000
+        lk = rng.integers(0, 120_000, nl, dtype=np.int64)
+        left, right = [lk], [rk]
+    else:
+        monkeypatch.setenv("CUDF_AMD_JOIN_DENSE", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_BUILD", "0")
+        monkeypatch.setenv("CUDF_AMD_JOIN_RADIX_MIN_PROBE", "0")
+        rk = rng.integers(0, 80_000, nr, dtype=np.int64) * 1_000_003      # duplicates on the build side
+        lk = rng.integers(0, 110_000, nl, dtype=np.int64) * 1_000_003
+        left, right = [lk], [rk]
+        if path == "radix_two_columns":
+            left, right = [lk, (lk % 977).astype(np.int32)], [rk, (rk % 977).astype(np.int32)]
+    hj = HashJoin(cudf_amd.Table([G.to_device(c) for c in right]), NullEquality.EQUAL)
+    t = cudf_amd.Table([G.to_device(c) for c in left])
+    (pl, pr), kernels = _kernels_of(lambda: hj.full_join(t))
+    assert kernels.get("join_complement") == 1 and kernels.get("join_build", 0) == 0, kernels  # (no table was built for it)
+    li, ri = pl.to_numpy()[0], pr.to_numpy()[0]
+    el, er = oracle.join(left, right, nulls_equal=True, kind="full")
+    assert len(li) == len(el) == hj.full_join_size(t)
+    assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
