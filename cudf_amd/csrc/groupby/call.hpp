@@ -47,6 +47,7 @@ namespace cudf::groupby::detail {
 // once per process: the test suite flips them between calls of one process (forced paths, shrunken tables).
 struct planner_env {
   int64_t lds_kb, agg_block, big_min_rows, estimate_min_rows, forced_p, s_items, preagg_min_pct, dense_log2p, scatter_block, rpt;
+  int64_t one_table_min_rows, sample_div;
   int64_t dense_nsplit, wc_g, slices, plan_load_pct;  // -1: not set (the default depends on the plan)
   bool dense, dense_composite, dense_one_table, dense_ring, dense_multi, hot, preagg, optimistic, optimistic2, exact, wc, cyclic,
     stamps, debug, no_simple, vec16, trace, collapse_runs;

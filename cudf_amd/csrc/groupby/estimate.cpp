@@ -37,12 +37,12 @@ aggregate_call::aggregate_call(table_view const& keys, null_policy policy, std::
   dense_signed    = p.cols[0].cls == cudf::detail::CLS_SINT;
   // (the dense-key, heavy-hitter and pre-aggregation paths are for big inputs; CUDF_AMD_GB_BIG_MIN_ROWS lets the fuzz tests walk
   // them at sizes a CPU checker can follow)
-  dense_candidate = p.simple && p.KU == 1 && p.narg == 0 && n >= env.big_min_rows && env.dense &&
+  dense_candidate = p.simple && p.KU == 1 && p.narg == 0 && n >= env.one_table_min_rows && env.dense &&
                     (p.NPAY == 1 || (p.NPAY >= 2 && p.NPAY <= RING_MAX_VALUES && env.dense_multi));
   // Composite dense keys: 1-4 integer key columns of any width (rows with a NULL key are dropped: no nullable key under
   // null_policy::INCLUDE), exactly one value column, no ARGMIN / ARGMAX
   dense_composite = !dense_candidate && p.nkeycols <= DENSE_MAX_KEYS && hp.value_cols.size() == 1 && p.narg == 0 &&
-                    hp.keynulls_unit < 0 && n >= env.big_min_rows && env.dense && env.dense_composite;
+                    hp.keynulls_unit < 0 && n >= env.one_table_min_rows && env.dense && env.dense_composite;
   for (int c = 0; c < p.nkeycols && dense_composite; ++c)
     dense_composite = p.cols[c].cls == cudf::detail::CLS_SINT || p.cols[c].cls == cudf::detail::CLS_UINT;
   allow_dense      = dense_candidate || dense_composite;
@@ -62,7 +62,9 @@ void aggregate_call::estimate()
   if (n > ag.fill_limit && !skip_estimate) {
     // 1M sampled rows for big inputs; small inputs sample 1/16 of their rows (at least 64K): the estimate only picks the
     // strategy, and a 1M-row sample costs more than the aggregation of a 1M-row input
-    int64_t const sample = std::min<int64_t>(n, std::clamp<int64_t>(n / 16, int64_t{1} << 16, int64_t{1} << 20));
+    // (round 4 tried n / 64: the 10M-row call 363 -> 340 us, but with 94K sampled rows of 6M a column with 30 % of its rows on 12 keys shows
+    // too few of its cold keys, looks sparse and leaves the dense path - CUDF_AMD_GB_SAMPLE_DIV stays 16)
+    int64_t const sample = std::min<int64_t>(n, std::clamp<int64_t>(n / std::max<int64_t>(env.sample_div, 1), int64_t{1} << 16, int64_t{1} << 20));
     // (linear counting wants the bitmap at a sixteenth of its load: 2^24 bits for the 1M-row sample of a big input, 2^20 for the
     // 64K-row sample of a 1M-row input - whose memset and population count were a 2 MB pass each for nothing)
     int bits_log2 = 16;

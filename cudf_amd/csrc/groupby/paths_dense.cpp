@@ -84,7 +84,8 @@ outcome aggregate_call::try_dense_ring()
 {
   // (heavy hitters in the sample: only the single-level ring scatter of one plain key takes them out of the partition)
   bool const ring_env = env.dense_ring;
-  if (!(allow_dense && env.forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !env.exact)) return outcome::skip;
+  // (below big_min_rows only the one-table path T is tried: the partition passes are for big inputs)
+  if (!(allow_dense && n >= env.big_min_rows && env.forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !env.exact)) return outcome::skip;
   if (dense_candidate && p.NPAY > 1) return ring_env ? try_dense_ring_multi() : outcome::skip;  // one value stream per column
       dense_map dm{};
       bool dense_ok = dense_map_from_sample(dm);
@@ -415,7 +416,7 @@ outcome aggregate_call::try_dense_ring_multi()
 outcome aggregate_call::try_dense_wc()
 {
   bool const ring_env = env.dense_ring;
-  if (!(allow_dense && env.forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !env.exact)) return outcome::skip;
+  if (!(allow_dense && n >= env.big_min_rows && env.forced_p == 0 && (hot_keys.empty() || (dense_candidate && ring_env)) && !env.exact)) return outcome::skip;
   if (dense_candidate && p.NPAY > 1) return outcome::skip;  // (16-byte records carry one value)
       dense_map dm{};
       bool dense_ok = dense_map_from_sample(dm);

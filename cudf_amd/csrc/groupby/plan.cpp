@@ -32,6 +32,9 @@ planner_env planner_env::load()
   e.lds_kb            = env_i64("CUDF_AMD_GB_LDS_KB", 159);  // 160 KiB minus the kernels' static words
   e.agg_block         = env_i64("CUDF_AMD_GB_AGG_BLOCK", 1024);
   e.big_min_rows      = env_i64("CUDF_AMD_GB_BIG_MIN_ROWS", int64_t{1} << 22);
+  e.sample_div        = env_i64("CUDF_AMD_GB_SAMPLE_DIV", 16);
+  // (the one-table path T needs no partition pass: it pays from far fewer rows - 1M rows on 1000 groups 260 -> ~150 us)
+  e.one_table_min_rows = std::min(e.big_min_rows, env_i64("CUDF_AMD_GB_ONE_TABLE_MIN_ROWS", int64_t{1} << 17));
   e.estimate_min_rows = env_i64("CUDF_AMD_GB_ESTIMATE_MIN_ROWS", 1 << 16);
   e.forced_p          = env_i64("CUDF_AMD_GB_P", 0);
   e.s_items           = env_i64("CUDF_AMD_GB_S_ITEMS", 1024);
