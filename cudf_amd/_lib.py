@@ -14,7 +14,24 @@ class ColumnView(C.Structure):
 
 class AggregationRequest(C.Structure):
     _fields_ = [("values", ColumnView), ("kinds", C.POINTER(C.c_int32)), ("num_kinds", C.c_int32),
-                ("params", C.POINTER(C.c_int32))]
+                ("params", C.POINTER(C.c_int32)), ("params2", C.POINTER(C.c_int32)), ("quantiles", C.POINTER(C.c_double)),
+                ("quantile_offsets", C.POINTER(C.c_int32))]
+
+    @classmethod
+    def of(cls, values_view, aggregations, keep):
+        """One request from Aggregation objects; `keep` receives the arrays that must outlive the call."""
+        n = len(aggregations)
+        kinds = (C.c_int32 * max(1, n))(*[int(a.kind()) for a in aggregations])
+        params = (C.c_int32 * max(1, n))(*[a.param(1 if a.kind().name in ("VARIANCE", "STD") else 0) for a in aggregations])
+        params2 = (C.c_int32 * max(1, n))(*[a.param2() for a in aggregations])
+        offs, flat = [0], []
+        for a in aggregations:
+            flat += a.quantiles()
+            offs.append(len(flat))
+        quantiles = (C.c_double * max(1, len(flat)))(*flat)
+        offsets = (C.c_int32 * (n + 1))(*offs)
+        keep += [kinds, params, params2, quantiles, offsets]
+        return cls(values_view, kinds, n, params, params2, quantiles, offsets)
 
 
 # Every symbol declared in include/cudf_amd_c.h: (restype, argtypes)
@@ -81,7 +98,7 @@ SYMBOLS = {
 _lib = None
 
 
-ABI_VERSION = 3  # include/cudf_amd_c.h CUDF_AMD_ABI_VERSION
+ABI_VERSION = 4  # include/cudf_amd_c.h CUDF_AMD_ABI_VERSION
 
 
 def load():

@@ -28,10 +28,29 @@ class Kind(IntEnum):
     NTH_ELEMENT = 19
 
 
+class Interpolation(IntEnum):  # cudf::interpolation (reference cpp/include/cudf/types.hpp:173-180)
+    LINEAR = 0
+    LOWER = 1
+    HIGHER = 2
+    MIDPOINT = 3
+    NEAREST = 4
+    NEAREST_HALF_UP = 5
+
+
 class Aggregation:
-    def __init__(self, kind: Kind, param: int = None):
+    def __init__(self, kind: Kind, param: int = None, param2: int = None, quantiles=None):
         self._kind = Kind(kind)
         self._param = param  # ddof of VARIANCE / STD, n of NTH_ELEMENT (cudf_amd_aggregation_request.params)
+        self._param2 = param2  # null policy of NTH_ELEMENT / NUNIQUE, interpolation of QUANTILE (.params2)
+        self._quantiles = [float(q) for q in quantiles] if quantiles is not None else []
+
+    def param2(self) -> int:
+        if self._param2 is not None:
+            return int(self._param2)
+        return 1 if self._kind == Kind.NTH_ELEMENT else 0  # the factories' defaults (aggregation.hpp:320-367)
+
+    def quantiles(self):
+        return list(self._quantiles)
 
     def kind(self) -> Kind:
         return self._kind
@@ -98,7 +117,16 @@ def argmin():
 
 
 def nth_element(n: int, null_handling: NullPolicy = NullPolicy.INCLUDE):
-    return Aggregation(Kind.NTH_ELEMENT, int(n))
+    return Aggregation(Kind.NTH_ELEMENT, int(n), int(null_handling))
+
+
+def nunique(null_handling: NullPolicy = NullPolicy.EXCLUDE):
+    return Aggregation(Kind.NUNIQUE, None, int(null_handling))
+
+
+def quantile(quantiles, interp: Interpolation = Interpolation.LINEAR):
+    # pylibcudf.aggregation.quantile(quantiles, interp) (aggregation.pyi; cudf::make_quantile_aggregation)
+    return Aggregation(Kind.QUANTILE, None, int(interp), quantiles)
 
 
 def m2():

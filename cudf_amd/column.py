@@ -220,9 +220,11 @@ class Column:
 
 
 class Table:
-    def __init__(self, columns):
+    def __init__(self, columns, ragged=False):
+        """ragged: the columns of one groupby request's results - a QUANTILE aggregation answers groups x quantiles values in one
+        column (reference group_quantiles.cu:84-87), next to columns of one value per group."""
         self._columns = list(columns)
-        if self._columns:
+        if self._columns and not ragged:
             n = self._columns[0].size()
             assert all(c.size() == n for c in self._columns), "Column size mismatch."
 
@@ -240,7 +242,7 @@ class Table:
         return arr
 
     @staticmethod
-    def _from_handle(handle, stream=None) -> "Table":
+    def _from_handle(handle, stream=None, ragged=False) -> "Table":
         lib = _lib.load()
         owner = _TableHandle(handle)
         cols = []
@@ -255,4 +257,4 @@ class Table:
                                        cv.offset, owner, stream=stream))
             cols.append(Column(DataType(TypeId(v.type_id), v.scale), v.size, v.data, v.null_mask, v.null_count,
                                v.offset, owner, children, stream=stream))
-        return Table(cols)
+        return Table(cols, ragged)

@@ -101,8 +101,12 @@ cudf::table_view to_table(cudf_amd_column_view const* cols, int32_t n)
 }
 hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
-std::unique_ptr<cudf::groupby_aggregation> make_agg(int32_t kind, int32_t const* param)
+std::unique_ptr<cudf::groupby_aggregation> make_agg(cudf_amd_aggregation_request const& req, int32_t k)
 {
+  int32_t const kind    = req.kinds[k];
+  int32_t const* param  = req.params ? req.params + k : nullptr;
+  int32_t const* param2 = req.params2 ? req.params2 + k : nullptr;
+  auto const policy     = [&](cudf::null_policy dflt) { return param2 ? (*param2 ? cudf::null_policy::INCLUDE : cudf::null_policy::EXCLUDE) : dflt; };
   using A = cudf::aggregation;
   switch (kind) {
     case A::SUM: return cudf::make_sum_aggregation<cudf::groupby_aggregation>();
@@ -120,7 +124,17 @@ std::unique_ptr<cudf::groupby_aggregation> make_agg(int32_t kind, int32_t const*
     case A::ARGMAX: return cudf::make_argmax_aggregation<cudf::groupby_aggregation>();
     case A::ARGMIN: return cudf::make_argmin_aggregation<cudf::groupby_aggregation>();
     case A::MEDIAN: return cudf::make_median_aggregation<cudf::groupby_aggregation>();
-    case A::NTH_ELEMENT: return cudf::make_nth_element_aggregation<cudf::groupby_aggregation>(param ? *param : 0);
+    case A::NTH_ELEMENT:
+      return cudf::make_nth_element_aggregation<cudf::groupby_aggregation>(param ? *param : 0, policy(cudf::null_policy::INCLUDE));
+    case A::NUNIQUE: return cudf::make_nunique_aggregation<cudf::groupby_aggregation>(policy(cudf::null_policy::EXCLUDE));
+    case A::QUANTILE: {
+      CUDF_EXPECTS(req.quantiles != nullptr && req.quantile_offsets != nullptr, "QUANTILE needs quantiles and quantile_offsets.",
+                   std::invalid_argument);
+      CUDF_EXPECTS(!param2 || (*param2 >= 0 && *param2 <= 5), "QUANTILE: unknown interpolation.", std::invalid_argument);
+      std::vector<double> q(req.quantiles + req.quantile_offsets[k], req.quantiles + req.quantile_offsets[k + 1]);
+      return cudf::make_quantile_aggregation<cudf::groupby_aggregation>(q, param2 ? static_cast<cudf::interpolation>(*param2)
+                                                                                  : cudf::interpolation::LINEAR);
+    }
     default: CUDF_FAIL("Unsupported aggregation kind in the C ABI.", std::invalid_argument);
   }
 }
@@ -131,7 +145,7 @@ extern "C" {
 const char* cudf_amd_last_error(void) { return g_last_error.c_str(); }
 const char* cudf_amd_version(void) { return "cudf_amd 0.3.0 (gfx950; libcudf 26.10 API subset)"; }
 // Bumped whenever a struct layout or the meaning of an argument of this header changes (2: cudf_amd_aggregation_request gained
-// `params`, cudf_amd_hash_partition writes num_partitions + 1 offsets; 3: loopback communicators, shuffle_join).
+// `params`, cudf_amd_hash_partition writes num_partitions + 1 offsets; 3: loopback communicators, shuffle_join; 4: the sort-groupby kinds' parameters).
 int32_t cudf_amd_abi_version(void) { return CUDF_AMD_ABI_VERSION; }
 
 // sizes of the live cudf_amd_malloc allocations: the resource's deallocate takes the size, the C ABI's free does not
@@ -263,7 +277,7 @@ cudf_amd_status cudf_amd_groupby_aggregate(const cudf_amd_column_view* keys, int
     for (int32_t r = 0; r < num_requests; ++r) {
       reqs[r].values = to_view(requests[r].values);
       for (int32_t k = 0; k < requests[r].num_kinds; ++k)
-        reqs[r].aggregations.push_back(make_agg(requests[r].kinds[k], requests[r].params ? requests[r].params + k : nullptr));
+        reqs[r].aggregations.push_back(make_agg(requests[r], k));
     }
     cudf::groupby::groupby gb{kt, include_null_keys ? cudf::null_policy::INCLUDE : cudf::null_policy::EXCLUDE,
                               keys_are_sorted ? cudf::sorted::YES : cudf::sorted::NO};
@@ -575,7 +589,7 @@ cudf_amd_status cudf_amd_shuffle_groupby(cudf_amd_comm_t comm, const cudf_amd_co
     for (int32_t r = 0; r < num_requests; ++r) {
       reqs[r].values = to_view(requests[r].values);
       for (int32_t k = 0; k < requests[r].num_kinds; ++k)
-        reqs[r].aggregations.push_back(make_agg(requests[r].kinds[k], requests[r].params ? requests[r].params + k : nullptr));
+        reqs[r].aggregations.push_back(make_agg(requests[r], k));
     }
     auto [ukeys, results] = cudf::distributed::shuffle_groupby(
       kt, reqs, *comm->comm, include_null_keys ? cudf::null_policy::INCLUDE : cudf::null_policy::EXCLUDE, cudf::stream_ref{as_stream(stream)});
@@ -603,7 +617,7 @@ cudf_amd_status cudf_amd_combine_groupby(cudf_amd_comm_t comm, const cudf_amd_co
     for (int32_t r = 0; r < num_requests; ++r) {
       reqs[r].values = to_view(requests[r].values);
       for (int32_t k = 0; k < requests[r].num_kinds; ++k)
-        reqs[r].aggregations.push_back(make_agg(requests[r].kinds[k], requests[r].params ? requests[r].params + k : nullptr));
+        reqs[r].aggregations.push_back(make_agg(requests[r], k));
     }
     auto [ukeys, results] = cudf::distributed::combine_groupby(
       kt, reqs, *comm->comm, include_null_keys ? cudf::null_policy::INCLUDE : cudf::null_policy::EXCLUDE, cudf::stream_ref{as_stream(stream)});

@@ -37,6 +37,58 @@ class ddof_aggregation final : public groupby_aggregation, public reduce_aggrega
   [[nodiscard]] std::unique_ptr<aggregation> clone() const override { return std::make_unique<ddof_aggregation>(*this); }
   size_type _ddof;
 };
+// the sort-groupby kinds' descriptors (reference detail/aggregation/aggregation.hpp:269-283, :335-376)
+class nth_element_aggregation final : public groupby_aggregation, public reduce_aggregation {
+ public:
+  nth_element_aggregation(size_type n, null_policy null_handling)
+    : aggregation{aggregation::NTH_ELEMENT}, _n{n}, _null_handling{null_handling}
+  {
+  }
+  [[nodiscard]] bool is_equal(aggregation const& other) const override
+  {
+    auto const* o = dynamic_cast<nth_element_aggregation const*>(&other);
+    return o != nullptr && aggregation::is_equal(other) && o->_n == _n && o->_null_handling == _null_handling;
+  }
+  [[nodiscard]] size_t do_hash() const override
+  {
+    return aggregation::do_hash() ^ std::hash<int>{}(_n) ^ std::hash<int>{}(static_cast<int>(_null_handling));
+  }
+  [[nodiscard]] std::unique_ptr<aggregation> clone() const override { return std::make_unique<nth_element_aggregation>(*this); }
+  size_type _n;
+  null_policy _null_handling;
+};
+class quantile_aggregation final : public groupby_aggregation, public reduce_aggregation {
+ public:
+  quantile_aggregation(std::vector<double> const& q, interpolation i) : aggregation{aggregation::QUANTILE}, _quantiles{q}, _interpolation{i}
+  {
+  }
+  [[nodiscard]] bool is_equal(aggregation const& other) const override
+  {
+    auto const* o = dynamic_cast<quantile_aggregation const*>(&other);
+    return o != nullptr && aggregation::is_equal(other) && o->_interpolation == _interpolation && o->_quantiles == _quantiles;
+  }
+  [[nodiscard]] size_t do_hash() const override
+  {
+    size_t h = aggregation::do_hash() ^ std::hash<int>{}(static_cast<int>(_interpolation));
+    for (double q : _quantiles) h ^= std::hash<double>{}(q) + 0x9e3779b9u + (h << 6) + (h >> 2);
+    return h;
+  }
+  [[nodiscard]] std::unique_ptr<aggregation> clone() const override { return std::make_unique<quantile_aggregation>(*this); }
+  std::vector<double> _quantiles;
+  interpolation _interpolation;
+};
+class nunique_aggregation final : public groupby_aggregation, public reduce_aggregation {
+ public:
+  explicit nunique_aggregation(null_policy null_handling) : aggregation{aggregation::NUNIQUE}, _null_handling{null_handling} {}
+  [[nodiscard]] bool is_equal(aggregation const& other) const override
+  {
+    auto const* o = dynamic_cast<nunique_aggregation const*>(&other);
+    return o != nullptr && aggregation::is_equal(other) && o->_null_handling == _null_handling;
+  }
+  [[nodiscard]] size_t do_hash() const override { return aggregation::do_hash() ^ std::hash<int>{}(static_cast<int>(_null_handling)); }
+  [[nodiscard]] std::unique_ptr<aggregation> clone() const override { return std::make_unique<nunique_aggregation>(*this); }
+  null_policy _null_handling;
+};
 data_type target_type(data_type source, aggregation::Kind k);
 bool is_valid_aggregation(data_type source, aggregation::Kind k);
 }  // namespace cudf::detail
@@ -81,6 +133,17 @@ host_plan build_plan(table_view const& keys, null_policy policy, std::span<aggre
 // Heavy-hitter handling covers plans whose accumulators are SUMs of the single value column and row COUNTs (no nulls).
 bool hot_plan_ok(plan_dev const& p);
 bool is_engine_kind(aggregation::Kind k);
+// MEDIAN / QUANTILE / NUNIQUE / NTH_ELEMENT: served by the sort-based groupby (sort_groupby.hip)
+inline bool is_sort_kind(aggregation::Kind k)
+{
+  return k == aggregation::MEDIAN || k == aggregation::QUANTILE || k == aggregation::NUNIQUE || k == aggregation::NTH_ELEMENT;
+}
+// The sort-based groupby (reference cpp/src/groupby/sort/aggregate.cpp:798-830, sort_helper.cu): radix-sorts the rows by key,
+// labels the groups and serves every request of the call; the unique keys come back in ascending order, nulls last.
+std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> sort_aggregate(table_view const& keys, null_policy include_null_keys,
+                                                                                  bool keys_are_sorted,
+                                                                                  std::span<aggregation_request const> requests,
+                                                                                  stream_ref stream, rmm::device_async_resource_ref mr);
 double hyperloglog_estimate(std::vector<uint32_t> const& regs);
 // Page-locked host staging for a call's small read-backs (per thread; the two buffers stay valid next to each other).
 int32_t* pinned_ints(std::size_t count);

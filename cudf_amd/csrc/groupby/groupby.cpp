@@ -66,8 +66,11 @@ data_type target_type(data_type source, aggregation::Kind k)
     case aggregation::M2:
     case aggregation::VARIANCE:
     case aggregation::STD: return plain_numeric ? data_type{type_id::FLOAT64} : invalid;
-    case aggregation::NTH_ELEMENT:
-    case aggregation::MEDIAN: return source;
+    // sort-groupby kinds (reference detail/aggregation/aggregation.hpp:1015-1049)
+    case aggregation::NTH_ELEMENT: return source;
+    case aggregation::MEDIAN:
+    case aggregation::QUANTILE: return data_type{type_id::FLOAT64};
+    case aggregation::NUNIQUE: return data_type{type_id::INT32};
     default: return invalid;
   }
 }
@@ -134,10 +137,24 @@ std::unique_ptr<Base> make_std_aggregation(size_type ddof)
 template std::unique_ptr<aggregation> make_std_aggregation<aggregation>(size_type);
 template std::unique_ptr<groupby_aggregation> make_std_aggregation<groupby_aggregation>(size_type);
 template <typename Base>
-std::unique_ptr<Base> make_nth_element_aggregation(size_type, null_policy)
+std::unique_ptr<Base> make_nth_element_aggregation(size_type n, null_policy null_handling)
 {
-  return std::make_unique<detail::simple_aggregation>(aggregation::NTH_ELEMENT);
+  return std::make_unique<detail::nth_element_aggregation>(n, null_handling);
 }
+template <typename Base>
+std::unique_ptr<Base> make_quantile_aggregation(std::vector<double> const& quantiles, interpolation interp)
+{
+  return std::make_unique<detail::quantile_aggregation>(quantiles, interp);
+}
+template std::unique_ptr<aggregation> make_quantile_aggregation<aggregation>(std::vector<double> const&, interpolation);
+template std::unique_ptr<groupby_aggregation> make_quantile_aggregation<groupby_aggregation>(std::vector<double> const&, interpolation);
+template <typename Base>
+std::unique_ptr<Base> make_nunique_aggregation(null_policy null_handling)
+{
+  return std::make_unique<detail::nunique_aggregation>(null_handling);
+}
+template std::unique_ptr<aggregation> make_nunique_aggregation<aggregation>(null_policy);
+template std::unique_ptr<groupby_aggregation> make_nunique_aggregation<groupby_aggregation>(null_policy);
 template std::unique_ptr<aggregation> make_nth_element_aggregation<aggregation>(size_type, null_policy);
 template std::unique_ptr<groupby_aggregation> make_nth_element_aggregation<groupby_aggregation>(size_type, null_policy);
 
@@ -181,9 +198,9 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
 {
   CUDF_FUNC_RANGE();  // (reference groupby.cu:224)
   using namespace detail;
-  // keys_are_sorted is a hint with which the reference picks its sort-based path (groupby.cu:64-69); group order is
-  // unspecified either way, so the hash path serves both
-  (void)_keys_are_sorted;
+  // keys_are_sorted alone does not change the dispatch here: the reference takes its sort-based path for pre-sorted keys
+  // (groupby.cu:64-69), but group order is unspecified either way and the hash path serves them faster; the hint is used when
+  // a request needs the sort-based path anyway (no sort of the keys then)
   // reference groupby.cu:225-229
   CUDF_EXPECTS(std::all_of(requests.begin(), requests.end(),
                            [this](auto const& r) { return r.values.size() == _keys.num_rows(); }),
@@ -196,15 +213,22 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
                              });
                            }),
                "Invalid type/aggregation combination.");
+  bool needs_sort = false;
   for (auto const& r : requests)
-    for (auto const& a : r.aggregations)
-      CUDF_EXPECTS(is_engine_kind(a->kind),
-                   "This aggregation needs the sort-based groupby, which this build does not provide.");
-
+    for (auto const& a : r.aggregations) {
+      CUDF_EXPECTS(is_engine_kind(a->kind) || is_sort_kind(a->kind), "Unsupported groupby aggregation on this path.");
+      needs_sort = needs_sort || is_sort_kind(a->kind);
+    }
 
   if (_keys.num_rows() == 0) {
     _last_path = hash_path::NONE;
     return empty_results(_keys, requests);
+  }
+  // one kind without a hash implementation takes the whole call down the sort-based path (reference groupby.cu:64-69,
+  // hash/groupby.cu can_use_hash_groupby)
+  if (needs_sort) {
+    _last_path = hash_path::SORT;
+    return sort_aggregate(_keys, _include_null_keys, _keys_are_sorted == sorted::YES, requests, stream, mr);
   }
   // plan -> estimate -> attempts (one executor per path: call.hpp) -> result columns
   aggregate_call call{_keys, _include_null_keys, requests, stream.value()};

@@ -117,11 +117,7 @@ def shuffle_groupby(comm: Communicator, keys: Table, requests, null_handling=0, 
     requests: cudf_amd.groupby.GroupByRequest list. -> (keys Table, [results Table per request]) of the groups this rank owns."""
     reqs, keep = [], []
     for r in requests:
-        kinds = (C.c_int32 * max(1, len(r._aggregations)))(*[int(a.kind()) for a in r._aggregations])
-        params = (C.c_int32 * max(1, len(r._aggregations)))(*[a.param(1 if a.kind().name in ("VARIANCE", "STD") else 0)
-                                                               for a in r._aggregations])
-        keep += [kinds, params]
-        reqs.append(_lib.AggregationRequest(r._values._view(), kinds, len(r._aggregations), params))
+        reqs.append(_lib.AggregationRequest.of(r._values._view(), r._aggregations, keep))
     rarr = (_lib.AggregationRequest * max(1, len(reqs)))(*reqs)
     out_keys, out_res = C.c_void_p(), C.c_void_p()
     _lib.check(getattr(_lib.load(), _entry)(comm._handle, keys._views(), keys.num_columns(), int(null_handling), rarr,

@@ -14,6 +14,7 @@ class HashPath(IntEnum):
     PARTITIONED_LDS = 2
     GLOBAL_TABLE = 3
     DENSE_DIRECT = 4
+    SORT = 5
 
 
 class GroupByRequest:
@@ -34,11 +35,7 @@ class GroupBy:
         lib = _lib.load()
         reqs, keep = [], []
         for r in requests:
-            kinds = (C.c_int32 * max(1, len(r._aggregations)))(*[int(a.kind()) for a in r._aggregations])
-            params = (C.c_int32 * max(1, len(r._aggregations)))(*[a.param(1 if a.kind().name in ("VARIANCE", "STD") else 0)
-                                                                   for a in r._aggregations])
-            keep += [kinds, params]
-            reqs.append(_lib.AggregationRequest(r._values._view(), kinds, len(r._aggregations), params))
+            reqs.append(_lib.AggregationRequest.of(r._values._view(), r._aggregations, keep))
         rarr = (_lib.AggregationRequest * max(1, len(reqs)))(*reqs)
         out_keys, out_res, path = C.c_void_p(), C.c_void_p(), C.c_int32(0)
         _lib.check(lib.cudf_amd_groupby_aggregate(self._keys._views(), self._keys.num_columns(),
@@ -47,9 +44,9 @@ class GroupBy:
                                                   C.byref(out_res), C.byref(path)))
         self.last_path = HashPath(path.value)
         keys = Table._from_handle(out_keys, stream)
-        flat = Table._from_handle(out_res, stream).columns()
+        flat = Table._from_handle(out_res, stream, ragged=True).columns()
         results, p = [], 0
         for r in requests:
-            results.append(Table(flat[p:p + len(r._aggregations)]))
+            results.append(Table(flat[p:p + len(r._aggregations)], ragged=True))
             p += len(r._aggregations)
         return keys, results

@@ -1,9 +1,9 @@
 // SPDX-License-Identifier: Apache-2.0
 // Aggregation descriptors for groupby requests. Kind values are numerically identical to the reference
 // (cpp/include/cudf/aggregation.hpp:78-121) because pylibcudf passes them through as ints; factories
-// mirror :212-266. Only the hash-groupby kinds are constructible on this path (SUM, SUM_OVERFLOW, PRODUCT, MIN, MAX,
-// COUNT_VALID, COUNT_ALL, SUM_OF_SQUARES, MEAN, M2, VARIANCE, STD, ARGMAX, ARGMIN); the rest of the enum is
-// kept so that values line up.
+// mirror :212-367. Constructible on this path: the hash-groupby kinds (SUM, SUM_OVERFLOW, PRODUCT, MIN, MAX,
+// COUNT_VALID, COUNT_ALL, SUM_OF_SQUARES, MEAN, M2, VARIANCE, STD, ARGMAX, ARGMIN) and the sort-groupby kinds
+// MEDIAN, QUANTILE, NUNIQUE, NTH_ELEMENT; the rest of the enum is kept so that values line up.
 #pragma once
 #include <cudf/types.hpp>
 #include <cudf/utilities/error.hpp>
@@ -88,11 +88,16 @@ template <typename Base = aggregation> std::unique_ptr<Base> make_variance_aggre
 template <typename Base = aggregation> std::unique_ptr<Base> make_std_aggregation(size_type ddof = 1);
 template <typename Base = aggregation> std::unique_ptr<Base> make_argmax_aggregation();
 template <typename Base = aggregation> std::unique_ptr<Base> make_argmin_aggregation();
-// Kinds that exist in the enum but have no hash implementation (forces the sort path in the reference,
-// cpp/tests/groupby/groupby_test_util.cpp:59-63); constructible so that the dispatch error can be tested.
+// Kinds without a hash implementation: a request holding one takes the whole call down the sort-based groupby
+// (reference cpp/src/groupby/groupby.cu:64-69, cpp/src/groupby/sort/aggregate.cpp:355-440).
 template <typename Base = aggregation>
 std::unique_ptr<Base> make_nth_element_aggregation(size_type n, null_policy null_handling = null_policy::INCLUDE);
 template <typename Base = aggregation> std::unique_ptr<Base> make_median_aggregation();
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_quantile_aggregation(std::vector<double> const& quantiles,
+                                                interpolation interp = interpolation::LINEAR);
+template <typename Base = aggregation>
+std::unique_ptr<Base> make_nunique_aggregation(null_policy null_handling = null_policy::EXCLUDE);
 
 namespace detail {
 // Accumulator/result type of `k` applied to a column of type `source`

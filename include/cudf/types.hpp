@@ -31,6 +31,8 @@ enum class null_order : bool { AFTER, BEFORE };
 enum class sorted : bool { NO, YES };
 enum class mask_state : int32_t { UNALLOCATED, UNINITIALIZED, ALL_VALID, ALL_NULL };
 enum class out_of_bounds_policy : bool { NULLIFY, DONT_CHECK };
+// quantile interpolation between the two neighbouring order statistics (reference types.hpp:173-180)
+enum class interpolation : int32_t { LINEAR, LOWER, HIGHER, MIDPOINT, NEAREST, NEAREST_HALF_UP };
 
 enum class type_id : int32_t {
   EMPTY,

@@ -55,6 +55,14 @@ typedef struct {
   /* one parameter per aggregation, or NULL for the defaults: ddof of VARIANCE / STD (make_variance_aggregation(ddof),
    * aggregation.hpp:259-266; default 1), n of NTH_ELEMENT; ignored by the other kinds */
   const int32_t* params;
+  /* a second parameter per aggregation, or NULL for the defaults: the null_policy of NTH_ELEMENT (default 1 = INCLUDE,
+   * aggregation.hpp:366-367) and of NUNIQUE (default 0 = EXCLUDE, :349), the cudf::interpolation of QUANTILE (default 0 = LINEAR,
+   * :320-321; types.hpp:173-180) */
+  const int32_t* params2;
+  /* QUANTILE: aggregation k asks for quantiles[quantile_offsets[k] .. quantile_offsets[k + 1]) (num_kinds + 1 offsets); both NULL
+   * when the request holds no QUANTILE. Its result column holds groups x quantiles values, group-major (group_quantiles.cu:84-87) */
+  const double* quantiles;
+  const int32_t* quantile_offsets;
 } cudf_amd_aggregation_request;
 
 /* Owning cudf::table / vector of cudf::column. */
@@ -66,8 +74,9 @@ const char* cudf_amd_last_error(void);
 const char* cudf_amd_version(void);
 /* ABI number of this header: bumped whenever a struct layout or the meaning of an argument changes, so that a consumer built
  * against an older header can refuse to run. 2: cudf_amd_aggregation_request gained `params`; cudf_amd_hash_partition writes
- * num_partitions + 1 offsets (the reference's current contract). 3: loopback communicators, message limit, shuffle_join. */
-#define CUDF_AMD_ABI_VERSION 3
+ * num_partitions + 1 offsets (the reference's current contract). 3: loopback communicators, message limit, shuffle_join.
+ * 4: cudf_amd_aggregation_request gained `params2`, `quantiles`, `quantile_offsets` (the sort-groupby kinds). */
+#define CUDF_AMD_ABI_VERSION 4
 int32_t cudf_amd_abi_version(void);
 
 /* ---- device memory / stream plumbing for bindings without a device allocator of their own */

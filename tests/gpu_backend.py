@@ -42,11 +42,27 @@ def from_device(col):
 last_path = None
 
 
-def groupby(keys, requests, include_null_keys=False):
+def make_aggregation(k):
+    """A kind name, or the parameterised form of tests/golden/kat_groupby_sort.json / oracle.sort_groupby: {"kind": ..., ...}."""
+    if isinstance(k, str):
+        return _AGG[k]()
+    policy = lambda dflt: NullPolicy.INCLUDE if k.get("null_policy", dflt) == "include" else NullPolicy.EXCLUDE
+    kind = k["kind"]
+    if kind == "nth_element":
+        return agg.nth_element(int(k.get("n", 0)), policy("include"))
+    if kind == "nunique":
+        return agg.nunique(policy("exclude"))
+    if kind == "quantile":
+        return agg.quantile(k["quantiles"], agg.Interpolation[k.get("interpolation", "linear").upper()])
+    return _AGG[kind]()
+
+
+def groupby(keys, requests, include_null_keys=False, keys_are_sorted=False):
     global last_path
+    from cudf_amd.types import Sorted
     kt = cudf_amd.Table([to_device(k) for k in keys])
-    reqs = [gb.GroupByRequest(to_device(v), [_AGG[k]() for k in kinds]) for v, kinds in requests]
-    g = gb.GroupBy(kt, NullPolicy.INCLUDE if include_null_keys else NullPolicy.EXCLUDE)
+    reqs = [gb.GroupByRequest(to_device(v), [make_aggregation(k) for k in kinds]) for v, kinds in requests]
+    g = gb.GroupBy(kt, NullPolicy.INCLUDE if include_null_keys else NullPolicy.EXCLUDE, Sorted.YES if keys_are_sorted else Sorted.NO)
     ukeys, results = g.aggregate(reqs)
     last_path = g.last_path
     return [from_device(c) for c in ukeys.columns()], [[from_device(c) for c in t.columns()] for t in results]

@@ -43,6 +43,8 @@ def host_col(values, type_name, valid=None):
 
 
 def expected_type_id(value_type, agg):
+    if isinstance(agg, dict):  # the sort-groupby kinds (detail/aggregation/aggregation.hpp:1015-1049)
+        return {"nth_element": TYPE_ID[value_type], "nunique": TYPE_ID["int32"]}.get(agg["kind"], TYPE_ID["float64"])
     integral = value_type in ("int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "bool")
     if agg in ("count_valid", "count_all", "argmin", "argmax"):
         return TYPE_ID["int32"]
@@ -177,6 +179,30 @@ def run_groupby_case(backend, c, kt, vt):
     ekc, erc = sort_groups([(ek.data, ek.valid, ek.type_id)], [[(ev_data, ev_valid, exp_tid)]])
     compare_columns(kc[0], ekc[0], "keys")
     compare_columns(rc[0][0], erc[0][0], "values")
+
+
+def sort_groupby_cases():
+    doc = load("kat_groupby_sort.json")
+    for c in doc["cases"]:
+        for kt in c["key_types"]:
+            for vt in c["value_types"]:
+                yield f'{c["name"]}[{kt}-{vt}]', c, kt, vt
+
+
+def run_sort_groupby_case(backend, c, kt, vt):
+    """The kinds only the sort-based groupby serves: its unique keys ascend, so keys and results are compared in place
+    (a QUANTILE result holds groups x quantiles values and could not be permuted with the keys anyway)."""
+    keys = [host_col(c["keys"], kt, c["keys_valid"])]
+    vals = host_col(c["values"], vt, c["values_valid"])
+    kc, rc = backend.groupby(keys, [(vals, [c["agg"]])], include_null_keys=(c["null_policy"] == "include"))
+    ek = host_col(c["expect_keys"], kt, c["expect_keys_valid"])
+    exp_tid = expected_type_id(vt, c["agg"])
+    exp_np = NP_OF_TYPE_ID[exp_tid]
+    ev_data = np.array([_num(v) for v in c["expect"]], dtype=np.float64 if np.dtype(exp_np).kind == "f" else np.int64).astype(exp_np)
+    ev_valid = None if c["expect_valid"] is None else np.array(c["expect_valid"], dtype=bool)
+    ek_data = ek.data.astype(np.bool_) if kt == "bool" else ek.data
+    compare_columns(kc[0], (ek_data, ek.valid, ek.type_id), "keys")
+    compare_columns(rc[0][0], (ev_data, ev_valid, exp_tid), "values")
 
 
 # ---------------------------------------------------------------- joins

@@ -36,5 +36,5 @@ def test_plan_exchange_rejects_a_rank_outside_the_world():
 def test_abi_version_is_reported():
     from cudf_amd import _lib
     lib = _lib.load()
-    assert lib.cudf_amd_abi_version() == 3
+    assert lib.cudf_amd_abi_version() == 4
     assert b"0.3.0" in lib.cudf_amd_version()

@@ -47,8 +47,8 @@ def test_groupby_errors(G):
     from oracle.oracle import HostColumn
     with pytest.raises(CudfAmdError, match="Invalid type/aggregation"):  # groupby.cu:186-201
         G.groupby([K], [(HostColumn(np.arange(3, dtype=np.int64), None, "timestamp_s"), ["sum"])])
-    with pytest.raises(CudfAmdError, match="sort-based"):  # sort-path aggregation: out of scope, fails loudly
-        G.groupby([K], [(K, ["nth_element"])])
+    with pytest.raises(CudfAmdError, match="Only arithmetic types"):  # group_quantiles.cu:125-131
+        G.groupby([K], [(HostColumn(np.arange(3, dtype=np.int64), None, "timestamp_s"), ["median"])])
 
 
 def _check_against_oracle(G, O, keys, requests, include=False, expect_path=None):

@@ -12,6 +12,14 @@ def test_groupby_kat(name, c, kt, vt):
     kat.run_groupby_case(O, c, kt, vt)
 
 
+@pytest.mark.parametrize("name,c,kt,vt", list(kat.sort_groupby_cases()), ids=[x[0] for x in kat.sort_groupby_cases()])
+def test_sort_groupby_kat(name, c, kt, vt):
+    """The kinds only the reference's sort-based groupby serves (oracle/sort_groupby.py against nth_element_tests.cpp,
+    nunique_tests.cpp, median_tests.cpp, quantile_tests.cpp)."""
+    from oracle import sort_groupby as SG
+    kat.run_sort_groupby_case(SG, c, kt, vt)
+
+
 def test_groupby_generated_kats():
     # max_tests.cpp:554-574 — 512 unique keys, keys == values
     k = np.arange(512, dtype=np.int32)
