@@ -26,6 +26,9 @@ def shapes():
     yield "float64 key", [C(lk.to(torch.float64) * 1.5)], [C(rk.to(torch.float64) * 1.5)]
     yield "(int64, int64) keys", [C(lk * 1_000_003), C(lk ^ 0x5bd1e995)], [C(rk * 1_000_003), C(rk ^ 0x5bd1e995)]
     yield "(int64, int32) keys", [C(lk * 1_000_003), C((lk % 1000).to(torch.int32))], [C(rk * 1_000_003), C((rk % 1000).to(torch.int32))]
+    # the same with every probe miss INSIDE the build side's value box (build = even multiples, misses = odd ones): nothing is rejected by range
+    le = torch.where(lk < nr, 2 * lk, 2 * (lk - nr) + 1)
+    yield "(int64, int32) keys, misses in range", [C(le * 1_000_003), C((le % 1000).to(torch.int32))], [C(2 * rk * 1_000_003), C(((2 * rk) % 1000).to(torch.int32))]
 
 
 for name, lcols, rcols in shapes():

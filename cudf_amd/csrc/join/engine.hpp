@@ -117,6 +117,12 @@ struct radix_scatter_args {
   int32_t kw;                  // 8-byte words of a key: 1 (default: 0 is read as 1) or 2
   void const* key2;
   int32_t key2_width, key2_class;
+  // pack != 0 (kw == 1, level 1): two INTEGER key columns (keys / key2) whose build-side ranges fit 63 bits together travel as ONE word,
+  // (c0 - pack_lo0) << pack_bits1 | (c1 - pack_lo1) - a bijection on the build side's value box, so the single-word join is exact. A probe
+  // row outside the box matches nothing: dropped, or (pack_keep_outside: left joins) kept under a word with bit 63 set, which no build
+  // word has. Columns are widened like `keys` (key_signed / key2_signed for 4-byte columns); lo / range are in that 64-bit arithmetic.
+  int32_t pack, pack_bits1, pack_keep_outside, key2_signed;
+  uint64_t pack_lo0, pack_lo1, pack_range0, pack_range1;  // range = max - min
   bitmask_type const* mask;    // validity of the key column (bit mask_offset + i), nullptr: no NULLs; NULL rows are dropped
   int64_t mask_offset;
   int64_t nrows;

@@ -140,6 +140,7 @@ struct dev_scalar {  // one T in device memory, stream ordered
 
 struct second_key {  // the second key column: of two packed 4-byte columns (radix_scatter_args::keys2) or of a two-word key (key2)
   int32_t width{0}, cls{0};  // two-word keys
+  int32_t is_signed{0};
   uint32_t const* keys{nullptr};
   bitmask_type const* mask{nullptr};
   int64_t mask_offset{0};
@@ -173,6 +174,7 @@ class hash_join_impl {
     _kw2          = (!build_check_nulls || _nulls_equal != null_equality::EQUAL) && is_two_word_key(right);
     if (_kw2) _keyw = static_cast<int>(size_of_id(right.column(0).type().id()));
     _key_signed   = _keyw != 0 && class_of(right.column(0).type().id()) == CLS_SINT;
+    if (_kw2) decide_packed_words(right, stream);
     _key_class    = (_keyw != 0 && !_pack2 && (is_float_key(right) || _kw2)) ? float_class_of(right.column(0)) : 0;
     _key64        = key64;
     _classic_load = load_factor;
@@ -284,6 +286,43 @@ class hash_join_impl {
     CUDF_HIP_TRY(hipStreamSynchronize(stream.value()));  // d_args goes out of scope; build is done for probes on any stream
     _classic_built = true;
   }
+  // Two integer key columns whose build-side ranges need at most 63 bits together travel through the radix join as ONE word (engine.hpp
+  // radix_scatter_args::pack): the exact minimum / maximum of both build columns decide (two passes over the build keys, one read-back).
+  void decide_packed_words(table_view const& right, stream_ref stream)
+  {
+    if (env_flag("CUDF_AMD_JOIN_PACK_RANGE", 1) == 0 || right.num_rows() < 2) return;
+    for (int c = 0; c < 2; ++c) {
+      auto const cls = class_of(right.column(c).type().id());
+      if (cls != CLS_SINT && cls != CLS_UINT) return;
+    }
+    hipStream_t const s = stream.value();
+    auto tmp            = cudf::get_current_device_resource_ref();
+    rmm::device_buffer mm{4 * sizeof(uint64_t), s, tmp}, d_args{2 * sizeof(join_args), s, tmp};
+    bool sgn[2];
+    for (int c = 0; c < 2; ++c) {
+      sgn[c]      = class_of(right.column(c).type().id()) == CLS_SINT;
+      join_args a = base_args(right, 0);
+      a.build.col[0] = _build_dev.col[c];
+      join::launch_key_minmax(a, static_cast<join_args*>(d_args.data()) + c, sgn[c] ? 1 : 0, static_cast<uint64_t*>(mm.data()) + 2 * c, s);
+    }
+    uint64_t h[4] = {0, 0, 0, 0};
+    CUDF_HIP_TRY(hipMemcpyAsync(h, mm.data(), sizeof(h), hipMemcpyDeviceToHost, s));
+    CUDF_HIP_TRY(hipStreamSynchronize(s));
+    int bits[2];
+    for (int c = 0; c < 2; ++c) {
+      bool const any_valid = sgn[c] ? static_cast<int64_t>(h[2 * c]) <= static_cast<int64_t>(h[2 * c + 1]) : h[2 * c] <= h[2 * c + 1];
+      if (!any_valid) return;
+      uint64_t const range = h[2 * c + 1] - h[2 * c];
+      bits[c]              = 0;
+      while (bits[c] < 64 && (range >> bits[c]) != 0) ++bits[c];
+    }
+    if (bits[0] + bits[1] > 63) return;
+    _kw2_packed = true;
+    _pk_lo[0] = h[0], _pk_lo[1] = h[2];
+    _pk_range[0] = h[1] - h[0], _pk_range[1] = h[3] - h[2];
+    _pk_bits1 = bits[1];
+  }
+  [[nodiscard]] bool two_words() const { return _kw2 && !_kw2_packed; }
   // ---- LDS radix join, build side (engine.hpp): two ring-scatter levels of {key, row id}; false if the build side does not take it
   // (too small or too big for 2048 ... 32768 partitions, a region or a partition that overflows: heavily duplicated keys)
   struct radix_side {
@@ -299,6 +338,7 @@ class hash_join_impl {
       auto const& c = t.column(1);
       k2.width      = _kw2 ? static_cast<int32_t>(size_of_id(c.type().id())) : 0;
       k2.cls        = _kw2 ? float_class_of(c) : 0;
+      k2.is_signed  = class_of(c.type().id()) == CLS_SINT ? 1 : 0;
       k2.keys       = reinterpret_cast<uint32_t const*>(key_bytes(c, _kw2 ? k2.width : 4));
       k2.mask       = (_has_nulls && c.has_nulls()) ? c.null_mask() : nullptr;
       k2.mask_offset = c.offset();
@@ -306,7 +346,7 @@ class hash_join_impl {
     return k2;
   }
   bool radix_partition(uint64_t const* keys, bitmask_type const* mask, int64_t mask_offset, int64_t nrows, int64_t valid_rows, radix_side& out,
-                       stream_ref stream, rmm::device_async_resource_ref mr2, second_key k2) const
+                       stream_ref stream, rmm::device_async_resource_ref mr2, second_key k2, bool keep_outside = false) const
   {
     hipStream_t const s = stream.value();
     auto tmp            = cudf::get_current_device_resource_ref();
@@ -322,7 +362,7 @@ class hash_join_impl {
     out.key1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1 * cap1) * 8, s, tmp};
     out.row1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1 * cap1) * 4, s, tmp};
     out.cnt1 = rmm::device_buffer{static_cast<std::size_t>(P1 * S1) * 4, s, tmp};
-    if (_kw2) {
+    if (two_words()) {
       out.key1w = rmm::device_buffer{static_cast<std::size_t>(P1 * S1 * cap1) * 8, s, tmp};
       out.key2w = rmm::device_buffer{static_cast<std::size_t>(_rx_nparts * slices2 * cap2) * 8, s, mr2};
     }
@@ -341,18 +381,26 @@ class hash_join_impl {
     a1.key_signed   = _key_signed ? 1 : 0;
     a1.key_class    = _key_class;
     a1.keys2        = _kw2 ? nullptr : k2.keys;
-    a1.kw           = _kw2 ? 2 : 1;
+    a1.kw           = two_words() ? 2 : 1;
     a1.key2         = _kw2 ? static_cast<void const*>(k2.keys) : nullptr;
     a1.key2_width   = k2.width;
     a1.key2_class   = k2.cls;
-    a1.out_key1     = _kw2 ? static_cast<uint64_t*>(out.key1w.data()) : nullptr;
+    a1.out_key1     = two_words() ? static_cast<uint64_t*>(out.key1w.data()) : nullptr;
+    if (_kw2_packed) {
+      a1.pack              = 1;
+      a1.pack_bits1        = _pk_bits1;
+      a1.pack_keep_outside = keep_outside ? 1 : 0;
+      a1.key2_signed       = k2.is_signed;
+      a1.pack_lo0 = _pk_lo[0], a1.pack_lo1 = _pk_lo[1];
+      a1.pack_range0 = _pk_range[0], a1.pack_range1 = _pk_range[1];
+    }
     a1.mask2        = k2.mask;
     a1.mask2_offset = k2.mask_offset;
     a1.mask         = mask;
     a1.mask_offset  = mask_offset;
     a1.nrows        = nrows;
     a1.P            = static_cast<int32_t>(P1);
-    int const ring_log2 = _kw2 ? 12 : 13;  // (two-word keys: half as many ring slots, 2048-row tiles)
+    int const ring_log2 = two_words() ? 12 : 13;  // (two-word keys: half as many ring slots, 2048-row tiles)
     a1.capl         = ring_log2 - log2i(P1);
     a1.shift        = 64 - log2i(P1);
     a1.slices       = static_cast<int32_t>(S1);
@@ -367,7 +415,7 @@ class hash_join_impl {
     a2.in_key          = a1.out_key;
     a2.kw              = a1.kw;
     a2.in_key1         = a1.out_key1;
-    a2.out_key1        = _kw2 ? static_cast<uint64_t*>(out.key2w.data()) : nullptr;
+    a2.out_key1        = two_words() ? static_cast<uint64_t*>(out.key2w.data()) : nullptr;
     a2.in_row          = a1.out_row;
     a2.in_region_count = a1.region_count;
     a2.in_region_cap   = cap1;
@@ -403,7 +451,7 @@ class hash_join_impl {
     // partitions: a power of two with at most ~3500 build rows each (LDS tables of 8192 slots: load <= 0.43), 128 x (16 ... 256)
     int64_t const part_rows = std::clamp<int64_t>(env_flag("CUDF_AMD_JOIN_RADIX_PART_ROWS", 3500), 256, 3500);
     int64_t nparts = 2048;
-    while (nparts < (_kw2 ? 16384 : 32768) && valid > nparts * part_rows) nparts <<= 1;  // (two-word keys: second-level rings of at least 32 slots)
+    while (nparts < (two_words() ? 16384 : 32768) && valid > nparts * part_rows) nparts <<= 1;  // (two-word keys: second-level rings of at least 32 slots)
     if (valid < env_flag("CUDF_AMD_JOIN_RADIX_MIN_BUILD", 3 << 20) || valid > nparts * 3500) return false;
     _rx_nparts = static_cast<int32_t>(nparts);
     hipStream_t const s = stream.value();
@@ -446,15 +494,15 @@ class hash_join_impl {
     hipStream_t const s = stream.value();
     auto tmp            = cudf::get_current_device_resource_ref();
     radix_side probe;
-    if (!radix_partition(key_bytes(col, _keyw), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, valid, probe, stream, tmp, second_of(left)))
+    if (!radix_partition(key_bytes(col, _keyw), probe_nulls ? col.null_mask() : nullptr, col.offset(), rows, valid, probe, stream, tmp, second_of(left), left_join))
       return std::nullopt;
     rmm::device_buffer counts{(static_cast<std::size_t>(_rx_nparts) + 1) * sizeof(unsigned long long), s, tmp}, ovf{sizeof(int32_t), s, tmp},
       d_args{sizeof(join::radix_join_args), s, tmp};
     CUDF_HIP_TRY(hipMemsetAsync(ovf.data(), 0, sizeof(int32_t), s));
     join::radix_join_args a{};
-    a.kw     = _kw2 ? 2 : 1;
-    a.b_key1 = _kw2 ? static_cast<uint64_t const*>(_rx_build.key2w.data()) : nullptr;
-    a.p_key1 = _kw2 ? static_cast<uint64_t const*>(probe.key2w.data()) : nullptr;
+    a.kw     = two_words() ? 2 : 1;
+    a.b_key1 = two_words() ? static_cast<uint64_t const*>(_rx_build.key2w.data()) : nullptr;
+    a.p_key1 = two_words() ? static_cast<uint64_t const*>(probe.key2w.data()) : nullptr;
     a.b_key = static_cast<uint64_t const*>(_rx_build.key2.data());
     a.b_row = static_cast<uint32_t const*>(_rx_build.row2.data());
     a.b_count = static_cast<int32_t const*>(_rx_build.cnt2.data());
@@ -1185,6 +1233,9 @@ class hash_join_impl {
   bool _key_signed{false};
   int32_t _key_class{0};    // CLS_F32 / CLS_F64: the one key column is a float (radix join only: its normalised bits are the key); 0: integer
   bool _kw2{false};         // two key columns of 4 / 8 bytes each as a two-word radix key (is_two_word_key)
+  bool _kw2_packed{false};  // ... whose build-side ranges fit one word (decide_packed_words): the single-word radix join serves them
+  uint64_t _pk_lo[2]{0, 0}, _pk_range[2]{0, 0};
+  int _pk_bits1{0};
   bool _pack2{false};       // two 4-byte integer key columns, packed into the radix join's 8-byte key (_keyw == 4)
   double _classic_load{0.5};
   // the open-addressing table in HBM: built by the constructor, or on first need when the build side took the radix partitions

@@ -139,6 +139,24 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
           t.r[k] = a.mask != nullptr ? gload(a.mask + ((a.mask_offset + row) >> 5)) : 0xffffffffu;
           // (a NULL in the second column drops the row as well: the word the later test reads becomes all zeros)
           if (a.mask2 != nullptr && !((gload(a.mask2 + ((a.mask2_offset + row) >> 5)) >> ((a.mask2_offset + row) & 31)) & 1u)) t.r[k] = 0;
+          if constexpr (KW == 1 && !DENSE) {
+            if (a.pack != 0) {  // two integer columns inside the build side's value box: one exact word (engine.hpp)
+              uint64_t c1;
+              if (a.key2_width == 4) {
+                uint32_t const k32 = gload(static_cast<uint32_t const*>(a.key2) + row);
+                c1                 = a.key2_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32);
+              } else {
+                c1 = gload(static_cast<uint64_t const*>(a.key2) + row);
+              }
+              uint64_t const d0 = t.k[k] - a.pack_lo0, d1 = c1 - a.pack_lo1;
+              if (d0 <= a.pack_range0 && d1 <= a.pack_range1) {
+                t.k[k] = (d0 << a.pack_bits1) | d1;
+              } else {
+                t.k[k] = 0x8000000000000000ull | (cudf::detail::mix64(static_cast<uint64_t>(row)) >> 1);
+                if (!a.pack_keep_outside) t.r[k] = 0;
+              }
+            }
+          }
         } else {
           int64_t const ri = record_of(row, reg_hint[k]);
           t.k[k]           = gload(a.in_key + ri);

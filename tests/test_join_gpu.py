@@ -563,14 +563,52 @@ def test_radix_join_takes_float_keys(G, oracle, force_radix_join, dtype, kind):
     assert kat.sorted_pairs(li, ri) == kat.sorted_pairs(el, er)
 
 
+@pytest.mark.parametrize("kind", ["inner", "left", "full"])
+@pytest.mark.parametrize("shape", ["narrow_ranges", "signed_narrow_first", "one_value_columns", "wide_second_column"])
+def test_two_integer_key_columns_in_one_word(G, oracle, force_radix_join, shape, kind):
+    """Two INTEGER key columns whose build-side ranges fit 63 bits together go through the single-word radix join as
+    (c0 - lo0) << bits1 | (c1 - lo1) (round 4, join.cpp decide_packed_words): probe rows below / above the build side's value box
+    in either column join nothing (a left / full join keeps them); ranges that do not fit stay on the two-word key."""
+    from oracle.oracle import HostColumn
+    rng = np.random.default_rng({"narrow_ranges": 1, "signed_narrow_first": 2, "one_value_columns": 3, "wide_second_column": 4}[shape])
+    nl, nr = 300_000, 60_000
+    t0, t1 = {"narrow_ranges": ("int64", "int32"), "signed_narrow_first": ("int32", "int64"), "one_value_columns": ("uint32", "int64"),
+              "wide_second_column": ("int64", "int64")}[shape]
+    if shape == "narrow_ranges":
+        r0, r1 = rng.integers(10**12, 10**12 + 5000, nr), rng.integers(-300, 300, nr)
+        l0, l1 = rng.integers(10**12 - 500, 10**12 + 5500, nl), rng.integers(-350, 350, nl)   # outside the box on all four sides
+    elif shape == "signed_narrow_first":
+        r0, r1 = rng.integers(-2**31, -2**31 + 700, nr), rng.integers(-2**40, 2**40, nr) // 2**24 * 2**24
+        l0, l1 = rng.integers(-2**31, -2**31 + 800, nl), rng.integers(-2**40, 2**40, nl) // 2**24 * 2**24
+        l1[:100] = np.iinfo(np.int64).min   # the difference to the box's corner wraps around
+        l1[100:200] = np.iinfo(np.int64).max
+    elif shape == "one_value_columns":
+        r0, r1 = np.full(nr, 4_000_000_000), rng.integers(0, 30_000, nr)   # a column of one value takes no bits
+        l0, l1 = np.where(rng.random(nl) < 0.1, 7, 4_000_000_000), rng.integers(0, 40_000, nl)
+    else:
+        r0, r1 = rng.integers(0, 1000, nr), rng.integers(-2**62, 2**62, nr)   # 10 + 63 bits: two words
+        pick = rng.integers(0, nr, nl)
+        l0, l1 = np.where(rng.random(nl) < 0.5, r0[pick], r0[pick] + 1), r1[pick]
+    right = [HostColumn(r0.astype(np.dtype(t0)), None, t0), HostColumn(r1.astype(np.dtype(t1)), None, t1)]
+    left = [HostColumn(l0.astype(np.dtype(t0)), None, t0), HostColumn(l1.astype(np.dtype(t1)), None, t1)]
+    (li, rj), kernels = _kernels_of(lambda: G.join(left, right, nulls_equal=True, kind=kind))
+    assert kernels.get("join_partition", 0) >= 2, kernels  # (both sides were radix-partitioned)
+    el, er = oracle.join(left, right, nulls_equal=True, kind=kind)
+    assert len(li) == len(el)
+    assert kat.sorted_pairs(li, rj) == kat.sorted_pairs(el, er)
+
+
+@pytest.mark.parametrize("pack", ["one_word_if_it_fits", "two_words"])
 @pytest.mark.parametrize("kind", ["inner", "left"])
 @pytest.mark.parametrize("shape", ["i64_i64", "i64_i32", "f64_i64", "u32_f32", "low_cardinality_first", "nulls_unequal"])
-def test_radix_join_takes_two_key_columns(G, oracle, force_radix_join, shape, kind):
+def test_radix_join_takes_two_key_columns(G, oracle, force_radix_join, monkeypatch, shape, kind, pack):
     """TWO key columns of 4 or 8 bytes each go through the LDS radix join as a two-word key (round 4): the partition digit and the LDS
     table's slot state are a 64-bit fold of the two words, every candidate is verified against the build record's two words. A first
     column with a handful of distinct values (all the identity is in the second), duplicated tuples on both sides, 5 % NULLs in either
     column (UNEQUAL: such rows join nothing; a left join keeps them... on the table path: the radix left join leaves NULLs to it)."""
     from oracle.oracle import HostColumn
+    if pack == "two_words":
+        monkeypatch.setenv("CUDF_AMD_JOIN_PACK_RANGE", "0")  # (integer columns of small ranges would travel as one word)
     rng = np.random.default_rng({"i64_i64": 1, "i64_i32": 2, "f64_i64": 3, "u32_f32": 4, "low_cardinality_first": 5, "nulls_unequal": 6}[shape])
     nl, nr = 260_000, 50_000
     t0, t1 = {"i64_i64": ("int64", "int64"), "i64_i32": ("int64", "int32"), "f64_i64": ("float64", "int64"), "u32_f32": ("uint32", "float32"),
