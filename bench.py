@@ -7,12 +7,13 @@ with 1M groups (configs[1], "C2"), one process per GPU.
 
 A step = one pass of the hot path over one batch of synthetic rows already resident in HBM:
   N == 1: cudf::groupby::groupby(keys).aggregate({values, [SUM, COUNT_VALID]}) through the C ABI.
-  N  > 1: configs[4] ("C5", weak scaling, 1B rows per GPU), hash-partitioned all-to-all in its COMBINER form
-          (`value`) in its LITERAL form, inside the library: cudf::distributed::shuffle_groupby = hash-range partition of the
-          local ROWS by owner rank -> counts by ncclAllGather, rows by ncclSend/ncclRecv over xGMI -> per-GPU groupby. It is
-          bound by the point-to-point xGMI links ((N-1)/N of 16 GB per GPU over N-1 links). The combiner form (per-GPU
-          groupby -> exchange of the <= 1M partial groups -> merge; identical result, xGMI carries MBs) is timed in the
-          same run and reported beside it as `preaggregated_variant`. BENCH_DIST_MODE=preaggregate swaps which is `value`.
+  N  > 1: configs[4] ("C5", weak scaling, 1B rows per GPU). `value` is the LITERAL form of the config, inside the library:
+          cudf::distributed::shuffle_groupby = hash-range partition of the local ROWS by owner rank -> counts by ncclAllGather,
+          rows by ncclSend / ncclRecv over xGMI -> per-GPU groupby. It is bound by the point-to-point xGMI links ((N-1)/N of
+          16 GB per GPU over N-1 links). The COMBINER form (cudf::distributed::combine_groupby: per-GPU groupby -> exchange of
+          the <= 1M partial groups -> merge groupby on the owner; identical result, xGMI carries MBs) is timed in the same run
+          after the primary region and reported beside it as `preaggregated_variant`. BENCH_DIST_MODE=preaggregate swaps
+          which of the two is `value`; BENCH_COMBINER=torch runs the combiner through torch.distributed instead of the library.
 Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events on the launch stream (the library's
 per-kernel profiler); `cpu_baseline` times the CPU oracle (oracle/, test infrastructure) on a bounded sample of the
 same workload on this box's host cores, plus pandas/Arrow on configs[0] (10M rows).

@@ -36,7 +36,7 @@ for name, keys, reqs, kref in shapes:
     cnt = res[-1].columns()[-1].to_torch()
     ok_count = int(cnt.sum()) == n
     ok_groups = uk.num_rows() == int(torch.unique(kref).numel())
-    print(f"{name:45s}: {dt*1e3:8.2f} ms  path {paths[-1]:16s} groups {uk.num_rows():>9} count_sum_ok={ok_count} groups_ok={ok_groups}", flush=True)
+    print(f"{name:45s}: {dt*1e3:8.2f} ms  path {paths[-1]:16s} groups {uk.num_rows():>9} count_sum_ok={ok_count} groups_ok={ok_groups} {prof}", flush=True)
     assert ok_count and ok_groups, name
     del uk, res, cnt
 print("exotic shapes OK")

@@ -106,6 +106,28 @@ int main()
     CHECK(mo[1] == 9 && mo[2] == 19 && mo[3] == 17);
   }
 
+  // a kind without a hash implementation takes the call down the sort-based path (groupby.cu:64-69): keys come back ascending.
+  // median_tests.cpp:33-53, quantile_tests.cpp:132-161 (two quantiles -> groups x 2 values), nth_element_tests.cpp:93-118
+  {
+    std::vector<cudf::groupby::aggregation_request> rs;
+    rs.emplace_back();
+    rs[0].values = vcol;
+    rs[0].aggregations.push_back(cudf::make_median_aggregation<cudf::groupby_aggregation>());
+    rs[0].aggregations.push_back(cudf::make_quantile_aggregation<cudf::groupby_aggregation>({0.25, 0.75}, cudf::interpolation::LINEAR));
+    rs[0].aggregations.push_back(cudf::make_nth_element_aggregation<cudf::groupby_aggregation>(-1));
+    rs[0].aggregations.push_back(cudf::make_nunique_aggregation<cudf::groupby_aggregation>());
+    rs[0].aggregations.push_back(cudf::make_sum_aggregation<cudf::groupby_aggregation>());
+    auto out = gb_obj.aggregate(rs);
+    CHECK(gb_obj.last_path() == cudf::groupby::hash_path::SORT);
+    CHECK((to_host<int32_t>(out.first->view().column(0)) == std::vector<int32_t>{1, 2, 3}));
+    CHECK((to_host<double>(out.second[0].results[0]->view()) == std::vector<double>{3., 4.5, 7.}));
+    CHECK(out.second[0].results[1]->size() == 6);
+    CHECK((to_host<double>(out.second[0].results[1]->view()) == std::vector<double>{1.5, 4.5, 3.25, 6., 4.5, 7.5}));
+    CHECK((to_host<int32_t>(out.second[0].results[2]->view()) == std::vector<int32_t>{6, 9, 8}));
+    CHECK((to_host<int32_t>(out.second[0].results[3]->view()) == std::vector<int32_t>{3, 4, 3}));
+    CHECK((to_host<int64_t>(out.second[0].results[4]->view()) == std::vector<int64_t>{9, 19, 17}));
+  }
+
   // size mismatch -> cudf::logic_error (groupby.cu:225-229)
   {
     dev_vec<int32_t> bad{{1, 2, 3}};
