@@ -556,37 +556,52 @@ __global__ void __launch_bounds__(1024, 4) k_aggregate(agg_args const* __restric
         begin = static_cast<int64_t>(src0 + sidx) * a.src_stride;
         end   = begin + min<int64_t>(max(a.src_count[src0 + sidx], 0), a.src_stride);
       }
-      for (int64_t r = begin + threadIdx.x; r < end; r += blockDim.x) {
-        uint64_t key[KUT];
-        uint64_t pay[PAYT > 0 ? PAYT : 1];
-        uint32_t valvalid;
-        if (!load_row(r, key, pay, valvalid)) continue;
-        int const slot = lds_lookup<KUT>(KU, kmask, st, keys, cap, key, hash_of(key));
-        if (slot < 0) continue;
-        for (int i = 0; i < p.narg; ++i) {
-          int const qv = p.arg[i].valacc, qi = p.arg[i].idxacc;
-          uint64_t v, rowid;
-          if constexpr (INPUT == IN_PARTIAL_RECORDS) {
-            v     = gload(records + r * U + KU + qv);
-            rowid = gload(records + r * U + KU + qi);
-            if (rowid == static_cast<uint64_t>(INT64_MAX)) continue;  // that partial saw no valid row
-          } else {
-            int const vb = p.acc[qi].valid_bit, pw = p.acc[qi].pay;
-            if (vb >= 0 && !((valvalid >> vb) & 1u)) continue;
-            if constexpr (INPUT == IN_COLUMNS) {
-              v     = col_load_acc_bits(p.cols[p.nkeycols + pw], r);
-              rowid = static_cast<uint64_t>(r);
+      // four rows per thread in flight: the loads of all four are issued before the first lookup (one row per iteration left the
+      // sweep waiting for a memory round trip per row: 29 ms of a 41 ms ARGMIN + ARGMAX call at 1B rows, profiles/r4_exotic_shapes.txt)
+      constexpr int SW = 4;
+      for (int64_t r0 = begin + threadIdx.x; r0 < end; r0 += static_cast<int64_t>(SW) * blockDim.x) {
+        uint64_t key[SW][KUT];
+        uint64_t pay[SW][PAYT > 0 ? PAYT : 1];
+        uint32_t valvalid[SW];
+        bool live[SW];
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+          int64_t const r = r0 + static_cast<int64_t>(j) * blockDim.x;
+          live[j]         = r < end && load_row(r, key[j], pay[j], valvalid[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+          if (!live[j]) continue;
+          int64_t const r = r0 + static_cast<int64_t>(j) * blockDim.x;
+          int const slot  = lds_lookup<KUT>(KU, kmask, st, keys, cap, key[j], hash_of(key[j]));
+          if (slot < 0) continue;
+          for (int i = 0; i < p.narg; ++i) {
+            int const qv = p.arg[i].valacc, qi = p.arg[i].idxacc;
+            uint64_t v, rowid = 0;
+            if constexpr (INPUT == IN_PARTIAL_RECORDS) {
+              v     = gload(records + r * U + KU + qv);
+              rowid = gload(records + r * U + KU + qi);
+              if (rowid == static_cast<uint64_t>(INT64_MAX)) continue;  // that partial saw no valid row
             } else {
-              v     = gload(records + r * U + KU + pw);
-              rowid = gload(records + r * U + p.rowid_unit) & 0xffffffffull;
+              int const vb = p.acc[qi].valid_bit, pw = p.acc[qi].pay;
+              if (vb >= 0 && !((valvalid[j] >> vb) & 1u)) continue;
+              if constexpr (INPUT == IN_COLUMNS) {
+                v     = col_load_acc_bits(p.cols[p.nkeycols + pw], r);
+                rowid = static_cast<uint64_t>(r);
+              } else {
+                v = gload(records + r * U + KU + pw);  // (the line load_row just read)
+              }
+            }
+            uint64_t const best = reinterpret_cast<uint64_t const*>(lds_raw + acc_off_rt(qv))[slot];
+            bool const same     = p.arg[i].is_float
+                                    ? __longlong_as_double(static_cast<long long>(v)) == __longlong_as_double(static_cast<long long>(best))
+                                    : v == best;
+            if (same) {
+              // (records: the row id is read only for the few rows that attain the extreme)
+              if constexpr (INPUT != IN_PARTIAL_RECORDS && INPUT != IN_COLUMNS) rowid = gload(records + r * U + p.rowid_unit) & 0xffffffffull;
+              atomicMin(reinterpret_cast<long long*>(lds_raw + acc_off_rt(qi)) + slot, static_cast<long long>(rowid));
             }
           }
-          uint64_t const best = reinterpret_cast<uint64_t const*>(lds_raw + acc_off_rt(qv))[slot];
-          bool const same     = p.arg[i].is_float
-                                  ? __longlong_as_double(static_cast<long long>(v)) == __longlong_as_double(static_cast<long long>(best))
-                                  : v == best;
-          if (same)
-            atomicMin(reinterpret_cast<long long*>(lds_raw + acc_off_rt(qi)) + slot, static_cast<long long>(rowid));
         }
       }
     }

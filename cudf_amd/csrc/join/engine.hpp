@@ -20,29 +20,12 @@ constexpr int BUILD_SKIP_ENTRIES = 1 << 16, BUILD_SKIP_AFTER = 32;
 struct join_args {
   device_table build;
   device_table probe;
-  uint64_t* table;         // capacity slots of slot_words 64-bit words
+  uint64_t* table;         // capacity 8-byte slots {32-bit hash tag | build row}, walked in aligned pairs
   // Build only: BUILD_SKIP_ENTRIES advisory hints {44 hash bits | n}: "the first n steps of this hash's probe sequence are
   // full" (kernels.hip k_build, seq_next). An insert that has walked BUILD_SKIP_AFTER steps looks its hint up and jumps
   // ahead; an insert that ended further than that along its sequence leaves one.
   uint64_t* build_skip;
   uint64_t capacity;
-  // slot_words == 2: the build side is one 8-byte integer key column whose NULLs (if any) are never inserted; the
-  // key sits next to its {tag | row} entry, so a probe reads ONE 16-byte slot instead of the slot and then a
-  // random build-key element
-  int32_t slot_words;
-  // The table is cut into 2^part_bits slices by the TOP bits of the row hash: home slot = part * slice +
-  // (low32(hash) * slice >> 32). A probe side that has been radix-partitioned on the same bits (below) walks one
-  // ~3 MB slice at a time, which stays in the XCD's L2 instead of taking an HBM round trip per probe.
-  int32_t part_bits;
-  uint64_t slice;          // slots per slice (== capacity when part_bits == 0)
-  // Partitioned probe (inner join, single 8-byte key): probe records (key, probe row) in per-(partition,
-  // workgroup) regions written by k_probe_partition; the count / retrieve passes then take one region per workgroup
-  uint64_t* precs;             // 16-byte records
-  int32_t* region_count;       // [nparts * pslices]
-  int64_t region_cap;          // records per region
-  int32_t pslices;             // partition-pass workgroups
-  int32_t partitioned;         // count / retrieve passes iterate regions instead of row chunks
-  int32_t* overflow;           // a region was too small: fall back to the direct probe
   int32_t nulls_equal;     // null_equality::EQUAL
   int32_t check_nulls;     // some key column (either side) has nulls
   int32_t kind;            // 0 inner, 1 left, 2 full
@@ -262,8 +245,6 @@ void launch_dense_build(join_args const& a, join_args* d_args, hipStream_t strea
 // Reference: cuco::static_multiset keeps duplicates as separate entries along the probe sequence (hash_join.cu:62-99).
 std::size_t dense_csr_entries(uint64_t range);
 void launch_dense_csr(join_args const& a, join_args* d_args, int32_t* cursor, uint32_t* tile_sums, hipStream_t stream);
-// probe-side radix partition (write-combining scatter, common/wc_scatter.hpp) into a.precs / a.region_count
-void launch_probe_partition(join_args const& a, join_args* d_args, hipStream_t stream);
 void launch_count(join_args const& a, join_args* d_args, hipStream_t stream);
 // exclusive scan of block_counts in place (block_counts[nblocks] = total pairs)
 void launch_scan(join_args const& a, hipStream_t stream);

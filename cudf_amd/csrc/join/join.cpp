@@ -160,9 +160,8 @@ class hash_join_impl {
     // `load_factor` is the caller's upper bound (reference default 0.5). The probe is bound by random memory requests
     // and a multiset walk ends at the first empty slot: 2.5 slots at load 0.5, 1.4 at 0.25 - so the table is kept
     // at <= 0.25 unless that would take more than 1/8 of the device memory (build_classic).
-    // CUDF_AMD_JOIN_PARTITIONED=1 (experimental): one 8-byte integer key whose NULLs can never
-    // match is stored inline (16-byte slots), big tables are sliced by the top hash bits and big inner-join probe
-    // sides are radix-partitioned on the same bits. Default: 8-byte slots, direct windowed probe.
+    // 8-byte slots {hash tag | row}, direct windowed probe. (The sliced table with inline keys and a radix-partitioned probe side
+    // of rounds 1-3 - CUDF_AMD_JOIN_PARTITIONED - was superseded by the LDS radix join and removed in round 4.)
     bool const build_check_nulls = _has_nulls && cudf::has_nulls(right);
     bool const key64 = is_single64(right) && (!build_check_nulls || _nulls_equal != null_equality::EQUAL);
     // (one 4-byte integer key: only the partitioned joins take it - they widen it in their first scatter level; everything else
@@ -260,23 +259,11 @@ class hash_join_impl {
     uint64_t capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / target_load));
     if (capacity * 8 > (uint64_t{36} << 30)) capacity = static_cast<uint64_t>(std::ceil(static_cast<double>(rows) / _classic_load));
     capacity          = std::clamp<uint64_t>(capacity, rows + 1, (uint64_t{1} << 32) - 2);  // always one empty slot
-    bool const key64  = _key64;
     auto mr           = _mr;
-    _slot_words      = (key64 && env_flag("CUDF_AMD_JOIN_PARTITIONED", 0)) ? 2 : 1;
-    // big inline-key tables are sliced by the top hash bits (~2-4 MB per slice, what one XCD's L2 holds) so that a
-    // radix-partitioned probe side walks one slice at a time
-    _part_bits = 0;
-    if (_slot_words == 2 && capacity * 16 >= (static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_SLICE_MIN_MB", 32)) << 20)) {
-      uint64_t const want = capacity * 16 / (static_cast<uint64_t>(env_flag("CUDF_AMD_JOIN_SLICE_KB", 2048)) << 10);
-      while ((uint64_t{1} << _part_bits) < want && _part_bits < env_flag("CUDF_AMD_JOIN_MAX_PART_BITS", 9)) ++_part_bits;
-      _part_bits = std::max(_part_bits, 3);  // region_of_block deals partitions to the 8 XCDs
-    }
-    uint64_t const P  = std::max<uint64_t>(uint64_t{1} << _part_bits, 2);  // even capacity: 16-byte aligned slot pairs
-    capacity          = std::min<uint64_t>((capacity + P - 1) / P * P, ((uint64_t{1} << 32) - 1) / P * P);
+    capacity          = std::min<uint64_t>((capacity + 1) / 2 * 2, ((uint64_t{1} << 32) - 1) / 2 * 2);  // even: 16-byte aligned slot pairs
     _capacity         = capacity;
-    _slice            = capacity >> _part_bits;
-    _table            = rmm::device_buffer{capacity * sizeof(uint64_t) * _slot_words, stream.value(), mr};
-    CUDF_HIP_TRY(hipMemsetAsync(_table.data(), 0xff, capacity * sizeof(uint64_t) * _slot_words, stream.value()));
+    _table            = rmm::device_buffer{capacity * sizeof(uint64_t), stream.value(), mr};
+    CUDF_HIP_TRY(hipMemsetAsync(_table.data(), 0xff, capacity * sizeof(uint64_t), stream.value()));
     join_args a = base_args(_right, 0);
     rmm::device_buffer d_args{sizeof(join_args), stream.value(), cudf::get_current_device_resource_ref()};
     rmm::device_buffer skip{sizeof(uint64_t) * join::BUILD_SKIP_ENTRIES, stream.value(), cudf::get_current_device_resource_ref()};
@@ -1054,36 +1041,7 @@ class hash_join_impl {
     std::size_t pairs = 0;
     join_args c = base_args(left, k == 0 ? 0 : 1);
     c.probe_row_base = row_base;
-    // Partitioned probe: big inner joins on one 8-byte key first radix-partition the probe keys on the bits that
-    // select the table slice; the count/retrieve passes then take one region per workgroup (see engine.hpp).
-    rmm::device_buffer precs{}, region_count{}, ovf{};
-    if (k == 0 && c.single64 && _part_bits > 0 && left.num_rows() >= env_flag("CUDF_AMD_JOIN_PARTITION_MIN_ROWS", 16 << 20)) {
-      int64_t const P = int64_t{1} << _part_bits, S = 256;
-      double const mean   = static_cast<double>(left.num_rows()) / static_cast<double>(P * S);
-      int64_t const cap_r = (static_cast<int64_t>(mean * 1.25 + 6.0 * std::sqrt(mean) + 16.0) + 7) / 8 * 8;
-      auto const tmp      = cudf::get_current_device_resource_ref();
-      precs        = rmm::device_buffer{static_cast<std::size_t>(P * S * cap_r) * 16, s, tmp};
-      region_count = rmm::device_buffer{static_cast<std::size_t>(P * S) * sizeof(int32_t), s, tmp};
-      ovf          = rmm::device_buffer{sizeof(int32_t), s, tmp};
-      CUDF_HIP_TRY(hipMemsetAsync(ovf.data(), 0, sizeof(int32_t), s));
-      c.precs        = static_cast<uint64_t*>(precs.data());
-      c.region_count = static_cast<int32_t*>(region_count.data());
-      c.region_cap   = cap_r;
-      c.pslices      = static_cast<int32_t>(S);
-      c.overflow     = static_cast<int32_t*>(ovf.data());
-      join::launch_probe_partition(c, static_cast<join_args*>(d_args.data()), s);
-      int32_t h_ovf = 0;
-      CUDF_HIP_TRY(hipMemcpyAsync(&h_ovf, ovf.data(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
-      CUDF_HIP_TRY(hipStreamSynchronize(s));
-      if (h_ovf == 0) {
-        c.partitioned = 1;
-        c.nblocks     = static_cast<int32_t>(8 * S);  // persistent workgroups, see region_of_segment
-      } else {  // heavily repeated probe keys: some region overflowed; probe directly
-        c.precs = nullptr;
-      }
-    }
-    std::size_t const cache_len = c.partitioned ? (std::size_t{1} << _part_bits) * static_cast<std::size_t>(c.pslices) * static_cast<std::size_t>(c.region_cap)
-                                                : static_cast<std::size_t>(left.num_rows());
+    std::size_t const cache_len = static_cast<std::size_t>(left.num_rows());
     rmm::device_buffer counts{(static_cast<std::size_t>(c.nblocks) + 1) * sizeof(unsigned long long), s,
                               cudf::get_current_device_resource_ref()};
     c.block_counts = static_cast<unsigned long long*>(counts.data());
@@ -1167,9 +1125,6 @@ class hash_join_impl {
     a.probe       = make_device_table(probe);
     a.table       = const_cast<uint64_t*>(static_cast<uint64_t const*>(_table.data()));
     a.capacity    = _capacity;
-    a.slot_words  = _slot_words;
-    a.part_bits   = _part_bits;
-    a.slice       = _slice;
     a.nulls_equal = _nulls_equal == null_equality::EQUAL;
     a.check_nulls = _has_nulls && (cudf::has_nulls(_right) || cudf::has_nulls(probe));
     a.kind        = kind;
@@ -1242,9 +1197,6 @@ class hash_join_impl {
   mutable std::mutex _classic_mu;
   mutable bool _classic_built{false};
   mutable uint64_t _capacity{0};
-  mutable int32_t _slot_words{1};
-  mutable int32_t _part_bits{0};
-  mutable uint64_t _slice{0};
   mutable rmm::device_buffer _table{};
   // LDS radix join: the build side in LDS-sized partitions
   bool _radix{false};

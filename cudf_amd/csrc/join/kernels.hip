@@ -2,7 +2,6 @@
 // gfx950 kernels of the hash-join engine (see engine.hpp).
 #include <mutex>
 #include "engine.hpp"
-#include "../common/wc_scatter.hpp"
 #include "../common/profiler.hpp"
 
 #include <cudf/join/join.hpp>
@@ -33,18 +32,7 @@ __device__ __forceinline__ uint64_t hash64_single(uint64_t key) { return mix64(0
 
 __device__ __forceinline__ uint64_t home_slot(uint64_t h, join_args const& a)
 {
-  uint64_t const part = a.part_bits ? (h >> (64 - a.part_bits)) : 0;
-  return part * a.slice + ((static_cast<uint64_t>(static_cast<uint32_t>(h)) * a.slice) >> 32);  // slice < 2^32
-}
-// Partitioned passes run 8 x pslices persistent workgroups. Workgroups are dealt round-robin to the 8 XCDs and
-// pslices (256 = 32 CUs x 8 resident workgroups of 256 lanes) of them fill one XCD: workgroup b = (x, w) walks
-// region w of partitions x, x+8, x+16, ... in that order, so the workgroups of an XCD are all inside the same
-// table slice at (roughly) the same time and its L2 holds ONE slice at a time.
-__device__ __forceinline__ int part_segments(join_args const& a) { return (1 << a.part_bits) >> 3; }
-__device__ __forceinline__ int region_of_segment(join_args const& a, int b, int seg)
-{
-  int const x = b & 7, w = b >> 3;
-  return (seg * 8 + x) * a.pslices + w;
+  return (static_cast<uint64_t>(static_cast<uint32_t>(h)) * a.capacity) >> 32;  // capacity < 2^32
 }
 __device__ __forceinline__ uint64_t make_entry(uint64_t h, int64_t row)
 {
@@ -123,8 +111,8 @@ __global__ void __launch_bounds__(256) k_build(join_args const* __restrict__ ap)
     }
     uint64_t const entry = make_entry(h, i);
     uint64_t const home  = home_slot(h, a);
-    int const sw         = a.slot_words;
-    bool const pairs     = sw == 1;                      // 8-byte slots: a step is an aligned pair of slots
+    constexpr int sw     = 1;
+    constexpr bool pairs = true;                         // 8-byte slots: a step is an aligned pair of slots
     uint64_t const nsteps = pairs ? cap >> 1 : cap;      // (capacity is even)
     uint64_t const st0   = pairs ? home >> 1 : home;
     uint64_t st = st0, stride = 0, slot = home;
@@ -167,72 +155,23 @@ __global__ void __launch_bounds__(256) k_build(join_args const* __restrict__ ap)
       uint64_t const e = __hip_atomic_load(hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((e >> 20 << 20) != hint_tag || (e & 0xfffffull) < n) __hip_atomic_store(hint, hint_tag | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if constexpr (SINGLE64) {
-      if (sw == 2) gstore(a.table + slot * 2 + 1, gload(keys + i));
-    }
   }
 }
 
-// ------------------------------------------------------------------ probe-side radix partition
-// (key, probe row) records of the valid probe keys, partitioned on the hash bits that select the table slice.
-template <int RPT, int G>
-__global__ void __launch_bounds__(1024) k_probe_partition(join_args const* __restrict__ ap)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  join_args const& a = *ap;
-  int const B        = blockDim.x;
-  int64_t const n    = a.probe.nrows;
-  int64_t per        = (n + a.pslices - 1) / a.pslices;
-  per                = (per + 31) & ~int64_t{31};
-  uint64_t const* pkeys          = static_cast<uint64_t const*>(a.probe.col[0].head) + a.probe.col[0].offset;
-  bitmask_type const* probe_mask = a.check_nulls ? a.probe.col[0].mask : nullptr;
-  int64_t const probe_off        = a.probe.col[0].offset;
-  int const shift                = 64 - a.part_bits;
-  wc_scatter_geom g;
-  g.P            = 1 << a.part_bits;
-  g.slices       = a.pslices;
-  g.item         = blockIdx.x;
-  g.begin        = min(n, static_cast<int64_t>(blockIdx.x) * per);
-  g.end          = min(n, g.begin + per);
-  g.step         = 0;
-  g.region_cap   = a.region_cap;
-  g.region_count = a.region_count;
-  g.overflow     = a.overflow;
-  g.out          = a.precs;
-  int64_t const end = g.end;
-  auto load_tile = [&](int64_t tile, uint64_t (&rec)[RPT][2], bool (&keep)[RPT]) {
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      int64_t const r = tile + static_cast<int64_t>(k) * B + threadIdx.x;
-      keep[k]         = r < end;
-      if (keep[k]) {
-        // a NULL probe key matches nothing (null_equality::UNEQUAL on this path) and an inner join drops it
-        if (probe_mask != nullptr) keep[k] = (gload(probe_mask + ((probe_off + r) >> 5)) >> ((probe_off + r) & 31)) & 1u;
-        rec[k][0] = gload(pkeys + r);
-        rec[k][1] = static_cast<uint64_t>(r);
-      }
-    }
-  };
-  auto digit_of = [&](uint64_t const (&rec)[2]) { return static_cast<uint32_t>(hash64_single(rec[0]) >> shift); };
-  wc_scatter_slice<RPT, G, 2, true>(lds_raw, g, load_tile, digit_of);
-}
-
 // ------------------------------------------------------------------ probe: count pass
-// One workgroup per contiguous chunk of probe rows (PART: persistent workgroups over regions of partitioned probe
-// records); R rows per lane with their first loads issued together. Writes the per-row match cache and the
+// One workgroup per contiguous chunk of probe rows; R rows per lane with their first loads issued together. Writes the per-row match cache and the
 // per-workgroup pair count.
 // MODE 0: any key columns (row hash, rows_equal).
 // MODE 1: one 8-byte integer key whose NULLs never match, 8-byte slots {tag | row}: candidates are verified against
 //         the build key column.
-// MODE 2: as 1 with the key stored inline (16-byte slots {tag | row, key}).
 // The pass is bound by the NUMBER of random memory requests (1.2 G requests in 18.6 ms = 66 G/s, the rate the
 // random-load microbenchmark reaches), not by their dependency chains: reading a 64-byte window of slots per row with
 // four 16-byte loads measured SLOWER (21.9 ms). So 8-byte slots are walked in aligned PAIRS - one 16-byte request
 // covers two slots - and the planner keeps the table at load <= 0.25, where a walk to the first empty slot is 1.4
 // slots on average instead of 2.5.
-constexpr int MODE_GENERIC = 0, MODE_KEY64 = 1, MODE_KEY64_INLINE = 2;
+constexpr int MODE_GENERIC = 0, MODE_KEY64 = 1;
 
-template <int MODE, bool PART>
+template <int MODE>
 __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict__ ap)
 {
   join_args const& a = *ap;
@@ -241,29 +180,20 @@ __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict
   int64_t const n    = a.probe.nrows;
   uint64_t const cap = a.capacity;
   int const kind     = a.kind;
-  bool const pairs   = MODE == MODE_KEY64 || (MODE == MODE_GENERIC && a.slot_words == 1);  // 8-byte slots
+  constexpr bool pairs = true;  // 8-byte slots, walked in aligned pairs
   uint64_t const nsteps = pairs ? cap >> 1 : cap;  // 16-byte steps in the table (capacity is even)
   uint64_t const* pkeys = KEY64 ? static_cast<uint64_t const*>(a.probe.col[0].head) + a.probe.col[0].offset : nullptr;
   uint64_t const* bkeys = KEY64 ? static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset : nullptr;
   u64x2 const* table16  = reinterpret_cast<u64x2 const*>(a.table);
-  u64x2 const* precs    = reinterpret_cast<u64x2 const*>(a.precs);
-  bitmask_type const* probe_mask = (KEY64 && !PART && a.check_nulls) ? a.probe.col[0].mask : nullptr;
+  bitmask_type const* probe_mask = (KEY64 && a.check_nulls) ? a.probe.col[0].mask : nullptr;
   int64_t const probe_off        = KEY64 ? a.probe.col[0].offset : 0;
   if (threadIdx.x == 0) s_total = 0;
   __syncthreads();
   constexpr int R = 4;
   unsigned long long local_count = 0;
-  int const nseg = PART ? part_segments(a) : 1;
-  for (int seg = 0; seg < nseg; ++seg) {
-    int64_t begin, end;
-    if constexpr (PART) {
-      int const ri = region_of_segment(a, blockIdx.x, seg);
-      begin        = static_cast<int64_t>(ri) * a.region_cap;
-      end          = begin + a.region_count[ri];
-    } else {
-      begin = static_cast<int64_t>(blockIdx.x) * a.chunk;
-      end   = min(n, begin + a.chunk);
-    }
+  {
+    int64_t const begin = static_cast<int64_t>(blockIdx.x) * a.chunk;
+    int64_t const end   = min(n, begin + a.chunk);
     for (int64_t base = begin; base < end; base += static_cast<int64_t>(blockDim.x) * R) {
       int64_t j[R];
       bool live[R], active[R];
@@ -276,10 +206,7 @@ __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict
         active[k] = live[k];
         h[k] = pkey[k] = 0;
         if (live[k]) {
-          if constexpr (PART) {
-            pkey[k] = gload(reinterpret_cast<uint64_t const*>(precs + j[k]));
-            h[k]    = hash64_single(pkey[k]);
-          } else if constexpr (KEY64) {
+          if constexpr (KEY64) {
             if (probe_mask != nullptr && !((gload(probe_mask + ((probe_off + j[k]) >> 5)) >> ((probe_off + j[k]) & 31)) & 1u)) {
               active[k] = false;  // NULL probe key under null_equality::UNEQUAL matches nothing
             } else {
@@ -306,12 +233,10 @@ __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict
         uint32_t first     = MATCH_NONE;
         unsigned int cnt   = 0;
         // one table entry: false at the first empty slot
-        auto visit = [&](uint64_t ee, uint64_t ek) -> bool {
+        auto visit = [&](uint64_t ee) -> bool {
           if (ee == EMPTY_SLOT) return false;
           bool match = false;
-          if constexpr (MODE == MODE_KEY64_INLINE) {
-            match = ek == pkey[k];
-          } else if (static_cast<uint32_t>(ee >> 32) == tag) {
+          if (static_cast<uint32_t>(ee >> 32) == tag) {
             size_type const brow = static_cast<size_type>(static_cast<uint32_t>(ee));
             if constexpr (MODE == MODE_KEY64) match = gload(bkeys + brow) == pkey[k];
             else match = rows_equal(a.probe, j[k], a.build, brow, a.nulls_equal != 0);
@@ -328,22 +253,16 @@ __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict
           uint32_t ns = 0;                       // step number along the key's probe sequence (seq_next)
           bool skip   = pairs && (slot[k] & 1);  // the home slot is the second of its pair
           for (;;) {
-            if (pairs) {
-              if (!skip && !visit(v.x, 0)) break;
-              skip = false;
-              if (!visit(v.y, 0)) break;
-            } else {
-              if (!visit(v.x, v.y)) break;
-            }
+            if (!skip && !visit(v.x)) break;
+            skip = false;
+            if (!visit(v.y)) break;
             st = seq_next(st, ns, h[k], nsteps, stride, pairs ? slot[k] >> 1 : slot[k]);
             v  = gload(table16 + st);
           }
         }
         gstore(a.match_cache + j[k], cnt > 1 ? (first | MATCH_MULTI) : first);
         unsigned int const emitted = (cnt == 0 && kind != 0) ? 1u : cnt;  // left/full joins emit lonely probe rows once
-        if constexpr (!PART) {
-          if (a.row_counts != nullptr) gstore(a.row_counts + j[k], static_cast<size_type>(emitted));
-        }
+        if (a.row_counts != nullptr) gstore(a.row_counts + j[k], static_cast<size_type>(emitted));
         local_count += emitted;
       }
     }
@@ -359,7 +278,7 @@ __global__ void __launch_bounds__(256) k_probe_count(join_args const* __restrict
 // the table again. Output slots come from a workgroup-local LDS cursor (64-lane ballot + popcount prefix, one LDS
 // atomic per wave and round) on top of the chunk's exclusive offset from the count pass: no global atomics (a
 // single global counter was measured 16x slower than the whole count pass: same-address atomics serialise).
-template <int MODE, bool PART>
+template <int MODE>
 __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restrict__ ap)
 {
   join_args const& a = *ap;
@@ -368,11 +287,9 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
   uint64_t const cap = a.capacity;
   int const kind     = a.kind;
   constexpr bool KEY64 = MODE != MODE_GENERIC;
-  int const sw       = MODE == MODE_KEY64_INLINE ? 2 : (MODE == MODE_KEY64 ? 1 : a.slot_words);
+  constexpr int sw   = 1;
   uint64_t const* pkeys = KEY64 ? static_cast<uint64_t const*>(a.probe.col[0].head) + a.probe.col[0].offset : nullptr;
   uint64_t const* bkeys = KEY64 ? static_cast<uint64_t const*>(a.build.col[0].head) + a.build.col[0].offset : nullptr;
-  u64x2 const* table16  = reinterpret_cast<u64x2 const*>(a.table);
-  u64x2 const* precs    = reinterpret_cast<u64x2 const*>(a.precs);
   if (threadIdx.x == 0) s_cursor = a.block_counts[blockIdx.x];
   __syncthreads();
   int const lane = threadIdx.x & 63;
@@ -394,17 +311,9 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
       if (kind == 2 && brow != JoinNoMatch) gstore(a.build_matched + brow, uint8_t{1});
     }
   };
-  int const nseg = PART ? part_segments(a) : 1;
-  for (int seg = 0; seg < nseg; ++seg) {
-  int64_t begin, end;
-  if constexpr (PART) {
-    int const ri = region_of_segment(a, blockIdx.x, seg);
-    begin        = static_cast<int64_t>(ri) * a.region_cap;
-    end          = begin + a.region_count[ri];
-  } else {
-    begin = static_cast<int64_t>(blockIdx.x) * a.chunk;
-    end   = min(n, begin + a.chunk);
-  }
+  {
+  int64_t const begin = static_cast<int64_t>(blockIdx.x) * a.chunk;
+  int64_t const end   = min(n, begin + a.chunk);
   for (int64_t j0 = begin; j0 < end; j0 += blockDim.x) {  // every lane of a wave iterates together (ballots)
     int64_t const j   = j0 + threadIdx.x;
     bool const live   = j < end;
@@ -413,13 +322,6 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
     bool const multi  = !none && (c & MATCH_MULTI);
     size_type prow    = static_cast<size_type>(j + a.probe_row_base);
     uint64_t pkey     = 0;
-    if constexpr (PART) {
-      if (live && !none) {
-        u64x2 const v = gload(precs + j);
-        pkey          = v.x;
-        prow          = static_cast<size_type>(static_cast<int64_t>(v.y) + a.probe_row_base);
-      }
-    }
     // zero or one match: straight from the cache
     emit(live && !none && !multi, prow, static_cast<size_type>(c & ~MATCH_MULTI));
     if (kind != 0) emit(live && none, prow, JoinNoMatch);
@@ -428,7 +330,7 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
       uint64_t h = 0;
       if (multi) {
         if constexpr (KEY64) {
-          if constexpr (!PART) pkey = gload(pkeys + j);
+          pkey = gload(pkeys + j);
           h = hash64_single(pkey);
         } else {
           h = join_row_hash(a.probe, j, a.check_nulls);
@@ -437,7 +339,7 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
       uint64_t slot      = multi ? home_slot(h, a) : 0;
       uint32_t const tag = static_cast<uint32_t>(h >> 32);
       bool walking       = multi;
-      bool const pairs   = sw == 1;  // the sequence advances in 16-byte steps: aligned pairs of 8-byte slots
+      constexpr bool pairs = true;  // the sequence advances in 16-byte steps: aligned pairs of 8-byte slots
       uint64_t const nsteps = pairs ? cap >> 1 : cap;
       uint64_t const st0 = pairs ? slot >> 1 : slot;
       uint64_t stride    = 0;
@@ -446,21 +348,12 @@ __global__ void __launch_bounds__(256) k_probe_retrieve(join_args const* __restr
         bool match     = false;
         size_type brow = 0;
         if (walking) {
-          uint64_t e, ek = 0;
-          if constexpr (MODE == MODE_KEY64_INLINE) {
-            u64x2 const v = gload(table16 + slot);
-            e             = v.x;
-            ek            = v.y;
-          } else {
-            e = gload(a.table + slot * sw);
-          }
+          uint64_t const e = gload(a.table + slot * sw);
           if (e == EMPTY_SLOT) {
             walking = false;
           } else {
             brow = static_cast<size_type>(static_cast<uint32_t>(e));
-            if constexpr (MODE == MODE_KEY64_INLINE) {
-              match = ek == pkey;
-            } else if (static_cast<uint32_t>(e >> 32) == tag) {
+            if (static_cast<uint32_t>(e >> 32) == tag) {
               if constexpr (MODE == MODE_KEY64) match = gload(bkeys + brow) == pkey;
               else match = rows_equal(a.probe, j, a.build, brow, a.nulls_equal != 0);
             }
@@ -987,33 +880,13 @@ void launch_dense_csr(join_args const& a, join_args* d_args, int32_t* cursor, ui
   hipLaunchKernelGGL(k_dense_csr_fill, dim3(grid_for(a.build.nrows)), dim3(256), 0, stream, d_args, cursor);
   CUDF_HIP_TRY(hipGetLastError());
 }
-void launch_probe_partition(join_args const& a, join_args* d_args, hipStream_t stream)
-{
-  hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
-  cudf::detail::prof::scope prof_{"join_probe_partition", stream};
-  constexpr int RPT = 5;
-  std::size_t const P = std::size_t{1} << a.part_bits;
-  int const G         = P > 512 ? 4 : 8;
-  auto const lds      = wc_scatter_lds_bytes(1024 * RPT, P, G);
-  CUDF_EXPECTS(lds <= 160 * 1024 - 64, "join probe partition: LDS budget exceeded");
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {
-    CUDF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(&k_probe_partition<RPT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    CUDF_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<void const*>(&k_probe_partition<RPT, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-  });
-  if (G == 4) hipLaunchKernelGGL((k_probe_partition<RPT, 4>), dim3(a.pslices), dim3(1024), lds, stream, d_args);
-  else hipLaunchKernelGGL((k_probe_partition<RPT, 8>), dim3(a.pslices), dim3(1024), lds, stream, d_args);
-  CUDF_HIP_TRY(hipGetLastError());
-}
 void launch_count(join_args const& a, join_args* d_args, hipStream_t stream)
 {
   hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_count", stream};
   if (a.dense_head != nullptr) hipLaunchKernelGGL(k_dense_count, dim3(a.nblocks), dim3(256), 0, stream, d_args);
-  else if (a.partitioned) hipLaunchKernelGGL((k_probe_count<MODE_KEY64_INLINE, true>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
-  else if (a.single64 && a.slot_words == 2) hipLaunchKernelGGL((k_probe_count<MODE_KEY64_INLINE, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
-  else if (a.single64) hipLaunchKernelGGL((k_probe_count<MODE_KEY64, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
-  else hipLaunchKernelGGL((k_probe_count<MODE_GENERIC, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  else if (a.single64) hipLaunchKernelGGL((k_probe_count<MODE_KEY64>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  else hipLaunchKernelGGL((k_probe_count<MODE_GENERIC>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 void launch_scan(join_args const& a, hipStream_t stream)
@@ -1026,10 +899,8 @@ void launch_retrieve(join_args const& a, join_args* d_args, hipStream_t stream)
   hipLaunchKernelGGL(k_store_args<join_args>, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_retrieve", stream};
   if (a.dense_head != nullptr) hipLaunchKernelGGL(k_dense_retrieve, dim3(a.nblocks), dim3(256), 0, stream, d_args);
-  else if (a.partitioned) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64_INLINE, true>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
-  else if (a.single64 && a.slot_words == 2) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64_INLINE, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
-  else if (a.single64) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
-  else hipLaunchKernelGGL((k_probe_retrieve<MODE_GENERIC, false>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  else if (a.single64) hipLaunchKernelGGL((k_probe_retrieve<MODE_KEY64>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
+  else hipLaunchKernelGGL((k_probe_retrieve<MODE_GENERIC>), dim3(a.nblocks), dim3(256), 0, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 void launch_dense_big_emit(join_args const& a, join_args* d_args, hipStream_t stream)

@@ -244,43 +244,8 @@ def test_large_properties(G):
     assert torch.unique(li_t).numel() == li_t.numel()
 
 
-@pytest.fixture
-def force_partitioned_probe(monkeypatch):
-    """Makes small inputs take the sliced table + radix-partitioned probe path (engine.hpp) that big inner joins use."""
-    monkeypatch.setenv("CUDF_AMD_JOIN_PARTITIONED", "1")
-    monkeypatch.setenv("CUDF_AMD_JOIN_SLICE_MIN_MB", "0")
-    monkeypatch.setenv("CUDF_AMD_JOIN_PARTITION_MIN_ROWS", "1")
-
-
-@pytest.mark.parametrize("nulls", [False, True])
-def test_partitioned_probe_matches_oracle(G, oracle, force_partitioned_probe, nulls):
-    """int64 keys, duplicates on both sides (several matches per probe row), optionally 5 % NULLs with
-    null_equality::UNEQUAL; 1.2M probe rows over 8 slices x 256 workgroup regions."""
-    rng = np.random.default_rng(99)
-    nl, nr = 1_200_000, 90_000
-    rk = rng.integers(0, 60_000, nr, dtype=np.int64)
-    lk = np.where(rng.random(nl) < 0.3, rng.integers(0, 60_000, nl), rng.integers(60_000, 200_000, nl)).astype(np.int64)
-    if nulls:
-        lv, rv = rng.random(nl) > 0.05, rng.random(nr) > 0.05
-        _check(G, oracle, [(lk, lv)], [(rk, rv)], False, "inner")
-    else:
-        _check(G, oracle, [lk], [rk], True, "inner")
-        _check(G, oracle, [lk], [rk], True, "left")   # non-inner kinds probe the sliced table directly
-        _check(G, oracle, [lk], [rk], True, "full")
-
-
-def test_partitioned_probe_overflow_falls_back(G, oracle, force_partitioned_probe):
-    """Half of the probe rows carry ONE key: its partition's regions overflow and the join probes directly."""
-    rng = np.random.default_rng(100)
-    nl, nr = 600_000, 50_000
-    rk = rng.permutation(100_000)[:nr].astype(np.int64)
-    lk = rng.integers(0, 100_000, nl, dtype=np.int64)
-    lk[::2] = rk[7]
-    _check(G, oracle, [lk], [rk], True, "inner")
-
-
-def test_partitioned_hash_join_object_reuse(G, oracle, force_partitioned_probe):
-    """One sliced table, several probes of different sizes (partitioned and direct) and the size API."""
+def test_hash_join_object_reuse(G, oracle):
+    """One hash_join object, several probes of different sizes and the size API."""
     import cudf_amd
     from cudf_amd.join import HashJoin
     from cudf_amd.types import NullEquality
@@ -383,14 +348,9 @@ _JOIN_FUZZ_TYPES = ["int8", "int16", "int32", "int64", "uint32", "uint64", "floa
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CUDF_AMD_FUZZ_SEEDS", "60"))))
 def test_fuzz_joins_against_oracle(G, oracle, seed, monkeypatch):
     """Seeded random joins: 1-3 key columns of mixed types, nulls on either side, both null equalities, all three kinds,
-    duplicate keys on both sides, sliced inputs, empty sides; every fourth seed goes through the sliced-table /
-    partitioned-probe path."""
+    duplicate keys on both sides, sliced inputs, empty sides."""
     from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
     rng = np.random.default_rng(5000 + seed)
-    if seed % 4 == 3:
-        monkeypatch.setenv("CUDF_AMD_JOIN_PARTITIONED", "1")
-        monkeypatch.setenv("CUDF_AMD_JOIN_SLICE_MIN_MB", "0")
-        monkeypatch.setenv("CUDF_AMD_JOIN_PARTITION_MIN_ROWS", "1")
     if seed % 4 in (1, 2):
         # the round-3 paths at fuzz sizes: whenever a case is ONE integer key column of 4 or 8 bytes whose NULLs never match, it goes
         # through the LDS radix join (seed % 4 == 1: dense tables off) or the dense table's ordered / partitioned / one-pass-left
