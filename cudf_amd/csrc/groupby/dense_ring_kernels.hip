@@ -15,6 +15,7 @@
 // (cpp/src/groupby/hash/compute_global_memory_aggs.cuh:74-187, single_pass_functors.cuh:86-157).
 #include "device_common.hpp"
 #include "dense_loader.hpp"
+#include "../common/ring_scatter.hpp"
 
 namespace cudf::groupby::detail {
 namespace {
@@ -191,68 +192,16 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
       }
     }
   };
-  // flush every complete granule of this wave's partitions; final: also the partial last granule
+  // flush every complete granule of this wave's partitions (common/ring_scatter.hpp); final: also the partial last granule
   auto flush = [&](bool final) {
-    uint32_t nrec = 0, nrect = 0;
-    int ab        = 0;
     int const dmine = wave * PW + lane;
-    if (lane < PW) {
-      uint32_t const t = tail[dmine], lim = head + CAP;
-      uint32_t const c = static_cast<int32_t>(t - lim) < 0 ? t : lim;  // records that made it into the ring
-      uint32_t const complete = final ? c : (c & ~(G - 1u));
-      nrec  = complete - head;
-      nrect = (final ? c : (c & ~(GT - 1u))) - headt;
-      if (complete > region_cap) {
-        s_abort = 1;
-        ab      = 1;
-      }
-    }
-    // values: 8 lanes per granule (two values = 16 bytes per lane), 8 partitions per batch
-    for (int b = 0; b * 8 < PW; ++b) {
-      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
-      uint32_t const mr = __shfl(nrec, pl), mh = __shfl(head, pl);
-      int const mab     = __shfl(ab, pl);
-      int const d       = wave * PW + pl;
-      int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
-      for (uint32_t g = 0;; ++g) {
-        uint32_t const q = g * G + sub * 2;
-        bool const act   = pl < PW && q < mr && !mab;
-        if (__ballot(act) == 0) break;
-        if (act) {
-          uint32_t const pos = mh + q;
-          u64x2 const v      = *reinterpret_cast<u64x2 const*>(rval + (static_cast<uint32_t>(d) << capl) + (pos & cmask));
-          if (q + 1 < mr) gstore(reinterpret_cast<u64x2*>(out_val + rbase + pos), v);
-          else gstore(out_val + rbase + pos, static_cast<uint64_t>(v.x));
-        }
-      }
-    }
-    // tags: 8 lanes per granule (16 bytes = 4 or 8 tags per lane), 8 partitions per batch
-    for (int b = 0; b * 8 < PW; ++b) {
-      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
-      uint32_t const mr = __shfl(nrect, pl), mh = __shfl(headt, pl);
-      int const mab     = __shfl(ab, pl);
-      int const d       = wave * PW + pl;
-      int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
-      for (uint32_t g = 0;; ++g) {
-        uint32_t const q = g * GT + sub * TPL;
-        bool const act   = pl < PW && q < mr && !mab;
-        if (__ballot(act) == 0) break;
-        if (act) {
-          uint32_t const pos = mh + q;
-          TAG const* src     = rtag + (static_cast<uint32_t>(d) << (capl + TL)) + (pos & tcmask);
-          if (q + TPL <= mr) {
-            gstore(reinterpret_cast<u32x4*>(out_tag + rbase + pos), *reinterpret_cast<u32x4 const*>(src));
-          } else {  // (the partial tail of the final flush)
-            for (uint32_t e = 0; q + e < mr; ++e) gstore(out_tag + rbase + pos + e, src[e]);
-          }
-        }
-      }
-    }
-    if (lane < PW) {
-      head += nrec;
-      headt += nrect;
-      limit[dmine] = head + CAP;
-    }
+    auto const f    = cudf::detail::ring::plan_flush<G, GT>(tail, lane < PW, dmine, head, headt, CAP, region_cap, final, s_abort);
+    auto const rbase_of = [&](int d) { return (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap; };
+    cudf::detail::ring::flush_stream(rval, out_val, wave, PW, lane, f.nrec, head, f.ab,
+                                     [&](uint32_t d, uint32_t pos) { return (d << capl) + (pos & cmask); }, rbase_of);
+    cudf::detail::ring::flush_stream(rtag, out_tag, wave, PW, lane, f.nrect, headt, f.ab,
+                                     [&](uint32_t d, uint32_t pos) { return (d << (capl + TL)) + (pos & tcmask); }, rbase_of);
+    cudf::detail::ring::commit_flush(limit, lane < PW, dmine, head, headt, f, CAP);
   };
 
   ring_tile<SRC, RPT, SHAPE> pre[D];
@@ -332,58 +281,14 @@ __global__ void __launch_bounds__(1024) k_dense_ring_scatter(dense_ring_args con
       }
       if constexpr (!COLS) issue(t0 + D * step, pre[j]);
       if (t0 >= end) break;  // (uniform)
-      // ---- reserve ring positions; rows whose position lies beyond the ring wait for the flush
-      uint32_t pos[RPT], lim[RPT];
-      bool pend[RPT];
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        pos[k] = 0;
-        lim[k] = 0;
-        if (keep[k]) {
-          pos[k] = atomicAdd(&tail[d[k]], 1u);
-          lim[k] = limit[d[k]];
-        }
-      }
-      bool any_pend = false;
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        pend[k] = keep[k] && static_cast<int32_t>(pos[k] - lim[k]) >= 0;
-        if (keep[k] && !pend[k]) {
-          uint32_t const w = (d[k] << capl) + (pos[k] & cmask);
-          rval[w] = val[k];
-          rtag[(d[k] << (capl + TL)) + (pos[k] & tcmask)] = static_cast<TAG>(tg[k]);
-        }
-        any_pend = any_pend || pend[k];
-      }
-      if (any_pend) s_pending = 1;
-      lds_barrier();
-      flush(false);
-      lds_barrier();
-      while (s_pending) {  // a ring was full: its granules are flushed by now, the waiting rows go in
-        lds_barrier();
-        if (threadIdx.x == 0) s_pending = 0;
-        lds_barrier();
-        any_pend = false;
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-          if (pend[k]) {
-            uint32_t const l2 = limit[d[k]];
-            if (static_cast<int32_t>(pos[k] - l2) < 0) {
-              uint32_t const w = (d[k] << capl) + (pos[k] & cmask);
-              rval[w] = val[k];
-              rtag[(d[k] << (capl + TL)) + (pos[k] & tcmask)] = static_cast<TAG>(tg[k]);
-              pend[k] = false;
-            } else {
-              any_pend = true;
-            }
-          }
-        }
-        if (any_pend) s_pending = 1;
-        lds_barrier();
-        flush(false);
-        lds_barrier();
-        if (s_abort) break;
-      }
+      // ---- reserve ring positions, write the records, flush; rows whose position lies beyond the ring wait for the flush
+      cudf::detail::ring::place_tile<RPT>(
+        tail, limit, keep, d, s_pending, s_abort,
+        [&](int k, uint32_t pos) {
+          rval[(d[k] << capl) + (pos & cmask)]                        = val[k];
+          rtag[(d[k] << (capl + TL)) + (pos & tcmask)] = static_cast<TAG>(tg[k]);
+        },
+        [&] { flush(false); }, [] {}, [] {});
       if (s_abort) {  // a region would overflow (skewed or clustered keys): the caller redoes the call
         if (threadIdx.x == 0) atomicOr(a.overflow, 1);
         return;

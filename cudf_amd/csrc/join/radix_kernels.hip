@@ -11,6 +11,7 @@
 // workgroup-local cursor by 64-lane ballots.
 #include "engine.hpp"
 #include "../common/profiler.hpp"
+#include "../common/ring_scatter.hpp"
 
 #include <cudf/join/join.hpp>
 #include <cudf/utilities/error.hpp>
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
   __shared__ int s_pending, s_abort, s_rounds;
   __shared__ int32_t s_pre[RADIX_MAX_REGION_LIST + 1];
   radix_scatter_args const& a = *ap;
-  constexpr uint32_t G = 16, GT = 32, TPL = 4;  // keys / row ids per 128-byte granule; row ids per lane of a flush (16 bytes)
+  constexpr uint32_t G = 16, GT = 32;  // keys / row ids per 128-byte granule
   int const P = a.P, capl = a.capl;
   uint32_t const CAP = 1u << capl, cmask = CAP - 1u, tcmask = (CAP << 1) - 1u;
   uint32_t const nslots = static_cast<uint32_t>(P) << capl;
@@ -166,70 +167,17 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
       }
     }
   };
-  auto flush = [&](bool final) {
-    uint32_t nrec = 0, nrect = 0;
-    int ab        = 0;
+  auto flush = [&](bool final) {  // (common/ring_scatter.hpp) keys: granules of 16; row ids: granules of 32, in rings twice as long
     int const dmine = wave * PW + lane;
-    if (lane < PW) {
-      uint32_t const t = tail[dmine], lim = head + CAP;
-      uint32_t const c = static_cast<int32_t>(t - lim) < 0 ? t : lim;
-      uint32_t const complete = final ? c : (c & ~(G - 1u));
-      nrec  = complete - head;
-      nrect = (final ? c : (c & ~(GT - 1u))) - headt;
-      if (complete > region_cap) {
-        s_abort = 1;
-        ab      = 1;
-      }
-    }
-    for (int b = 0; b * 8 < PW; ++b) {  // keys: 8 lanes per granule (two keys per lane), 8 partitions per batch
-      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
-      uint32_t const mr = __shfl(nrec, pl), mh = __shfl(head, pl);
-      int const mab     = __shfl(ab, pl);
-      int const d       = wave * PW + pl;
-      int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
-      for (uint32_t g = 0;; ++g) {
-        uint32_t const q = g * G + sub * 2;
-        bool const act   = pl < PW && q < mr && !mab;
-        if (__ballot(act) == 0) break;
-        if (act) {
-          uint32_t const pos = mh + q;
-          u64x2 const v      = *reinterpret_cast<u64x2 const*>(rkey + (static_cast<uint32_t>(d) << capl) + (pos & cmask));
-          if (q + 1 < mr) gstore(reinterpret_cast<u64x2*>(a.out_key + rbase + pos), v);
-          else gstore(a.out_key + rbase + pos, static_cast<uint64_t>(v.x));
-          if constexpr (KW == 2) {
-            u64x2 const v1 = *reinterpret_cast<u64x2 const*>(rkey1 + (static_cast<uint32_t>(d) << capl) + (pos & cmask));
-            if (q + 1 < mr) gstore(reinterpret_cast<u64x2*>(a.out_key1 + rbase + pos), v1);
-            else gstore(a.out_key1 + rbase + pos, static_cast<uint64_t>(v1.x));
-          }
-        }
-      }
-    }
-    for (int b = 0; !DENSE && b * 8 < PW; ++b) {  // row ids: 8 lanes per granule (four ids per lane)
-      int const pl = b * 8 + (lane >> 3), sub = lane & 7;
-      uint32_t const mr = __shfl(nrect, pl), mh = __shfl(headt, pl);
-      int const mab     = __shfl(ab, pl);
-      int const d       = wave * PW + pl;
-      int64_t const rbase = (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap;
-      for (uint32_t g = 0;; ++g) {
-        uint32_t const q = g * GT + sub * TPL;
-        bool const act   = pl < PW && q < mr && !mab;
-        if (__ballot(act) == 0) break;
-        if (act) {
-          uint32_t const pos  = mh + q;
-          uint32_t const* src = rrow + (static_cast<uint32_t>(d) << (capl + 1)) + (pos & tcmask);
-          if (q + TPL <= mr) {
-            gstore(reinterpret_cast<u32x4*>(a.out_row + rbase + pos), *reinterpret_cast<u32x4 const*>(src));
-          } else {
-            for (uint32_t e = 0; q + e < mr; ++e) gstore(a.out_row + rbase + pos + e, src[e]);
-          }
-        }
-      }
-    }
-    if (lane < PW) {
-      head += nrec;
-      headt += nrect;
-      limit[dmine] = head + CAP;
-    }
+    auto const f    = cudf::detail::ring::plan_flush<G, GT>(tail, lane < PW, dmine, head, headt, CAP, region_cap, final, s_abort);
+    auto const rbase_of = [&](int d) { return (region0 + static_cast<int64_t>(d) * a.slices + item) * a.region_cap; };
+    auto const key_slot = [&](uint32_t d, uint32_t pos) { return (d << capl) + (pos & cmask); };
+    cudf::detail::ring::flush_stream(rkey, a.out_key, wave, PW, lane, f.nrec, head, f.ab, key_slot, rbase_of);
+    if constexpr (KW == 2) cudf::detail::ring::flush_stream(rkey1, a.out_key1, wave, PW, lane, f.nrec, head, f.ab, key_slot, rbase_of);
+    if constexpr (!DENSE)
+      cudf::detail::ring::flush_stream(rrow, a.out_row, wave, PW, lane, f.nrect, headt, f.ab,
+                                       [&](uint32_t d, uint32_t pos) { return (d << (capl + 1)) + (pos & tcmask); }, rbase_of);
+    cudf::detail::ring::commit_flush(limit, lane < PW, dmine, head, headt, f, CAP);
   };
   auto put = [&](uint32_t d, uint32_t pos, uint64_t key, [[maybe_unused]] uint64_t key1, uint32_t rowid) {
     rkey[(d << capl) + (pos & cmask)] = key;
@@ -272,56 +220,16 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
       }
       issue(t0 + D * step, pre[j]);
       if (t0 >= end) break;  // (uniform)
-      uint32_t pos[RPT], lim[RPT];
-      bool pend[RPT];
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        pos[k] = 0;
-        lim[k] = 0;
-        if (keep[k]) {
-          pos[k] = atomicAdd(&tail[d[k]], 1u);
-          lim[k] = limit[d[k]];
-        }
-      }
-      bool any_pend = false;
-#pragma unroll
-      for (int k = 0; k < RPT; ++k) {
-        pend[k] = keep[k] && static_cast<int32_t>(pos[k] - lim[k]) >= 0;
-        if (keep[k] && !pend[k]) put(d[k], pos[k], key[k], key1[k], rowid[k]);
-        any_pend = any_pend || pend[k];
-      }
-      if (any_pend) s_pending = 1;
-      lds_barrier();
-      flush(false);
-      lds_barrier();
-      if (DENSE && threadIdx.x == 0 && s_rounds > 0) --s_rounds;  // (a tile without a wait pays one back)
-      while (s_pending) {  // a ring was full: its granules are flushed by now, the waiting rows go in
-        lds_barrier();
-        if (threadIdx.x == 0) {
-          s_pending = 0;
-          // (DENSE: rows that arrive sorted or clustered by key fill one ring tile after tile; the caller's direct path is the
-          // better one for them - give up once the waiting rounds outnumber the tiles)
+      // (DENSE: rows that arrive sorted or clustered by key fill one ring tile after tile; the caller's direct path is the better one
+      // for them - a tile without a wait pays one round back, and the workgroup gives up once the waiting rounds outnumber the tiles)
+      cudf::detail::ring::place_tile<RPT>(
+        tail, limit, keep, d, s_pending, s_abort, [&](int k, uint32_t pos) { put(d[k], pos, key[k], key1[k], rowid[k]); }, [&] { flush(false); },
+        [&] {
+          if (DENSE && threadIdx.x == 0 && s_rounds > 0) --s_rounds;
+        },
+        [&] {
           if (DENSE && ++s_rounds > a.pending_budget) s_abort = 1;
-        }
-        lds_barrier();
-        any_pend = false;
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-          if (pend[k]) {
-            if (static_cast<int32_t>(pos[k] - limit[d[k]]) < 0) {
-              put(d[k], pos[k], key[k], key1[k], rowid[k]);
-              pend[k] = false;
-            } else {
-              any_pend = true;
-            }
-          }
-        }
-        if (any_pend) s_pending = 1;
-        lds_barrier();
-        flush(false);
-        lds_barrier();
-        if (s_abort) break;
-      }
+        });
       if (s_abort) {
         if (threadIdx.x == 0) atomicOr(a.overflow, 1);
         return;
