@@ -467,7 +467,7 @@ def main():
             traffic, traffic_note = None, None
             try:  # PMC traffic of this kernel at this workload, collected with rocprofv3 (see the file's "how"): quoted only
                 # if it was taken from the source tree this library is built from - otherwise it is stale and says so
-                pmc_file = next(f for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                pmc_file = next(f for f in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                     doc = json.load(f)
                 if doc.get("sources_sha256") != _sources_sha256():

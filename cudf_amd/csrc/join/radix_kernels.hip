@@ -41,10 +41,25 @@ constexpr int RADIX_MAX_REGION_LIST = 256;
 // DENSE (level 1 only; the dense direct-address join's partition pass, dense_part_kernels.hip): a row is the ONE 8-byte record
 // {key - dense_lo (32 bits) | row id << 32}, its partition the top bits of that offset (a contiguous slice of the direct-address
 // table); rows whose key lies outside [dense_lo, dense_lo + dense_range) are dropped like NULL rows. No row-id stream.
-template <int LEVEL, int RPT, int D, bool DENSE, int B = 1024, int KW = 1>
+// SHAPE (level 1): what the key columns are, so that the row loop holds NO run-time branch and NO arithmetic on a loaded word before
+// the tile is decoded (either one makes the compiler wait for all outstanding loads: the general loader's first level ran C3's shape at
+// 4.3 instead of 2.4 ms - 243 against 28 `s_waitcnt vmcnt(0)` in the kernel):
+//   0  anything, tested at run time (4-byte keys, two packed 4-byte columns, float32, two-word keys)
+//   1  one 8-byte integer column, read as is                                  (C3)
+//   2  one float64 column: its normalised bits                                (normalize_key_bits, arithmetic only)
+//   3 / 4 / 5  two integer columns of 8+8 / 8+4 / 4+8 bytes packed into one exact word (engine.hpp radix_scatter_args::pack)
+//   6 / 7 / 8  two integer columns of 8+8 / 8+4 / 4+8 bytes as a two-word key (KW == 2)
+constexpr int SHAPE_ANY = 0, SHAPE_INT64 = 1, SHAPE_F64 = 2, SHAPE_PACK88 = 3, SHAPE_PACK84 = 4, SHAPE_PACK48 = 5, SHAPE_TWO88 = 6, SHAPE_TWO84 = 7,
+              SHAPE_TWO48 = 8;
+template <int LEVEL, int RPT, int D, bool DENSE, int B = 1024, int KW = 1, int SHAPE = SHAPE_ANY>
 __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* __restrict__ ap)
 {
-  static_assert(KW == 1 || (KW == 2 && !DENSE), "two-word keys: the hash-partitioned (radix) join only");
+  static_assert(SHAPE == SHAPE_ANY || (LEVEL == 1 && (KW == 2) == (SHAPE >= SHAPE_TWO88)), "SHAPE: the first level; 6-8 are the two-word keys");
+  static_assert(SHAPE < SHAPE_PACK88 || !DENSE, "two key columns: the hash-partitioned (radix) join only");
+  constexpr bool PLAIN = SHAPE == SHAPE_INT64 || SHAPE == SHAPE_F64;
+  constexpr bool PACK  = SHAPE >= SHAPE_PACK88 && SHAPE <= SHAPE_PACK48;
+  constexpr bool TWO   = SHAPE >= SHAPE_TWO88;
+  constexpr int W0 = (SHAPE == SHAPE_PACK48 || SHAPE == SHAPE_TWO48) ? 4 : 8, W1 = (SHAPE == SHAPE_PACK84 || SHAPE == SHAPE_TWO84) ? 4 : 8;  // two columns: widths
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   __shared__ int s_pending, s_abort, s_rounds;
   __shared__ int32_t s_pre[RADIX_MAX_REGION_LIST + 1];
@@ -111,10 +126,15 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
     while (reg + 1 < nreg && s_pre[reg + 1] <= v) ++reg;
     return rfirst + static_cast<int64_t>(reg) * rstride + (v - s_pre[reg]);
   };
+  // The loads of a tile are issued D tiles ahead and only LOADED there: every widening, normalisation or packing of a loaded word
+  // happens where the tile is decoded. (Arithmetic on a loaded value inside issue() makes the compiler wait for the load right there:
+  // the level-1 kernel then ran at 4.3 instead of 2.4 ms - 243 against 28 `s_waitcnt vmcnt(0)`.)
+  constexpr bool SECOND = KW == 2 || PACK || (LEVEL == 1 && SHAPE == SHAPE_ANY && !DENSE);  // a second loaded word per row (second key column)
   struct tile_regs {
-    uint64_t k[RPT];
-    uint64_t k1[KW == 2 ? RPT : 1];  // the second key word
-    uint32_t r[RPT];  // level 1: the validity word of the row; level 2: the row id
+    uint64_t k[RPT];                  // level 1: the first key column's raw bits (zero-extended); level 2: the key
+    uint64_t k1[SECOND ? RPT : 1];    // level 1: the second key column's raw bits; level 2, KW == 2: the second key word
+    uint32_t r[RPT];                  // level 1: the validity word of the row; level 2: the row id
+    uint32_t r2[(LEVEL == 1 && SECOND) ? RPT : 1];  // level 1: the second column's validity word
   };
   auto issue = [&](int64_t tile, tile_regs& t) {
 #pragma unroll
@@ -122,42 +142,27 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
       int64_t const row = tile + static_cast<int64_t>(k) * B + threadIdx.x;
       if (row < end) {
         if constexpr (LEVEL == 1) {
-          if (a.keys2 != nullptr) {  // TWO 4-byte integer key columns, packed into the 8-byte key (a bijection: rows are equal iff both are)
-            uint32_t const c0 = gload(reinterpret_cast<uint32_t const*>(a.keys) + row), c1 = gload(a.keys2 + row);
-            t.k[k]            = static_cast<uint64_t>(c0) | (static_cast<uint64_t>(c1) << 32);
-          } else if (a.key_width == 4) {  // a 4-byte integer key column: widened here (sign-extended when the type is signed)
-            uint32_t const k32 = gload(reinterpret_cast<uint32_t const*>(a.keys) + row);
-            t.k[k]             = a.key_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32);
-          } else {
+          if constexpr (PLAIN) {
             t.k[k] = gload(a.keys + row);
-          }
-          if (a.key_class != 0) t.k[k] = normalize_key_bits(t.k[k], a.key_class);  // (a float key: equal values, equal bits)
-          if constexpr (KW == 2) {  // the second column: raw bits zero-extended (equal values have equal bits once floats are normalised)
-            uint64_t b1 = a.key2_width == 4 ? static_cast<uint64_t>(gload(static_cast<uint32_t const*>(a.key2) + row)) : gload(static_cast<uint64_t const*>(a.key2) + row);
-            if (a.key2_class != 0) b1 = normalize_key_bits(b1, a.key2_class);
-            t.k1[k] = b1;
-          }
-          t.r[k] = a.mask != nullptr ? gload(a.mask + ((a.mask_offset + row) >> 5)) : 0xffffffffu;
-          // (a NULL in the second column drops the row as well: the word the later test reads becomes all zeros)
-          if (a.mask2 != nullptr && !((gload(a.mask2 + ((a.mask2_offset + row) >> 5)) >> ((a.mask2_offset + row) & 31)) & 1u)) t.r[k] = 0;
-          if constexpr (KW == 1 && !DENSE) {
-            if (a.pack != 0) {  // two integer columns inside the build side's value box: one exact word (engine.hpp)
-              uint64_t c1;
-              if (a.key2_width == 4) {
-                uint32_t const k32 = gload(static_cast<uint32_t const*>(a.key2) + row);
-                c1                 = a.key2_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32);
-              } else {
-                c1 = gload(static_cast<uint64_t const*>(a.key2) + row);
+          } else if constexpr (PACK || TWO) {
+            if constexpr (W0 == 4) t.k[k] = gload(reinterpret_cast<uint32_t const*>(a.keys) + row);
+            else t.k[k] = gload(a.keys + row);
+            if constexpr (W1 == 4) t.k1[k] = gload(static_cast<uint32_t const*>(a.key2) + row);
+            else t.k1[k] = gload(static_cast<uint64_t const*>(a.key2) + row);
+            t.r2[k] = a.mask2 != nullptr ? gload(a.mask2 + ((a.mask2_offset + row) >> 5)) : 0xffffffffu;
+          } else {
+            if (a.key_width == 4) t.k[k] = gload(reinterpret_cast<uint32_t const*>(a.keys) + row);
+            else t.k[k] = gload(a.keys + row);
+            if constexpr (SECOND) {
+              void const* const second = a.keys2 != nullptr ? static_cast<void const*>(a.keys2) : a.key2;
+              if (second != nullptr) {
+                if (a.keys2 != nullptr || a.key2_width == 4) t.k1[k] = gload(static_cast<uint32_t const*>(second) + row);
+                else t.k1[k] = gload(static_cast<uint64_t const*>(second) + row);
               }
-              uint64_t const d0 = t.k[k] - a.pack_lo0, d1 = c1 - a.pack_lo1;
-              if (d0 <= a.pack_range0 && d1 <= a.pack_range1) {
-                t.k[k] = (d0 << a.pack_bits1) | d1;
-              } else {
-                t.k[k] = 0x8000000000000000ull | (cudf::detail::mix64(static_cast<uint64_t>(row)) >> 1);
-                if (!a.pack_keep_outside) t.r[k] = 0;
-              }
+              t.r2[k] = a.mask2 != nullptr ? gload(a.mask2 + ((a.mask2_offset + row) >> 5)) : 0xffffffffu;
             }
           }
+          t.r[k] = a.mask != nullptr ? gload(a.mask + ((a.mask_offset + row) >> 5)) : 0xffffffffu;
         } else {
           int64_t const ri = record_of(row, reg_hint[k]);
           t.k[k]           = gload(a.in_key + ri);
@@ -202,11 +207,49 @@ __global__ void __launch_bounds__(B) k_radix_scatter(radix_scatter_args const* _
         keep[k]           = row < end;
         key[k]            = pre[j].k[k];
         key1[k]           = 0;
-        if constexpr (KW == 2) key1[k] = pre[j].k1[k];
         if constexpr (LEVEL == 1) {
           rowid[k] = static_cast<uint32_t>(row);
           keep[k]  = keep[k] && ((pre[j].r[k] >> ((a.mask_offset + row) & 31)) & 1u);  // a NULL key joins nothing (UNEQUAL)
+          auto const widen32 = [](uint64_t raw, int is_signed) {  // (a select, not a branch)
+            return is_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(raw)))) : (raw & 0xffffffffull);
+          };
+          if constexpr (SHAPE == SHAPE_F64) {
+            key[k] = normalize_key_bits(key[k], cudf::detail::CLS_F64);  // equal values, equal bits
+          } else if constexpr (PACK) {  // two integer columns inside the build side's value box: one exact word (engine.hpp)
+            uint64_t const c0 = W0 == 4 ? widen32(key[k], a.key_signed) : key[k];
+            uint64_t const c1 = W1 == 4 ? widen32(pre[j].k1[k], a.key2_signed) : pre[j].k1[k];
+            uint64_t const d0 = c0 - a.pack_lo0, d1 = c1 - a.pack_lo1;
+            bool const inside = d0 <= a.pack_range0 && d1 <= a.pack_range1;
+            key[k]  = inside ? ((d0 << a.pack_bits1) | d1) : (0x8000000000000000ull | (cudf::detail::mix64(static_cast<uint64_t>(row)) >> 1));
+            keep[k] = keep[k] && ((pre[j].r2[k] >> ((a.mask2_offset + row) & 31)) & 1u) && (inside || a.pack_keep_outside != 0);
+          } else if constexpr (TWO) {  // the first column widened like a single key column, the second's raw bits zero-extended
+            if constexpr (W0 == 4) key[k] = widen32(key[k], a.key_signed);
+            key1[k] = pre[j].k1[k];
+            keep[k] = keep[k] && ((pre[j].r2[k] >> ((a.mask2_offset + row) & 31)) & 1u);
+          } else if constexpr (SHAPE == SHAPE_ANY) {
+            if (a.keys2 != nullptr) {  // TWO 4-byte integer key columns, packed into the 8-byte key (a bijection: rows are equal iff both are)
+              key[k] = (key[k] & 0xffffffffull) | (pre[j].k1[k] << 32);
+            } else if (a.key_width == 4) {  // a 4-byte integer key column: widened here (sign-extended when the type is signed)
+              key[k] = widen32(key[k], a.key_signed);
+            }
+            if (a.key_class != 0) key[k] = normalize_key_bits(key[k], a.key_class);  // (a float key: equal values, equal bits)
+            if constexpr (SECOND) {
+              // (a NULL in the second column drops the row as well)
+              keep[k] = keep[k] && ((pre[j].r2[k] >> ((a.mask2_offset + row) & 31)) & 1u);
+              if constexpr (KW == 2) {  // the second column: raw bits zero-extended (equal values have equal bits once floats are normalised)
+                key1[k] = pre[j].k1[k];
+                if (a.key2_class != 0) key1[k] = normalize_key_bits(key1[k], a.key2_class);
+              } else if (a.pack != 0) {
+                uint64_t const c1 = a.key2_width == 4 ? widen32(pre[j].k1[k], a.key2_signed) : pre[j].k1[k];
+                uint64_t const d0 = key[k] - a.pack_lo0, d1 = c1 - a.pack_lo1;
+                bool const inside = d0 <= a.pack_range0 && d1 <= a.pack_range1;
+                key[k]  = inside ? ((d0 << a.pack_bits1) | d1) : (0x8000000000000000ull | (cudf::detail::mix64(static_cast<uint64_t>(row)) >> 1));
+                keep[k] = keep[k] && (inside || a.pack_keep_outside != 0);
+              }
+            }
+          }
         } else {
+          if constexpr (KW == 2) key1[k] = pre[j].k1[k];
           rowid[k] = pre[j].r[k];
         }
         if constexpr (DENSE) {
@@ -651,19 +694,50 @@ void launch_radix_scatter(radix_scatter_args const& a, radix_scatter_args* d_arg
     for (void const* fn : {reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false>), reinterpret_cast<void const*>(&k_radix_scatter<2, 4, 2, false>),
                            reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true>), reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true, 512>),
                            reinterpret_cast<void const*>(&k_radix_scatter<1, 8, 2, true>), reinterpret_cast<void const*>(&k_radix_scatter<1, 2, 2, false, 1024, 2>),
-                           reinterpret_cast<void const*>(&k_radix_scatter<2, 2, 2, false, 1024, 2>)}) {
+                           reinterpret_cast<void const*>(&k_radix_scatter<2, 2, 2, false, 1024, 2>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_INT64>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, true, 1024, 1, SHAPE_INT64>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_F64>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_PACK88>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_PACK84>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_PACK48>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 2, 2, false, 1024, 2, SHAPE_TWO88>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 2, 2, false, 1024, 2, SHAPE_TWO84>),
+                           reinterpret_cast<void const*>(&k_radix_scatter<1, 2, 2, false, 1024, 2, SHAPE_TWO48>)}) {
       hipFuncAttributes attr{};
       CUDF_HIP_TRY(hipFuncGetAttributes(&attr, fn));
       CUDF_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_cast<int>(attr.sharedSizeBytes)));
     }
   });
   hipLaunchKernelGGL(k_store_radix_args<radix_scatter_args>, dim3(1), dim3(1), 0, stream, a, d_args);
+  int shape = SHAPE_ANY;
+  if (a.level == 1 && a.kw == 2 && !dense && a.key_class == 0 && a.key2_class == 0) {
+    int const w = a.key_width * 10 + a.key2_width;
+    shape       = w == 88 ? SHAPE_TWO88 : w == 84 ? SHAPE_TWO84 : w == 48 ? SHAPE_TWO48 : SHAPE_ANY;
+  }
+  if (a.level == 1 && a.kw <= 1 && a.keys2 == nullptr) {
+    if (a.pack != 0 && !dense) {
+      int const w = a.key_width * 10 + a.key2_width;
+      shape       = w == 88 ? SHAPE_PACK88 : w == 84 ? SHAPE_PACK84 : w == 48 ? SHAPE_PACK48 : SHAPE_ANY;
+    } else if (a.pack == 0 && a.key_width == 8) {
+      shape = a.key_class == 0 ? SHAPE_INT64 : (a.key_class == static_cast<int32_t>(cudf::detail::CLS_F64) && !dense) ? SHAPE_F64 : SHAPE_ANY;
+    }
+  }
   cudf::detail::prof::scope prof_{a.level == 1 ? "join_partition" : "join_partition_level2", stream};
   if (dense && a.block == 512) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true, 512>), dim3(a.slices), dim3(512), lds, stream, d_args);
   else if (dense && a.rpt == 8) hipLaunchKernelGGL((k_radix_scatter<1, 8, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (dense && shape == SHAPE_INT64) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true, 1024, 1, SHAPE_INT64>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else if (dense) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, true>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (shape == SHAPE_TWO88) hipLaunchKernelGGL((k_radix_scatter<1, 2, 2, false, 1024, 2, SHAPE_TWO88>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (shape == SHAPE_TWO84) hipLaunchKernelGGL((k_radix_scatter<1, 2, 2, false, 1024, 2, SHAPE_TWO84>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (shape == SHAPE_TWO48) hipLaunchKernelGGL((k_radix_scatter<1, 2, 2, false, 1024, 2, SHAPE_TWO48>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else if (a.kw == 2 && a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 2, 2, false, 1024, 2>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else if (a.kw == 2) hipLaunchKernelGGL((k_radix_scatter<2, 2, 2, false, 1024, 2>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
+  else if (shape == SHAPE_INT64) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_INT64>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (shape == SHAPE_F64) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_F64>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (shape == SHAPE_PACK88) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_PACK88>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (shape == SHAPE_PACK84) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_PACK84>), dim3(a.slices), dim3(1024), lds, stream, d_args);
+  else if (shape == SHAPE_PACK48) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false, 1024, 1, SHAPE_PACK48>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else if (a.level == 1) hipLaunchKernelGGL((k_radix_scatter<1, 4, 2, false>), dim3(a.slices), dim3(1024), lds, stream, d_args);
   else hipLaunchKernelGGL((k_radix_scatter<2, 4, 2, false>), dim3(a.nseg * a.slices), dim3(1024), lds, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
