@@ -148,7 +148,43 @@ __global__ void __launch_bounds__(256) k_dense_part_lookup(dense_part_args const
 
 __global__ void k_store_dense_stage_args(dense_stage_args v, dense_stage_args* dst) { *dst = v; }
 
+// The rows' loads of one round, all issued before any of them is used: NARROW (a 4-byte key column) and MASKED (a validity mask) are
+// compile-time so that no load sits under a run-time branch, rows past the end read the last row instead of being skipped, and a row
+// that fails the range test still reads head[0] (one hot line) - the compiler then counts its waits instead of draining every load:
+// 34 `s_waitcnt vmcnt(0)` for 32 loads before, eight dependent round trips per round; now the R key loads, the R mask loads and the R
+// table lookups each travel together.
+template <bool NARROW, bool MASKED, int R, typename RowOf>
+__device__ __forceinline__ void dense_lookup_round(dense_stage_args const& a, int64_t last_row, RowOf row_of, int64_t limit, int32_t (&h)[R])
+{
+  uint64_t raw[R];
+  uint32_t mword[R];
+  uint32_t const* keys32 = reinterpret_cast<uint32_t const*>(a.keys);
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    int64_t const r = min(row_of(j), last_row);
+    if constexpr (NARROW) raw[j] = gload_stream(keys32 + r);
+    else raw[j] = gload_stream(a.keys + r);
+    if constexpr (MASKED) mword[j] = gload(a.mask + ((a.mask_offset + r) >> 5));
+  }
+  uint64_t idx[R];
+  bool in[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    int64_t const r = row_of(j);
+    uint64_t key    = raw[j];
+    if constexpr (NARROW) key = a.key_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(static_cast<uint32_t>(raw[j])))) : raw[j];
+    idx[j] = key - a.dense_lo;
+    in[j]  = r < limit && idx[j] < a.dense_range;  // a key outside the build side's range matches nothing
+    if constexpr (MASKED) in[j] = in[j] && ((mword[j] >> ((a.mask_offset + r) & 31)) & 1u);
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) h[j] = gload(a.head + (in[j] ? idx[j] : 0));
+#pragma unroll
+  for (int j = 0; j < R; ++j) h[j] = in[j] ? h[j] : -1;
+}
+
 // (engine.hpp dense_stage_args) one wave = one contiguous range of probe rows, walked in order, 8 row sets of 64 in flight
+template <bool NARROW, bool MASKED>
 __global__ void __launch_bounds__(256) k_dense_probe_staged(dense_stage_args const* __restrict__ ap)
 {
   dense_stage_args const& a = *ap;
@@ -159,32 +195,10 @@ __global__ void __launch_bounds__(256) k_dense_probe_staged(dense_stage_args con
   uint64_t const below = (1ull << lane) - 1ull;
   int64_t const begin = w * a.wave_rows, end = min(a.nrows, begin + a.wave_rows);
   uint64_t* stage      = a.stage + w * a.wave_rows;
-  uint64_t const lo = a.dense_lo, range = a.dense_range;
-  bool const narrow = a.key_width == 4;
-  uint32_t const* keys32 = reinterpret_cast<uint32_t const*>(a.keys);
   unsigned long long npairs = 0;
   for (int64_t base = begin; base < end; base += 64 * R) {
-    uint64_t idx[R];
-    bool in[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      int64_t const r = base + j * 64 + lane;
-      in[j]           = r < end;
-      idx[j]          = 0;
-      if (in[j]) {
-        if (narrow) {
-          uint32_t const k32 = gload_stream(keys32 + r);
-          idx[j] = (a.key_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32)) - lo;
-        } else {
-          idx[j] = gload_stream(a.keys + r) - lo;
-        }
-        if (a.mask != nullptr) in[j] = (gload(a.mask + ((a.mask_offset + r) >> 5)) >> ((a.mask_offset + r) & 31)) & 1u;
-        in[j] = in[j] && idx[j] < range;  // a key outside the build side's range matches nothing and reads nothing
-      }
-    }
     int32_t h[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) h[j] = in[j] ? gload(a.head + idx[j]) : -1;
+    dense_lookup_round<NARROW, MASKED, R>(a, end - 1, [&](int j) { return base + j * 64 + lane; }, end, h);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       unsigned long long const m = __ballot(h[j] >= 0);
@@ -223,37 +237,16 @@ __global__ void __launch_bounds__(256) k_dense_inrange_sample(dense_stage_args c
 }
 
 // (engine.hpp launch_dense_left_direct)
+template <bool NARROW, bool MASKED>
 __global__ void __launch_bounds__(256) k_dense_left_direct(dense_stage_args const* __restrict__ ap, size_type* __restrict__ out_probe,
                                                            size_type* __restrict__ out_build)
 {
   dense_stage_args const& a = *ap;
   constexpr int R = 8;
-  uint64_t const lo = a.dense_lo, range = a.dense_range;
-  bool const narrow = a.key_width == 4;
-  uint32_t const* keys32 = reinterpret_cast<uint32_t const*>(a.keys);
   int64_t const stride = static_cast<int64_t>(gridDim.x) * blockDim.x * R;
   for (int64_t base = static_cast<int64_t>(blockIdx.x) * blockDim.x * R; base < a.nrows; base += stride) {
-    uint64_t idx[R];
-    bool in[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      int64_t const r = base + j * 256 + threadIdx.x;
-      in[j]           = r < a.nrows;
-      idx[j]          = 0;
-      if (in[j]) {
-        if (narrow) {
-          uint32_t const k32 = gload_stream(keys32 + r);
-          idx[j] = (a.key_signed ? static_cast<uint64_t>(static_cast<int64_t>(static_cast<int32_t>(k32))) : static_cast<uint64_t>(k32)) - lo;
-        } else {
-          idx[j] = gload_stream(a.keys + r) - lo;
-        }
-        if (a.mask != nullptr) in[j] = (gload(a.mask + ((a.mask_offset + r) >> 5)) >> ((a.mask_offset + r) & 31)) & 1u;
-        in[j] = in[j] && idx[j] < range;
-      }
-    }
     int32_t h[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) h[j] = in[j] ? gload(a.head + idx[j]) : -1;
+    dense_lookup_round<NARROW, MASKED, R>(a, a.nrows - 1, [&](int j) { return base + j * 256 + threadIdx.x; }, a.nrows, h);
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       int64_t const r = base + j * 256 + threadIdx.x;
@@ -264,6 +257,16 @@ __global__ void __launch_bounds__(256) k_dense_left_direct(dense_stage_args cons
     }
   }
 }
+
+// one launch among the four (NARROW, MASKED) variants of a kernel template
+#define CUDF_AMD_DENSE_VARIANT(KERNEL, a, grid, stream, ...)                                                                         \
+  do {                                                                                                                               \
+    bool const narrow_ = (a).key_width == 4, masked_ = (a).mask != nullptr;                                                          \
+    if (narrow_ && masked_) hipLaunchKernelGGL((KERNEL<true, true>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                 \
+    else if (narrow_) hipLaunchKernelGGL((KERNEL<true, false>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                      \
+    else if (masked_) hipLaunchKernelGGL((KERNEL<false, true>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                      \
+    else hipLaunchKernelGGL((KERNEL<false, false>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                                  \
+  } while (0)
 
 }  // namespace
 
@@ -286,7 +289,7 @@ void launch_dense_left_direct(dense_stage_args const& a, dense_stage_args* d_arg
   hipLaunchKernelGGL(k_store_dense_stage_args, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_retrieve", stream};
   unsigned const grid = static_cast<unsigned>(std::clamp<int64_t>((a.nrows + 2047) / 2048, 1, 8192));
-  hipLaunchKernelGGL(k_dense_left_direct, dim3(grid), dim3(256), 0, stream, d_args, out_probe, out_build);
+  CUDF_AMD_DENSE_VARIANT(k_dense_left_direct, a, grid, stream, d_args, out_probe, out_build);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
@@ -297,7 +300,7 @@ void launch_dense_probe_staged(dense_stage_args const& a, dense_stage_args* d_ar
                "dense join, ordered probe: arguments");
   hipLaunchKernelGGL(k_store_dense_stage_args, dim3(1), dim3(1), 0, stream, a, d_args);
   cudf::detail::prof::scope prof_{"join_count", stream};
-  hipLaunchKernelGGL(k_dense_probe_staged, dim3((a.nwaves + 3) / 4), dim3(256), 0, stream, d_args);
+  CUDF_AMD_DENSE_VARIANT(k_dense_probe_staged, a, (a.nwaves + 3) / 4, stream, d_args);
   CUDF_HIP_TRY(hipGetLastError());
 }
 
