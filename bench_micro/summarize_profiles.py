@@ -38,12 +38,25 @@ def label_map():
             sc = re.search(r'prof::scope \w+\{([^}]*)\}', line)
             if sc:
                 label = re.findall(r'"([a-z0-9_]+)"', sc.group(1))
-            for k in re.findall(r'hipLaunchKernelGGL\(\(?\s*(k_[A-Za-z0-9_]+)', line):
+            for k in re.findall(r'hipLaunchKernelGGL\(\(?\s*(k_[A-Za-z0-9_]+)', line) + re.findall(r'CUDF_AMD_DENSE_VARIANT\((k_[A-Za-z0-9_]+)', line):
                 if label:
                     m.setdefault(k, set()).update(label)
             if line.startswith("}"):
                 label = None
     return {k: sorted(v) for k, v in m.items()}
+
+
+def labels_for(full, kernel, targs, labels_of):
+    """Profiler labels of one dispatch. Two kernel names serve two labels each, told apart by their first template argument (the level),
+    and one name (k_radix_scatter) exists in two namespaces (the joins' ring scatter, the sort-based groupby's radix pass)."""
+    first = targs[1:].split(",")[0].strip() if targs else ""
+    if kernel == "k_radix_scatter":
+        if "join" in full:
+            return ["join_partition_level2" if first == "2" else "join_partition"]
+        return ["sort_scatter"]
+    if kernel == "k_dense_ring_scatter":
+        return ["partition_scatter_level2" if first == "2" else "partition_scatter"]
+    return labels_of.get(kernel, [])
 
 
 def config_traffic():
@@ -56,7 +69,7 @@ def config_traffic():
     doc["sources_sha256"] = sources_sha256()
     doc["how"] += ("; `labels`: HBM bytes per STEP of the kernels that run under each profiler label of the library (the names bench.py's "
                    "`roofline.kernel` carries), = sum over their dispatches / 3 runs (2 steps + 1 warm-up); a kernel that runs under two "
-                   "labels (k_radix_join: count and retrieve) is charged to both")
+                   "labels (k_radix_join: count and retrieve) is charged to both; the two levels of a ring scatter are told apart by the kernel's first template argument")
     doc["labels"] = {}
     RUNS = 3
     for c in ("c3", "c3sparse", "c3inrange", "c4"):
@@ -76,7 +89,7 @@ def config_traffic():
                 acc[name][0] += float(r["Counter_Value"])
                 acc[name][1].add(r.get("Dispatch_Id"))
                 if m:
-                    for l in labels_of.get(m.group(1), []):
+                    for l in labels_for(full, m.group(1), m.group(2) or "", labels_of):
                         lab[l] += float(r["Counter_Value"]) * 1024 * (2 if counter == "FETCH_SIZE" else 1) / RUNS
             for k, (tot, ids) in acc.items():
                 per.setdefault(k, {})[counter + "_KB_per_launch"] = tot / max(1, len(ids))
