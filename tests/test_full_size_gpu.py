@@ -113,3 +113,46 @@ def test_c4_full_size(gpu):
     # per-group reference (counts by bincount, sums by scatter_add_, min / max by scatter_reduce_), not global properties
     assert checks["all_ok"] and checks["global_max_ok"] and checks["global_min_ok"] and checks["mean_within_min_max"], checks
     torch.cuda.empty_cache()
+
+
+def test_sort_groupby_at_two_hundred_million_rows(gpu):
+    """The sort-based path (MEDIAN / NTH_ELEMENT / NUNIQUE + a SUM riding along) at 200M rows on 1M groups, against torch on the same rows:
+    the unique keys ascend, NTH_ELEMENT(0) = the value of every key's FIRST row (the key sort is stable), NTH_ELEMENT(-1) its last,
+    NUNIQUE = the distinct values per key (values drawn from 1000 levels), MEDIAN = the middle of the group's sorted values (stable
+    torch sorts by value, then by key), counts exact."""
+    import torch
+    import cudf_amd
+    from cudf_amd import aggregation as agg, groupby as gb
+    from cudf_amd.types import NullPolicy
+    dev = torch.device("cuda", 0)
+    n, groups = 200_000_000, 1_000_000
+    g = torch.Generator(device=dev).manual_seed(7)
+    k = torch.randint(0, groups, (n,), generator=g, device=dev, dtype=torch.int64)
+    v = torch.randint(0, 1000, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.float64) * 0.25 - 100.0
+    grp = gb.GroupBy(cudf_amd.Table([cudf_amd.Column.from_torch(k)]))
+    uk, res = grp.aggregate([gb.GroupByRequest(cudf_amd.Column.from_torch(v), [agg.median(), agg.nth_element(0), agg.nth_element(-1), agg.nunique(),
+                                                                           agg.sum(), agg.count(NullPolicy.INCLUDE)])],
+                            stream=torch.cuda.current_stream())
+    assert grp.last_path.name == "SORT"
+    keys = uk.columns()[0].to_torch()
+    med, first, last, nuniq, s, cnt = [c.to_torch() for c in res[0].columns()]
+    exp_c = torch.bincount(k, minlength=groups)
+    assert bool((exp_c > 0).all()) and keys.numel() == groups and bool((keys == torch.arange(groups, device=dev)).all())
+    assert bool((cnt.to(torch.int64) == exp_c).all())
+    by_value = torch.sort(v, stable=True)
+    by_key = torch.sort(k[by_value.indices], stable=True)          # rows in (key, value) order
+    vs = by_value.values[by_key.indices]
+    del by_value, by_key
+    off = torch.cumsum(exp_c, 0) - exp_c
+    lo, hi = off + (exp_c - 1) // 2, off + exp_c // 2               # the two middle elements (equal for odd sizes)
+    assert bool((med == 0.5 * vs[lo] + 0.5 * vs[hi]).all())          # quantiles_util.hpp linear(): (1 - 0.5) * lo + 0.5 * hi
+    distinct = torch.ones(n, dtype=torch.int64, device=dev)
+    distinct[1:] = (vs[1:] != vs[:-1]).to(torch.int64)
+    distinct[off] = 1
+    assert bool((nuniq.to(torch.int64) == torch.zeros(groups, dtype=torch.int64, device=dev).scatter_add_(0, torch.repeat_interleave(
+        torch.arange(groups, device=dev), exp_c), distinct)).all())
+    del vs, distinct
+    order = torch.sort(k, stable=True).indices                      # rows in key order, original order inside a key
+    assert bool((first == v[order[off]]).all()) and bool((last == v[order[off + exp_c - 1]]).all())
+    exp_s = torch.zeros(groups, dtype=torch.float64, device=dev).scatter_add_(0, k, v)
+    assert float((s - exp_s).abs().max()) <= float(exp_c.max()) ** 2 * np.finfo(np.float64).eps * 150.0
