@@ -700,7 +700,11 @@ struct helper {
 
   helper(table_view const& k, hipStream_t stream) : keys{k}, dkeys{cudf::detail::make_device_table(k)}, keep{stream, get_current_device_resource_ref(), {}}, s{stream} {}
 
-  void build(bool exclude_null_keys, bool presorted)
+  // inner_values: a values column whose order INSIDE the groups is wanted and nobody needs the rows of a group in their original
+  // order (no NTH_ELEMENT in the call): its words are sorted first, the key columns after them - one sort yields the groups AND that
+  // column's (key, null, value) order, instead of a key sort plus a second sort by (label, null, value): 11 instead of 14 passes and
+  // one gather instead of two at 100M rows on 1M groups.
+  void build(bool exclude_null_keys, bool presorted, column_view const* inner_values = nullptr)
   {
     n = keys.num_rows();
     bool const keys_have_nulls = std::any_of(keys.begin(), keys.end(), [](auto const& c) { return c.has_nulls(); });
@@ -714,6 +718,30 @@ struct helper {
     {
       scratch sort_tmp{s, get_current_device_resource_ref(), {}};
       pair_sorter sorter{n, sort_tmp, s};
+      if (!presorted && inner_values != nullptr) {
+        fill_args fa{};
+        fa.col    = cudf::detail::make_device_column(*inner_values);
+        fa.n      = n;
+        fa.or_and = sorter.or_and();
+        fa.source = WORD_VALUE;
+        sorter.reset_reduction();
+        fa.payload = sorter.payload();
+        fa.words   = sorter.words();
+        {
+          prof::scope p_{"sort_words", s};
+          hipLaunchKernelGGL(k_fill_words, dim3(fill_grid(n)), dim3(256), 0, s, fa);
+        }
+        sorter.sort_filled();
+        if (inner_values->has_nulls()) {  // nulls after the values
+          sorter.reset_reduction();
+          fa.source  = WORD_NULL_FLAG;
+          fa.payload = sorter.payload();
+          fa.words   = sorter.words();
+          hipLaunchKernelGGL(k_fill_words, dim3(fill_grid(n)), dim3(256), 0, s, fa);
+          sorter.sort_filled();
+        }
+        _value_orders_in_key_order = std::make_pair(inner_values->head(), inner_values->offset());
+      }
       if (!presorted) {
         for (int c = dkeys.ncols - 1; c >= 0; --c) {
           fill_args fa{};
@@ -786,6 +814,7 @@ struct helper {
   uint32_t* value_order(column_view const& values)
   {
     auto const key = std::make_pair(values.head(), values.offset());
+    if (_value_orders_in_key_order == key) return order;  // (build() sorted this column's words before the keys)
     if (auto it = _value_orders.find(key); it != _value_orders.end()) return it->second;
     auto* vrow = keep.alloc<uint32_t>(static_cast<std::size_t>(nk));
     {
@@ -833,6 +862,7 @@ struct helper {
 
  private:
   std::map<std::pair<void const*, size_type>, uint32_t*> _value_orders;
+  std::pair<void const*, size_type> _value_orders_in_key_order{nullptr, 0};
 };
 
 std::unique_ptr<column> int32_column(int64_t size, stream_ref stream, rmm::device_async_resource_ref mr)
@@ -870,7 +900,17 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> sort_aggregat
   hipStream_t const s = stream.value();
   CUDF_EXPECTS(keys.num_columns() > 0, "The sort-based groupby needs at least one key column.");
   helper h{keys, s};
-  h.build(include_null_keys == null_policy::EXCLUDE, keys_are_sorted);
+  // which order the one sort should produce (helper::build)
+  column_view const* inner_values = nullptr;
+  bool any_nth                    = false;
+  for (auto const& r : requests)
+    for (auto const& a : r.aggregations) {
+      any_nth = any_nth || a->kind == aggregation::NTH_ELEMENT;
+      if (inner_values == nullptr && (a->kind == aggregation::MEDIAN || a->kind == aggregation::QUANTILE || a->kind == aggregation::NUNIQUE) &&
+          r.values.size() == keys.num_rows() && r.values.head() != nullptr)
+        inner_values = &r.values;
+    }
+  h.build(include_null_keys == null_policy::EXCLUDE, keys_are_sorted, any_nth ? nullptr : inner_values);
   int32_t const G = h.G;
 
   std::vector<aggregation_result> results(requests.size());
