@@ -18,6 +18,7 @@
 #include <cudf/utilities/error.hpp>
 
 #include <chrono>
+#include <optional>
 #include <span>
 #include <string>
 #include <vector>
@@ -138,6 +139,12 @@ inline bool is_sort_kind(aggregation::Kind k)
 {
   return k == aggregation::MEDIAN || k == aggregation::QUANTILE || k == aggregation::NUNIQUE || k == aggregation::NTH_ELEMENT;
 }
+// ARGMIN / ARGMAX over one integer key column of a small range as MIN / MAX + one lookup pass over the rows (arg_lookup.hip); nullopt: not
+// such a call (the engine's own ARGMIN / ARGMAX). *path = the path of the MIN / MAX call.
+std::optional<std::pair<std::unique_ptr<table>, std::vector<aggregation_result>>> arg_by_lookup(table_view const& keys, null_policy include_null_keys,
+                                                                                              std::span<aggregation_request const> requests,
+                                                                                              stream_ref stream, rmm::device_async_resource_ref mr,
+                                                                                              hash_path* path);
 // The sort-based groupby (reference cpp/src/groupby/sort/aggregate.cpp:798-830, sort_helper.cu): radix-sorts the rows by key,
 // labels the groups and serves every request of the call; the unique keys come back in ascending order, nulls last.
 std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> sort_aggregate(table_view const& keys, null_policy include_null_keys,

@@ -230,6 +230,8 @@ std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> groupby::aggr
     _last_path = hash_path::SORT;
     return sort_aggregate(_keys, _include_null_keys, _keys_are_sorted == sorted::YES, requests, stream, mr);
   }
+  // ARGMIN / ARGMAX over one integer key column of a small range: MIN / MAX (on whatever path those take) + one lookup pass (arg_lookup.hip)
+  if (auto answered = arg_by_lookup(_keys, _include_null_keys, requests, stream, mr, &_last_path)) return std::move(*answered);
   // plan -> estimate -> attempts (one executor per path: call.hpp) -> result columns
   aggregate_call call{_keys, _include_null_keys, requests, stream.value()};
   try {

@@ -916,3 +916,47 @@ def test_all_nan_group_min_max_argmin_argmax_pinned(G):
     assert mn[0] == np.inf and mx[0] == -np.inf and amn[0] == -1 and amx[0] == -1
     assert mn[1:].tolist() == [5.0, 7.0] and mx[1:].tolist() == [5.0, 7.0]
     assert amn[1:].tolist() == [3, 5] and amx[1:].tolist() == [3, 5]
+
+
+@pytest.mark.parametrize("include", [False, True])
+@pytest.mark.parametrize("ktype,vtype", [("int64", "float64"), ("int32", "int32"), ("uint8", "float32"), ("int16", "int64"), ("int64", "bool"),
+                                         ("int32", "timestamp_ms")])
+def test_argmin_argmax_by_lookup(G, oracle, monkeypatch, ktype, vtype, include):
+    """ARGMIN / ARGMAX over one integer key column of a small range are answered as MIN / MAX + one lookup pass over the rows (round 4,
+    arg_lookup.hip) from CUDF_AMD_GB_BIG_MIN_ROWS rows on: the smallest row among those that attain the extreme (ties on purpose: values from
+    a small pool), NULL keys (their own group under INCLUDE), NULL values, a group without a valid value (null), NaN / -0.0 / +0.0 among the
+    floats, negative keys, other kinds and a repeated ARGMIN in the same call - against the oracle and against the engine's own ARGMIN / ARGMAX."""
+    from oracle.oracle import HostColumn, NP_OF_TYPE_ID, TYPE_ID
+    rng = np.random.default_rng(["int64", "int32", "uint8", "int16"].index(ktype) * 16 + len(vtype) + (7 if include else 0))
+    n = 60_000
+    kdt, vdt = NP_OF_TYPE_ID[TYPE_ID[ktype]], NP_OF_TYPE_ID[TYPE_ID[vtype]]
+    klo = -40 if np.dtype(kdt).kind == "i" else 0
+    k = rng.integers(klo, klo + 97, n).astype(kdt)
+    kvalid = rng.random(n) > 0.05
+    vvalid = rng.random(n) > 0.2
+    vvalid[k == k[0]] = False  # one group without any valid value
+    keys = [HostColumn(k, kvalid, ktype)]
+    monkeypatch.setenv("CUDF_AMD_GB_BIG_MIN_ROWS", "1000")
+    # with_nan: a NaN among a group's values makes the REFERENCE's answer depend on the arrival order of its atomics (the oracle follows row
+    # order: a group whose first valid value is NaN keeps that row) - such data is compared with the engine's own ARGMIN / ARGMAX only
+    for with_nan in (False, True):
+        if np.dtype(vdt).kind == "f":
+            pool = np.concatenate([rng.normal(size=20), [-0.0, 0.0, np.inf, -np.inf] + ([np.nan] if with_nan else [])]).astype(vdt)
+            v = pool[rng.integers(0, len(pool), n)]
+        elif np.dtype(vdt).kind == "b":
+            v = rng.integers(0, 2, n).astype(np.uint8)
+        else:
+            v = rng.integers(-7, 8, n).astype(vdt)
+        vals = HostColumn(v, vvalid, vtype)
+        requests = [(vals, ["argmin", "argmax", "min", "count_valid", "argmin"]),
+                    (HostColumn(v, None, vtype), ["argmax", "sum" if vtype != "timestamp_ms" else "max"])]
+        monkeypatch.delenv("CUDF_AMD_GB_ARG_LOOKUP", raising=False)
+        if not with_nan:
+            _check_against_oracle(G, oracle, keys, requests, include=include)
+        by_lookup = kat.sort_groups(*G.groupby(keys, requests, include_null_keys=include))
+        monkeypatch.setenv("CUDF_AMD_GB_ARG_LOOKUP", "0")
+        by_engine = kat.sort_groups(*G.groupby(keys, requests, include_null_keys=include))
+        for (_, kinds), ra, rb in zip(requests, by_lookup[1], by_engine[1]):
+            for kind, a, b in zip(kinds, ra, rb):
+                if kind != "sum":  # (float sums: order-dependent; the oracle comparison above bounds them)
+                    kat.compare_columns(a, b, f"lookup against the engine [{kind}]")
