@@ -145,6 +145,8 @@ std::optional<std::pair<std::unique_ptr<table>, std::vector<aggregation_result>>
                                                                                               std::span<aggregation_request const> requests,
                                                                                               stream_ref stream, rmm::device_async_resource_ref mr,
                                                                                               hash_path* path);
+// (sort_groupby.hip) the number of runs of equal adjacent key rows, nulls equal nulls
+int64_t count_key_runs(table_view const& keys, stream_ref stream);
 // The sort-based groupby (reference cpp/src/groupby/sort/aggregate.cpp:798-830, sort_helper.cu): radix-sorts the rows by key,
 // labels the groups and serves every request of the call; the unique keys come back in ascending order, nulls last.
 std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> sort_aggregate(table_view const& keys, null_policy include_null_keys,

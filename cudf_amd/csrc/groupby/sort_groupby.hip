@@ -715,7 +715,9 @@ struct helper {
     scratch tmp{s, get_current_device_resource_ref(), {}};
     auto* flags       = tmp.alloc<uint32_t>(static_cast<std::size_t>(n));
     bool flags_filled = false;
-    {
+    if (presorted) {  // the rows as they lie: no sorter, no scratch for one
+      hipLaunchKernelGGL(k_iota, dim3(blocks_of(n)), dim3(256), 0, s, order, n);
+    } else {
       scratch sort_tmp{s, get_current_device_resource_ref(), {}};
       pair_sorter sorter{n, sort_tmp, s};
       if (!presorted && inner_values != nullptr) {
@@ -891,6 +893,37 @@ std::unique_ptr<column> reorder(column_view const& c, column_view const& where, 
   return std::move(t->release()[0]);
 }
 }  // namespace
+
+namespace {
+__global__ void __launch_bounds__(256) k_count_runs(device_table keys, int64_t n, unsigned long long* out)
+{
+  unsigned long long mine = 0;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * 256)
+    mine += (i == 0 || !cudf::detail::rows_equal(keys, i - 1, keys, i, true)) ? 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+}  // namespace
+
+// the number of runs of equal adjacent key rows (nulls equal nulls): one coalesced pass over the key columns
+int64_t count_key_runs(table_view const& keys, stream_ref stream)
+{
+  int64_t const n = keys.num_rows();
+  if (n == 0) return 0;
+  hipStream_t const s = stream.value();
+  rmm::device_buffer d{sizeof(unsigned long long), s, get_current_device_resource_ref()};
+  CUDF_HIP_TRY(hipMemsetAsync(d.data(), 0, sizeof(unsigned long long), s));
+  {
+    prof::scope p_{"sort_boundaries", s};
+    hipLaunchKernelGGL(k_count_runs, dim3(static_cast<unsigned>(std::min<int64_t>((n + 255) / 256, 256 * 32))), dim3(256), 0, s,
+                       cudf::detail::make_device_table(keys), n, static_cast<unsigned long long*>(d.data()));
+  }
+  CUDF_HIP_TRY(hipGetLastError());
+  unsigned long long h = 0;
+  CUDF_HIP_TRY(hipMemcpyAsync(&h, d.data(), sizeof(h), hipMemcpyDeviceToHost, s));
+  CUDF_HIP_TRY(hipStreamSynchronize(s));
+  return static_cast<int64_t>(h);
+}
 
 std::pair<std::unique_ptr<table>, std::vector<aggregation_result>> sort_aggregate(table_view const& keys, null_policy include_null_keys,
                                                                                   bool keys_are_sorted,

@@ -29,6 +29,7 @@ struct aggregation_result {
 };
 
 // Which kernel family served the last aggregate() call (repo addition, for tests and benchmarks).
+// (SORT: the sort-based groupby - MEDIAN / QUANTILE / NUNIQUE / NTH_ELEMENT, or pre-sorted keys whose runs are not the distinct keys)
 enum class hash_path : int32_t { NONE = 0, LDS_SINGLE_PASS = 1, PARTITIONED_LDS = 2, GLOBAL_TABLE = 3, DENSE_DIRECT = 4, SORT = 5 };
 
 class groupby {

@@ -25,7 +25,9 @@ def SG():
 @pytest.mark.parametrize("name,c,kt,vt", list(kat.sort_groupby_cases()), ids=[x[0] for x in kat.sort_groupby_cases()])
 def test_sort_groupby_kat(G, name, c, kt, vt):
     kat.run_sort_groupby_case(G, c, kt, vt)
-    if len(c["keys"]):
+    if len(c["keys"]) and isinstance(c["agg"], dict):  # (a pre-sorted-keys case with a hash kind is answered by the hash path where runs == keys)
+        assert G.last_path.name == "SORT"
+    if c["name"] == "pre_sorted_keys_nulls_before_include_nulls":  # the claim is wrong there: the call is redone on the runs
         assert G.last_path.name == "SORT"
 
 
